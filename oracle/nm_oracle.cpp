@@ -1,0 +1,598 @@
+/*
+ * oracle/nm_oracle.cpp -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement of the SIFT detect/describe + brute-force L2 match path of gift-surg/NiftyMatch
+ * (reference tree at /root/reference, cited below as path:line relative to src/gpu/). It is the parity checker
+ * for the HIP library and the timed CPU baseline of bench.py. Nothing in the product links, imports or calls it;
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load liboracle.
+ *
+ * PARITY UNPINNED: the reference ships no tests, fixtures or golden vectors for this path (its tests live in a
+ * private external repo, CONTRIBUTING.md:7,17) and is CUDA-only, so it cannot be compiled or run here. This file
+ * is pinned by hand-derived known-answer tests (tests/test_oracle_kat.py) and by the Q-table of SURVEY.md 8(a),
+ * which fixes every place where the reference's behaviour is undefined (races, atomics order, stale memory).
+ *
+ * Floating-point contract (shared with the HIP kernels, see DESIGN.md "fp spec"):
+ *   - compiled with -ffp-contract=off; every fused multiply-add is an explicit fmaf()/fma() below. The places
+ *     where nvcc (-fmad=true default) would contract a*b+c are written as the fma LLVM's DAG combiner produces:
+ *     (a*b + c*d) -> fma(a,b,c*d); (x - y*z) -> fma(-y,z,x).
+ *   - mixed float/double expressions keep the reference's C++ promotion rules literally.
+ *   - device libm calls go through oracle/nmo_math.h (one fixed implementation inside CUDA's documented ulp bounds).
+ *   - atomics with undefined order get ONE fixed order, stated at each site.
+ */
+#include "nmo_math.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define NMO_API extern "C" __attribute__((visibility("default")))
+
+static const double NMO_2PI_D = 6.283185307179586476925286766559;   /* 2*M_PI */
+static const float  NMO_2PI_F = (float)(2 * 3.14159265358979323846);
+
+/* ---------------------------------------------------------------------------------------------------------- */
+/* threading control (bench.py's cpu_baseline reports the thread count it used)                                */
+NMO_API int nmo_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n; return 1;
+#endif
+}
+
+/* ---------------------------------------------------------------------------------------------------------- */
+/* SiftParams -- sift/siftparams.h:30-51                                                                       */
+struct nmo_params {
+    int width, height, num_octaves, num_dog_levels, level_max, level_min;
+    float sigma_d_0, sigma_k, sigma_0, sigma_n, base_smooth, peak_threshold, edge_threshold;
+    float sigmas[8];
+    int num_sigmas;
+};
+
+NMO_API void nmo_sift_params(int width, int height, nmo_params *p)
+{
+    std::memset(p, 0, sizeof(*p));
+    p->width = width; p->height = height;
+    p->num_dog_levels = 3; p->sigma_n = 0.5f; p->peak_threshold = 0.f; p->edge_threshold = 10.f;
+    p->level_max = p->num_dog_levels + 1;
+    p->level_min = -1;
+    /* siftparams.h:36 -- MINIMUM_OCTAVE_SIZE 32 */
+    p->num_octaves = (int)std::floor(std::log(std::min(width, height) * 2.0 / 32) / std::log(2.0));
+    if (p->num_octaves <= 0) p->num_octaves = 1;
+    /* :39  std::pow(float,float) -> float */
+    p->sigma_k = std::pow(2.0f, 1.0f / p->num_dog_levels);
+    p->sigma_0 = 1.6f * p->sigma_k;
+    /* :41  float * double sqrt -> narrowed */
+    p->sigma_d_0 = (float)((double)p->sigma_0 * std::sqrt(1.0 - 1.0 / (double)(p->sigma_k * p->sigma_k)));
+    /* :43  std::pow(float,int) promotes to double */
+    float sa = (float)((double)p->sigma_0 * std::pow((double)p->sigma_k, (double)p->level_min));
+    float sb = p->sigma_n;
+    if (sa > sb) p->base_smooth = std::sqrt(sa * sa - sb * sb);
+    p->num_sigmas = 0;
+    for (int i = p->level_min + 1; i <= p->level_max; ++i)
+        p->sigmas[p->num_sigmas++] = (float)((double)p->sigma_d_0 * std::pow((double)p->sigma_k, (double)i));
+}
+
+/* PyramidData::create_kernel_for_sigma -- sift/pyramidata.cu:105-123. taps must hold 2*ceil(4*sigma)+1 floats. */
+NMO_API int nmo_create_kernel_for_sigma(float sigma, float *taps)
+{
+    const int r = (int)(std::ceil(sigma * 4));
+    const int len = 2 * r + 1;
+    float sum = 0.f;
+    for (int j = 0; j < len; ++j) {
+        float val = ((float)j - r) / sigma;
+        val = (float)std::exp(-0.5 * (val * val));      /* host double exp, as the reference */
+        if (taps) taps[j] = val;
+        sum += val;
+    }
+    if (taps) for (int j = 0; j < len; ++j) taps[j] = taps[j] / sum;
+    return r;
+}
+
+/* ---------------------------------------------------------------------------------------------------------- */
+/* convolve -- kernels/convolution.cu:16-159. Zero padding (Q2), taps k=-r..r, sum = fma(x, w[r-k], sum) from 0,
+ * rows into `buffer`, then columns of `buffer` into `result`. Q3: every pixel written exactly once.           */
+NMO_API void nmo_convolve(float *result, const float *image, float *buffer, int width, int height,
+                          const float *kernel, int r)
+{
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < height; ++y) {
+        const float *row = image + (size_t)y * width;
+        float *out = buffer + (size_t)y * width;
+        for (int x = 0; x < width; ++x) {
+            float sum = 0.f;
+            for (int k = -r; k <= r; ++k) {
+                const int xx = x + k;
+                const float v = (xx >= 0 && xx < width) ? row[xx] : 0.f;
+                sum = std::fmaf(v, kernel[r - k], sum);
+            }
+            out[x] = sum;
+        }
+    }
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < height; ++y) {
+        float *out = result + (size_t)y * width;
+        for (int x = 0; x < width; ++x) {
+            float sum = 0.f;
+            for (int k = -r; k <= r; ++k) {
+                const int yy = y + k;
+                const float v = (yy >= 0 && yy < height) ? buffer[(size_t)yy * width + x] : 0.f;
+                sum = std::fmaf(v, kernel[r - k], sum);
+            }
+            out[x] = sum;
+        }
+    }
+}
+
+/* downsample_by_2 -- kernels/downsample.cu:6-17 */
+NMO_API void nmo_downsample2(float *result, int rw, int rh, const float *source, int sw, int sh)
+{
+    (void)sh;
+    for (int y = 0; y < rh; ++y)
+        for (int x = 0; x < rw; ++x)
+            result[(size_t)y * rw + x] = source[(size_t)(y * 2) * sw + (x * 2)];
+}
+
+/* subtract -- kernels/cudamath.cu:26-35 : C = A - B */
+NMO_API void nmo_subtract(const float *A, const float *B, float *C, int width, int height)
+{
+    const size_t n = (size_t)width * height;
+    for (size_t i = 0; i < n; ++i) C[i] = A[i] - B[i];
+}
+
+static inline float nmo_mod_2pi_f(float x)          /* kernels/cudamath.h:82-87 */
+{
+    while (x > NMO_2PI_F) x -= NMO_2PI_F;
+    while (x < 0.0f) x += NMO_2PI_F;
+    return x;
+}
+
+/* gradient -- kernels/cudamath.cu:38-54. grad is float2 (mag, angle). Border pixels = (0,0) (Q4). Q5 types. */
+NMO_API void nmo_gradient(const float *src, float *grad, int width, int height)
+{
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < height; ++y) {
+        for (int x = 0; x < width; ++x) {
+            float *g2 = grad + 2 * ((size_t)y * width + x);
+            if (x < 1 || x >= width - 1 || y < 1 || y >= height - 1) { g2[0] = 0.f; g2[1] = 0.f; continue; }
+            const float nx = src[(size_t)y * width + x + 1], px = src[(size_t)y * width + x - 1];
+            const float ny = src[(size_t)(y + 1) * width + x], py = src[(size_t)(y - 1) * width + x];
+            const float dx = nx - px, dy = ny - py;
+            const float g = (float)(0.5 * (double)std::sqrt(std::fmaf(dx, dx, dy * dy)));
+            float r = 0.0f;
+            if (g != 0.0f) r = nmo_mod_2pi_f((float)((double)nmo_atan2f(dy, dx) + NMO_2PI_D));
+            g2[0] = g; g2[1] = r;
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------------------- */
+/* keypoints -- kernels/keypoint.cu:19-201. Planes are plain row-major arrays: the reference's texture fetches
+ * at (x+0.5, y+0.5) with linear filtering are exact texel loads (gpu/utils/cudatex2D.cu:15-19).               */
+struct nmo_f4 { float x, y, z, w; };
+
+template <bool GT>
+static inline bool nmo_is_extremum(const float *cur, const float *dn, const float *up, int x, int y, int w)
+{
+    const float cv = cur[(size_t)y * w + x];
+    const float *planes[3] = {cur, dn, up};
+    for (int p = 0; p < 3; ++p)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                if (p == 0 && dx == 0 && dy == 0) continue;
+                const float pv = planes[p][(size_t)(y + dy) * w + (x + dx)];
+                if (GT ? !(cv > pv) : !(cv < pv)) return false;
+            }
+    return true;
+}
+
+/* keypoint.cu:108-180 (Q7). Returns true and fills out[4] when the candidate is accepted. */
+static inline bool nmo_refine(const float *cur, const float *dn, const float *up, int x, int y, int w,
+                              float peak, float edge, float xper, float sigma0, int num_dogs, int level,
+                              float *out)
+{
+#define C_(dx, dy) cur[(size_t)(y + (dy)) * w + (x + (dx))]
+#define D_(dx, dy) dn[(size_t)(y + (dy)) * w + (x + (dx))]
+#define U_(dx, dy) up[(size_t)(y + (dy)) * w + (x + (dx))]
+    const float c = C_(0, 0);
+    const float fx = (float)(0.5 * (double)(C_(1, 0) - C_(-1, 0)));
+    const float fy = (float)(0.5 * (double)(C_(0, 1) - C_(0, -1)));
+    const float fs = (float)(0.5 * (double)(U_(0, 0) - D_(0, 0)));
+    const float fxx = (float)((double)(C_(1, 0) + C_(-1, 0)) - 2.0 * (double)c);
+    const float fyy = (float)((double)(C_(0, 1) + C_(0, -1)) - 2.0 * (double)c);
+    const float fss = (float)((double)(U_(0, 0) + D_(0, 0)) - 2.0 * (double)c);
+    const float fxy = (float)(0.25 * (double)(((C_(1, 1) + C_(-1, -1)) - C_(-1, 1)) - C_(1, -1)));
+    const float fxs = (float)(0.25 * (double)(((U_(1, 0) + D_(-1, 0)) - U_(-1, 0)) - D_(1, 0)));
+    const float fys = (float)(0.25 * (double)(((U_(0, 1) + D_(0, -1)) - U_(0, -1)) - D_(0, 1)));
+#undef C_
+#undef D_
+#undef U_
+    nmo_f4 A0 = fxx > 0 ? nmo_f4{fxx, fxy, fxs, -fx} : nmo_f4{-fxx, -fxy, -fxs, fx};
+    nmo_f4 A1 = fxy > 0 ? nmo_f4{fxy, fyy, fys, -fy} : nmo_f4{-fxy, -fyy, -fys, fy};
+    nmo_f4 A2 = fxs > 0 ? nmo_f4{fxs, fys, fss, -fs} : nmo_f4{-fxs, -fys, -fss, fs};
+    nmo_f4 t;
+    const float max_a = std::fmax(std::fmax(A0.x, A1.x), A2.x);
+    if (!((double)max_a >= 1e-10)) return false;
+    if (max_a == A1.x)      { t = A1; A1 = A0; A0 = t; }
+    else if (max_a == A2.x) { t = A2; A2 = A0; A0 = t; }
+    A0.y /= A0.x; A0.z /= A0.x; A0.w /= A0.x;
+    A1.y = std::fmaf(-A1.x, A0.y, A1.y); A1.z = std::fmaf(-A1.x, A0.z, A1.z); A1.w = std::fmaf(-A1.x, A0.w, A1.w);
+    A2.y = std::fmaf(-A2.x, A0.y, A2.y); A2.z = std::fmaf(-A2.x, A0.z, A2.z); A2.w = std::fmaf(-A2.x, A0.w, A2.w);
+    if (std::fabs(A2.y) > std::fabs(A1.y)) { t = A2; A2 = A1; A1 = t; }
+    if (!((double)std::fabs(A1.y) >= 1e-10)) return false;
+    A1.z /= A1.y; A1.w /= A1.y;
+    A2.z = std::fmaf(-A2.y, A1.z, A2.z); A2.w = std::fmaf(-A2.y, A1.w, A2.w);
+    if (!((double)std::fabs(A2.z) >= 1e-10)) return false;
+    const float ds = A2.w / A2.z;
+    const float dy = std::fmaf(-ds, A1.z, A1.w);
+    const float dx = std::fmaf(-dy, A0.y, std::fmaf(-ds, A0.z, A0.w));
+    const float tt = std::fmaf(ds, fs, std::fmaf(dx, fx, dy * fy));
+    const float v = (float)((double)c + 0.5 * (double)tt);
+    const float tr = fxx + fyy;
+    const float s = (tr * tr) / std::fmaf(fxx, fyy, -(fxy * fxy));
+    const float ethr = ((edge + 1) * (edge + 1)) / edge;
+    if ((std::fabs(v) > peak) && s < ethr && std::fabs(dx) < 1 && std::fabs(dy) < 1 && std::fabs(ds) < 1) {
+        out[0] = ((float)x + dx) * xper;
+        out[1] = ((float)y + dy) * xper;
+        out[2] = (float)(((double)sigma0 * nmo_exp2((double)((float)level + ds) / (double)num_dogs)) * (double)xper);
+        out[3] = (float)level;
+        return true;
+    }
+    return false;
+}
+
+/* CUDA bilinear fetch of the full-resolution mask at texture coordinate (u,v), border addressing, unnormalised
+ * (cudatex2D.cu:15-19, keypoint.cu:214). The hardware keeps 8 fractional bits; for xper = 2^o the fractional
+ * part is 0 (o = 0) or 0.5 (o >= 1), both exact in 1.8 fixed point.                                           */
+static inline float nmo_mask_fetch(const float *mask, int mw, int mh, float u, float v)
+{
+    const float xb = u - 0.5f, yb = v - 0.5f;
+    const float fi = std::floor(xb), fj = std::floor(yb);
+    const float a = xb - fi, b = yb - fj;
+    const int i = (int)fi, j = (int)fj;
+    auto T = [&](int ii, int jj) -> float {
+        return (ii >= 0 && ii < mw && jj >= 0 && jj < mh) ? mask[(size_t)jj * mw + ii] : 0.f;
+    };
+    return (1 - a) * (1 - b) * T(i, j) + a * (1 - b) * T(i + 1, j) + (1 - a) * b * T(i, j + 1) + a * b * T(i + 1, j + 1);
+}
+
+/* find_keypoints -- keypoint.cu:183-251. `result` is the dense W*H float4 map the CALLER pre-filled with -1
+ * (siftfunctions.cu:120-121); only accepted pixels are written. mask == NULL -> unmasked overload.          */
+NMO_API void nmo_find_keypoints(const float *cur, const float *dn, const float *up, const float *mask, int mask_w,
+                                int mask_h, int width, int height, float peak, float edge, float xper,
+                                float sigma0, int num_dogs, int level, float *result)
+{
+#pragma omp parallel for schedule(static)
+    for (int y = 1; y <= height - 2; ++y) {
+        for (int x = 1; x <= width - 2; ++x) {
+            if (mask && nmo_mask_fetch(mask, mask_w, mask_h, ((float)x + 0.5f) * xper, ((float)y + 0.5f) * xper) < 1.f)
+                continue;
+            const float c = cur[(size_t)y * width + x];
+            const float thr = 0.8f * peak;
+            if ((c <= thr && nmo_is_extremum<false>(cur, dn, up, x, y, width)) ||
+                (c >= thr && nmo_is_extremum<true>(cur, dn, up, x, y, width)))
+                nmo_refine(cur, dn, up, x, y, width, peak, edge, xper, sigma0, num_dogs, level,
+                           result + 4 * ((size_t)y * width + x));
+        }
+    }
+}
+
+/* PyramidData::gpu_collate_keypoints_for_level -- sift/pyramidata.cu:84-91: stable copy_if(w >= 0) (Q8). */
+NMO_API int nmo_compact_keypoints(const float *dense, int num_pixels, float *out)
+{
+    int n = 0;
+    for (int i = 0; i < num_pixels; ++i)
+        if (dense[4 * (size_t)i + 3] >= 0) { std::memcpy(out + 4 * (size_t)n, dense + 4 * (size_t)i, 16); ++n; }
+    return n;
+}
+
+/* ---------------------------------------------------------------------------------------------------------- */
+/* orientations -- kernels/orientation.cu:11-129 (semantics), :132-216 (intent of the racy parts), Q10/Q11.
+ * FIXED ORDER: histogram votes are summed per bin in raster order of the clipped window (ys outer, xs inner),
+ * which is the order of the reference's own one-thread kernel (:165-176). Smoothing is the race-free circular
+ * 3-tap mean of :181-192. `result` is float2 per keypoint and must be pre-filled with (-1,-1) by the caller
+ * (pyramidata.cu:90).                                                                                       */
+NMO_API void nmo_detect_orientations(const float *key_pts, const float *grad, int num_pts, int ow, int oh,
+                                     float gauss_factor, float xper, float *result)
+{
+    const int NBINS = 36;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int pt = 0; pt < num_pts; ++pt) {
+        const float *kp = key_pts + 4 * (size_t)pt;
+        if (kp[3] < 0) continue;
+        const float x = kp[0] / xper, y = kp[1] / xper, s = kp[2] / xper;
+        const int xi = (int)((double)x + 0.5), yi = (int)((double)y + 0.5);
+        const float sigma_w = gauss_factor * s;
+        int W = std::max((int)std::floor(3 * sigma_w), 1);
+        W = std::min(22 / 2 - 1, W);                              /* blockDim (22,22) -> 10 (orientation.cu:29-30) */
+        const long grad_index = ((long)kp[3] * oh + yi) * ow + xi; /* Q10: integer arithmetic */
+        const float *g = grad + 2 * grad_index;
+        float hist[NBINS];
+        for (int i = 0; i < NBINS; ++i) hist[i] = 0.f;
+        const int xmin = std::max(-W, -xi), xmax = std::min(W, ow - 1 - xi);
+        const int ymin = std::max(-W, -yi), ymax = std::min(W, oh - 1 - yi);
+        const float denom = (2 * sigma_w) * sigma_w;
+        for (int cy = ymin; cy <= ymax; ++cy)
+            for (int cx = xmin; cx <= xmax; ++cx) {
+                const float dx = (float)(cx + xi) - x, dy = (float)(cy + yi) - y;
+                const float r2 = std::fmaf(dx, dx, dy * dy);
+                if (!((double)r2 < (double)(W * W) + 0.6)) continue;
+                const float wgt = nmo_expf(r2 / denom);                               /* exp(+...) per Q11 */
+                const float *gp = g + 2 * ((long)cy * ow + cx);
+                const float q = (float)((double)(36.0f * gp[1]) / NMO_2PI_D);
+                const int bin = (int)std::floor(q);
+                hist[bin % NBINS] += gp[0] * wgt;
+            }
+        for (int iter = 0; iter < 6; ++iter) {
+            float prev = hist[NBINS - 1];
+            const float first = hist[0];
+            int i;
+            for (i = 0; i < NBINS - 1; ++i) {
+                const float newh = (float)((double)((prev + hist[i]) + hist[(i + 1) % NBINS]) / 3.0);
+                prev = hist[i];
+                hist[i] = newh;
+            }
+            hist[i] = (float)((double)((prev + hist[i]) + first) / 3.0);
+        }
+        float maxh = 0.f;
+        for (int i = 0; i < NBINS; ++i) maxh = std::fmax(maxh, hist[i]);
+        const float threshold = (float)((double)maxh * 0.8);
+        int nangles = 0;
+        for (int i = 0; i < NBINS && nangles < 2; ++i) {
+            const float h0 = hist[i], hm = hist[(i - 1 + NBINS) % NBINS], hp = hist[(i + 1 + NBINS) % NBINS];
+            if (h0 > threshold && h0 > hm && h0 > hp) {
+                const float di = (float)((-0.5 * (double)(hp - hm)) / (double)((hp + hm) - 2 * h0));
+                const float th = (float)((NMO_2PI_D * ((double)((float)i + di) + 0.5)) / (double)NBINS);
+                result[2 * (size_t)pt + nangles] = th;
+                ++nangles;
+            }
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------------------- */
+/* descriptors -- kernels/descriptor.cu:32-145, Q12. Only the DIAGONAL 16x16 chunks of the window vote (cx and
+ * cy advance together, :142-143); exp(+...) window; no normalisation; first orientation only.
+ * FIXED ORDER (the reference's global atomicAdd order is undefined): the 256 positions of a chunk are indexed
+ * p = ty*16+tx; position p belongs to partial histogram L = p mod 64. Each partial accumulates its votes in the
+ * order (chunk, p div 64, dbinx, dbiny, dbint). bin = balanced pairwise tree over L = 0..63:
+ * stride 1,2,4,...,32: v[i] += v[i+stride].                                                                 */
+NMO_API void nmo_compute_sift_descriptors(const float *key_pts, const float *orients, const float *grad,
+                                          int num_pts, int ow, int oh, int num_dogs, float xper, float *desc,
+                                          float *xp, float *yp)
+{
+    const int NBO = 8, NBP = 4;
+    const int binto = 1, binyo = NBO * NBP, binxo = NBO;
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int pt = 0; pt < num_pts; ++pt) {
+        const float *kp = key_pts + 4 * (size_t)pt;
+        const float x = kp[0] / xper, y = kp[1] / xper, s = kp[2] / xper;
+        const int xi = (int)((double)x + 0.5), yi = (int)((double)y + 0.5), si = (int)kp[3];
+        if (xi < 0 || xi >= ow || yi < 0 || yi >= oh || si < 0 || si >= num_dogs) continue;
+        const float SBP = (float)((double)(3 * s) + 1.e-07);
+        const int W = (int)std::floor(std::sqrt(2.0) * (double)SBP * (NBP + 1) / 2.0 + 0.5);
+        const int xmin = std::max(-W, -xi), xmax = std::min(W, ow - 1 - xi);
+        const int ymin = std::max(-W, -yi), ymax = std::min(W, oh - 1 - yi);
+        const int max_dims = std::max(xmax - xmin, ymax - ymin);
+        const int chunks = (int)std::ceil((max_dims + 1.f) / 16);
+        xp[pt] = kp[0]; yp[pt] = kp[1];
+        const float *gptr = grad + 2 * (((long)si * oh + yi) * ow + xi);
+        const float angle0 = orients[2 * (size_t)pt];
+        const double st0 = (double)nmo_sinf(angle0), ct0 = (double)nmo_cosf(angle0);
+        std::vector<float> part(64 * 128, 0.f);           /* part[L*128 + (80 + loc)] */
+        for (int c = 0; c < chunks; ++c)
+            for (int q = 0; q < 4; ++q)
+                for (int L = 0; L < 64; ++L) {
+                    const int p = 64 * q + L;
+                    const int cx = (p & 15) + xmin + 16 * c, cy = (p >> 4) + ymin + 16 * c;
+                    if (!(cx <= xmax && cy <= ymax)) continue;
+                    const float mod = gptr[2 * ((long)cy * ow + cx)];
+                    const float ang = gptr[2 * ((long)cy * ow + cx) + 1];
+                    const float theta = nmo_mod_2pi_f(ang - angle0);
+                    const float dx = (float)(xi + cx) - x, dy = (float)(yi + cy) - y;
+                    const float nx = (float)(std::fma(ct0, (double)dx, st0 * (double)dy) / (double)SBP);
+                    const float ny = (float)(std::fma(-st0, (double)dx, ct0 * (double)dy) / (double)SBP);
+                    const float nt = (float)((double)(8.0f * theta) / NMO_2PI_D);
+                    const float win = (float)nmo_exp((double)std::fmaf(nx, nx, ny * ny) / 8.0);
+                    const int binx = (int)std::floor((double)nx - 0.5);
+                    const int biny = (int)std::floor((double)ny - 0.5);
+                    const int bint = (int)std::floor(nt);
+                    const float rbinx = (float)((double)nx - ((double)binx + 0.5));
+                    const float rbiny = (float)((double)ny - ((double)biny + 0.5));
+                    const float rbint = nt - (float)bint;
+                    for (int dbx = 0; dbx < 2; ++dbx)
+                        for (int dby = 0; dby < 2; ++dby)
+                            for (int dbt = 0; dbt < 2; ++dbt) {
+                                if (binx + dbx >= -(NBP / 2) && binx + dbx < (NBP / 2) &&
+                                    biny + dby >= -(NBP / 2) && biny + dby < (NBP / 2)) {
+                                    const float wt = win * mod * std::fabs((1.f - dbx) - rbinx) *
+                                                     std::fabs((1.f - dby) - rbiny) * std::fabs((1.f - dbt) - rbint);
+                                    const int loc = (binx + dbx) * binxo + (biny + dby) * binyo +
+                                                    ((bint + dbt) * binto) % NBO;
+                                    part[L * 128 + 80 + loc] += wt;
+                                }
+                            }
+                }
+        for (int stride = 1; stride < 64; stride *= 2)
+            for (int i = 0; i < 64; i += 2 * stride)
+                for (int b = 0; b < 128; ++b) part[i * 128 + b] += part[(i + stride) * 128 + b];
+        std::memcpy(desc + 128 * (size_t)pt, part.data(), 128 * sizeof(float));
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------------------- */
+/* matcher -- kernels/transpose.cu:9-30, kernels/match.cu:14-117, sift/siftfunctions.cu:15-40               */
+NMO_API void nmo_transpose(float *out, const float *in, int width, int height)
+{
+    for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) out[(size_t)x * height + y] = in[(size_t)y * width + x];
+}
+
+/* compute_brute_force_distance: At is dim x size_A, B is size_B x dim, D is size_B x size_A (match.cu:36-47). */
+NMO_API void nmo_bf_distance(const float *At, int size_A, const float *B, int size_B, int dim, float *D)
+{
+#pragma omp parallel for schedule(static)
+    for (int j = 0; j < size_B; ++j)
+        for (int i = 0; i < size_A; ++i) {
+            float acc = 0.0f;
+            for (int k = 0; k < dim; ++k) {
+                const float t = At[(size_t)k * size_A + i] - B[(size_t)j * dim + k];
+                acc = std::fmaf(t, t, acc);
+            }
+            D[(size_t)j * size_A + i] = acc;
+        }
+}
+
+/* get_sift_matches -- match.cu:83-117 (Q14). result[i] untouched when min2 <= 0. */
+NMO_API void nmo_get_sift_matches(const float *distance, int rows, int cols, int buffer_width, int *result,
+                                  float ambiguity)
+{
+    for (int i = 0; i < rows; ++i) {
+        const float *row = distance + (size_t)i * buffer_width;
+        float min1 = row[0];
+        float min2 = (float)0x7f800000;       /* int -> float conversion, 2139095040.0f, NOT +inf (match.cu:91) */
+        int idx = 0;
+        for (int j = 1; j < cols; ++j) {
+            const float cur = row[j];
+            if (cur < min1) { min2 = min1; idx = j; min1 = cur; }
+            else if (cur < min2) min2 = cur;
+        }
+        if (min2 > 0) {
+            const float a = min1 / min2;
+            result[i] = (a < ambiguity) ? idx : -1;
+        }
+    }
+}
+
+/* compute_sift_matches -- siftfunctions.cu:15-40. distance is nA x nB (may be NULL: extension, skip the store).
+ * Also returns per-row (min1, idx, min2) when the pointers are non-NULL (used to check the multi-GPU merge). */
+NMO_API void nmo_sift_matches(const float *A, int nA, const float *B, int nB, float *distance, int *result,
+                              float ambiguity, float *min1_out, int *idx_out, float *min2_out)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < nA; ++i) {
+        float min1 = 0.f, min2 = (float)0x7f800000; int idx = 0;
+        for (int j = 0; j < nB; ++j) {
+            float acc = 0.0f;
+            for (int k = 0; k < 128; ++k) {
+                const float t = A[(size_t)i * 128 + k] - B[(size_t)j * 128 + k];
+                acc = std::fmaf(t, t, acc);
+            }
+            if (distance) distance[(size_t)i * nB + j] = acc;
+            if (j == 0) { min1 = acc; idx = 0; }
+            else if (acc < min1) { min2 = min1; idx = j; min1 = acc; }
+            else if (acc < min2) min2 = acc;
+        }
+        if (min1_out) min1_out[i] = min1;
+        if (idx_out) idx_out[i] = idx;
+        if (min2_out) min2_out[i] = min2;
+        if (min2 > 0) {
+            const float a = min1 / min2;
+            result[i] = (a < ambiguity) ? idx : -1;
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------------------- */
+/* Per-frame driver: the client loop implied by the data-structure contracts, calling the stage
+ * functions above in the reference's orchestration order (sift/siftfunctions.cu:42-181).
+ * Outputs (all optional except desc/x/y): kpts_out = compacted float4 list in output order, orient_out = float2.
+ * Returns the number of descriptors written (<= capacity, Q13).                                             */
+NMO_API int nmo_sift_detect_describe(const float *gray, int width, int height, int capacity, float *desc,
+                                     float *xs, float *ys, float *kpts_out, float *orient_out,
+                                     int *counts_out /* [num_octaves*3] accepted per (octave, level) or NULL */)
+{
+    nmo_params P; nmo_sift_params(width, height, &P);
+    const size_t npix = (size_t)width * height;
+    const int nlev = P.level_max - P.level_min + 1;          /* 6 (pyramidata.cu:28) */
+    const int ndog = P.level_max - P.level_min;              /* 5 */
+    std::vector<std::vector<float>> oct(nlev, std::vector<float>(npix, 0.f)), dog(ndog, std::vector<float>(npix, 0.f));
+    std::vector<float> buffer(npix, 0.f), grad(2 * npix * ndog, 0.f);
+    std::vector<float> keymap(4 * npix), coll[3], orient[3];
+    std::vector<float> base_k(2 * (int)std::ceil(P.base_smooth * 4) + 1);
+    const int base_r = nmo_create_kernel_for_sigma(P.base_smooth, base_k.data());
+    std::vector<std::vector<float>> taps(P.num_sigmas); std::vector<int> radii(P.num_sigmas);
+    for (int i = 0; i < P.num_sigmas; ++i) {
+        taps[i].resize(2 * (int)std::ceil(P.sigmas[i] * 4) + 1);
+        radii[i] = nmo_create_kernel_for_sigma(P.sigmas[i], taps[i].data());
+    }
+    int num_items = 0;
+    nmo_convolve(oct[0].data(), gray, buffer.data(), width, height, base_k.data(), base_r);
+    for (int o = 0; o < P.num_octaves; ++o) {
+        const int ow = width >> o, oh = height >> o;
+        const float xper = (float)std::pow(2.0, o);
+        if (o > 0) nmo_downsample2(oct[0].data(), ow, oh, oct[3].data(), width >> (o - 1), height >> (o - 1));
+        for (int i = 1; i < nlev; ++i)
+            nmo_convolve(oct[i].data(), oct[i - 1].data(), buffer.data(), ow, oh, taps[i - 1].data(), radii[i - 1]);
+        for (int i = 0; i < ndog; ++i) nmo_subtract(oct[i + 1].data(), oct[i].data(), dog[i].data(), ow, oh);
+        for (int i = P.level_min + 1; i <= P.level_max - 2; ++i)
+            nmo_gradient(oct[i + 1].data(), grad.data() + 2 * (size_t)i * ow * oh, ow, oh);
+        int cnt[3] = {0, 0, 0};
+        for (int i = 1; i < ndog - 1; ++i) {
+            for (size_t k = 0; k < 4 * npix; ++k) keymap[k] = -1.0f;
+            nmo_find_keypoints(dog[i].data(), dog[i - 1].data(), dog[i + 1].data(), nullptr, 0, 0, ow, oh,
+                               P.peak_threshold, P.edge_threshold, xper, P.sigma_0, P.num_dog_levels, i - 1,
+                               keymap.data());
+            coll[i - 1].assign(4 * (size_t)ow * oh, -1.f);
+            cnt[i - 1] = nmo_compact_keypoints(keymap.data(), ow * oh, coll[i - 1].data());
+        }
+        /* compute_orientations / compute_descriptors: an empty level ends the octave (Q9). */
+        int live = 0;
+        for (int l = 0; l < P.num_dog_levels; ++l) { if (cnt[l] == 0) break; ++live; }
+        for (int l = 0; l < P.num_dog_levels; ++l) {
+            int n = (l < live) ? cnt[l] : 0;
+            if (counts_out) counts_out[o * 3 + l] = n;
+            if (n == 0) continue;
+            orient[l].assign(2 * (size_t)n, -1.f);
+            nmo_detect_orientations(coll[l].data(), grad.data(), n, ow, oh, 1.5f, xper, orient[l].data());
+        }
+        for (int l = 0; l < live; ++l) {
+            int n = cnt[l];
+            if (n + num_items > capacity) n = capacity - num_items;
+            if (n > 0) {
+                nmo_compute_sift_descriptors(coll[l].data(), orient[l].data(), grad.data(), n, ow, oh,
+                                             P.num_dog_levels, xper, desc + 128 * (size_t)num_items,
+                                             xs + num_items, ys + num_items);
+                if (kpts_out) std::memcpy(kpts_out + 4 * (size_t)num_items, coll[l].data(), 16 * (size_t)n);
+                if (orient_out) std::memcpy(orient_out + 2 * (size_t)num_items, orient[l].data(), 8 * (size_t)n);
+                num_items += n;
+            }
+        }
+    }
+    return num_items;
+}
+
+/* Stage-level pyramid only (Gaussian levels + DoG + gradients of one octave), for stage parity tests and the
+ * cpu_baseline "pyramid" figure. levels: 6 planes, dogs: 5 planes, each ow*oh, contiguous.                  */
+NMO_API void nmo_octave_pyramid(const float *level0, int ow, int oh, int width, int height, float *levels,
+                                float *dogs, float *grad3 /* 3 planes float2 or NULL */)
+{
+    nmo_params P; nmo_sift_params(width, height, &P);
+    const size_t n = (size_t)ow * oh;
+    std::vector<float> buffer(n);
+    std::memcpy(levels, level0, n * 4);
+    for (int i = 0; i < P.num_sigmas; ++i) {
+        std::vector<float> t(2 * (int)std::ceil(P.sigmas[i] * 4) + 1);
+        const int r = nmo_create_kernel_for_sigma(P.sigmas[i], t.data());
+        nmo_convolve(levels + (i + 1) * n, levels + i * n, buffer.data(), ow, oh, t.data(), r);
+    }
+    for (int i = 0; i < 5; ++i) nmo_subtract(levels + (i + 1) * n, levels + i * n, dogs + i * n, ow, oh);
+    if (grad3) for (int l = 0; l < 3; ++l) nmo_gradient(levels + (l + 1) * n, grad3 + 2 * l * n, ow, oh);
+}
+
+/* ---------------------------------------------------------------------------------------------------------- */
+/* vectorised math entry points for tests/test_oracle_math.py                                                */
+NMO_API void nmo_vec_atan2f(const float *y, const float *x, float *o, int n) { for (int i = 0; i < n; ++i) o[i] = nmo_atan2f(y[i], x[i]); }
+NMO_API void nmo_vec_expf(const float *x, float *o, int n) { for (int i = 0; i < n; ++i) o[i] = nmo_expf(x[i]); }
+NMO_API void nmo_vec_sinf(const float *x, float *o, int n) { for (int i = 0; i < n; ++i) o[i] = nmo_sinf(x[i]); }
+NMO_API void nmo_vec_cosf(const float *x, float *o, int n) { for (int i = 0; i < n; ++i) o[i] = nmo_cosf(x[i]); }
+NMO_API void nmo_vec_exp(const double *x, double *o, int n) { for (int i = 0; i < n; ++i) o[i] = nmo_exp(x[i]); }
+NMO_API void nmo_vec_exp2(const double *x, double *o, int n) { for (int i = 0; i < n; ++i) o[i] = nmo_exp2(x[i]); }
