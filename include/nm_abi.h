@@ -1,0 +1,164 @@
+/*
+ * include/nm_abi.h -- C ABI of libnm_hip.so: the MI355X (gfx950) drop-in for NiftyMatch's SIFT detect/describe +
+ * brute-force L2 match path.
+ *
+ * Every entry point replaces one host launcher of the reference (file:line under /root/reference/src/gpu/) and
+ * keeps its argument order and meaning. Differences common to all of them:
+ *   - plain C: raw DEVICE pointers, ints, floats; `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - float2/float4 arrays are passed as float* with the same memory layout (x,y[,z,w] interleaved);
+ *   - the return value is 0 on success or the hipError_t of the failing launch / API call (the reference prints
+ *     and exit()s inside the launcher, helper_cuda.h getLastCudaError; the C++ wrappers in niftymatch_amd/nm/ restore
+ *     that convention on top of this status);
+ *   - textures are replaced by plain row-major planes (the reference's fetches are exact texel loads,
+ *     utils/cudatex2D.cu:15-19);
+ *   - all launches are asynchronous on `stream`; none allocates, frees or synchronises unless stated.
+ * All functions are re-entrant; all state lives in the arguments.
+ */
+#ifndef NM_ABI_H
+#define NM_ABI_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define NM_API __attribute__((visibility("default")))
+#else
+#define NM_API
+#endif
+
+/* ---- integer helpers: the reference's only extern "C" symbols (kernels/cudamath.h:18-45, cudamath.cu:5-23) ---- */
+NM_API int DivUp(int a, int b);
+NM_API int DivDown(int a, int b);
+NM_API int AlignUp(int a, int b);
+NM_API int AlignDown(int a, int b);
+
+/* ---- library / device ---- */
+NM_API const char *nm_version(void);                 /* "niftymatch_amd <ver> gfx950" */
+NM_API int nm_device_count(int *count);              /* hipGetDeviceCount */
+NM_API int nm_set_device(int device);                /* replaces CudaUtils::setup_CUDA (utils/cudautils.cpp:19-28) */
+NM_API const char *nm_error_string(int status);      /* hipGetErrorString */
+
+/* Fill `count` 32-bit words at device pointer dst with `pattern` (replaces thrust::fill / device_vector value
+ * initialisation, sift/siftfunctions.cu:84-85,120-121, sift/pyramidata.cu:42-46).                                */
+NM_API int nm_fill_u32(void *dst, size_t count, unsigned int pattern, void *stream);
+
+/* Profiling hook (no reference counterpart; the reference's CudaTimer brackets whole calls, utils/cudatimer.cu:3-22).
+ * While a (start, stop) hipEvent_t pair is registered for `site`, the launcher records start immediately before and
+ * stop immediately after that kernel (sequence) on the stream it launches on. Pass NULLs to clear. Per host thread.
+ *   NM_PROF_MATCH_TOP2 : the MFMA top-2 kernel inside nm_sift_match_f32 / nm_sift_match_shard_f32
+ *   NM_PROF_PYRAMID_O0 : the octave-0 pyramid sequence (5 fused Gaussian+DoG launches + gradients) inside
+ *                        nm_sift_detect_describe / nm_sift_octave_pyramid                                       */
+#define NM_PROF_MATCH_TOP2 0
+#define NM_PROF_PYRAMID_O0 1
+#define NM_PROF_SITES 2
+NM_API int nm_profile_events(int site, void *start_event, void *stop_event);
+
+/* ---- host-side scale-space constants ---- */
+/* PyramidData::create_kernel_for_sigma (sift/pyramidata.cu:105-123). HOST function: writes 2*radius+1 normalised
+ * taps to host memory `taps` (may be NULL to query) and returns radius = ceil(4*sigma).                          */
+NM_API int nm_create_kernel_for_sigma(float sigma, float *taps);
+
+/* ---- pyramid stages ---- */
+/* convolve<float> (kernels/convolution.h:19-23, convolution.cu:141-159): zero-padded separable correlation,
+ * `buffer` receives the row pass, `result` the column pass of `buffer`. `kernel` = 2r+1 taps in DEVICE memory.   */
+NM_API int nm_convolve_f32(float *result, const float *image, float *buffer, int width, int height,
+                           const float *kernel, int kernel_radius, void *stream);
+/* downsample_by_2<float> (kernels/downsample.h:21-24, downsample.cu:20-29). */
+NM_API int nm_downsample2_f32(float *result, int result_width, int result_height, const float *source,
+                              int source_width, int source_height, void *stream);
+/* subtract<float> (kernels/cudamath.h:56-60, cudamath.cu:57-67): C = A - B. */
+NM_API int nm_subtract_f32(const float *A, const float *B, float *C, int width, int height, void *stream);
+/* gradient<float> (kernels/cudamath.h:71-75, cudamath.cu:72-80): result is float2 (magnitude, angle in (0,2pi]).
+ * Deviation: the 1-pixel border, which the reference never writes, is written as (0,0).            */
+NM_API int nm_gradient_f32(const float *source, float *result, int width, int height, void *stream);
+
+/* ---- keypoints ---- */
+/* find_keypoints, unmasked overload (kernels/keypoint.h:25-32, keypoint.cu:240-251). current/down/up are DoG
+ * planes (were cudaTextureObject_t). `result` is the dense width*height float4 map, pre-filled with -1 by the
+ * caller as in the reference (sift/siftfunctions.cu:120-121).                                                   */
+NM_API int nm_find_keypoints_f32(const float *current, const float *down, const float *up, int width, int height,
+                                 float peak_threshold, float edge_threshold, float xper, float sigma_0,
+                                 int num_dogs, int dog, float *result, void *stream);
+/* find_keypoints, masked overload (kernels/keypoint.h:52-59, keypoint.cu:226-237). `mask` is the full-resolution
+ * mask plane mask_width x mask_height; it is sampled exactly as the reference's bilinear border texture fetch at
+ * ((x+0.5)*xper, (y+0.5)*xper) (keypoint.cu:214).                                                                */
+NM_API int nm_find_keypoints_masked_f32(const float *current, const float *mask, int mask_width, int mask_height,
+                                        const float *down, const float *up, int width, int height,
+                                        float peak_threshold, float edge_threshold, float xper, float sigma_0,
+                                        int num_dogs, int dog, float *result, void *stream);
+/* PyramidData::gpu_collate_keypoints_for_level's thrust::copy_if (sift/pyramidata.cu:84-88): stable compaction
+ * of the entries with w >= 0 among the first num_pixels of `dense` into `out`; the count is written to the
+ * DEVICE int *d_count. workspace: nm_compact_workspace_bytes(num_pixels) bytes of device scratch.               */
+NM_API size_t nm_compact_workspace_bytes(int num_pixels);
+NM_API int nm_compact_keypoints(const float *dense, int num_pixels, float *out, int *d_count, void *workspace,
+                                void *stream);
+
+/* ---- orientation + descriptor ---- */
+/* detect_orientations (kernels/orientation.h:19-24, orientation.cu:219-230). `result` float2 per keypoint,
+ * pre-filled with (-1,-1) by the caller (pyramidata.cu:90).                                                     */
+NM_API int nm_detect_orientations(const float *key_pts, const float *grad, int num_pts, int octave_width,
+                                  int octave_height, float gauss_factor, float xper, float *result, void *stream);
+/* compute_sift_descriptors (kernels/descriptor.h:25-30, descriptor.cu:243-255). */
+NM_API int nm_compute_sift_descriptors(const float *key_pts, const float *orients, const float *grad, int num_pts,
+                                       int octave_width, int octave_height, int num_dogs, float xper, float *desc,
+                                       float *x, float *y, void *stream);
+
+/* ---- matcher ---- */
+/* transpose<float> (kernels/transpose.h:16-21, transpose.cu:33-40): odata[x*height+y] = idata[y*width+x]. */
+NM_API int nm_transpose_f32(float *odata, const float *idata, int width, int height, void *stream);
+/* compute_brute_force_distance<float> (kernels/match.h:18-23, match.cu:120-135): A is the TRANSPOSED query set
+ * (dim x size_A), B is size_B x dim, result[j*size_A + i] = squared L2 distance. dim must be 128.               */
+NM_API int nm_bf_distance_f32(const float *A, int size_A, const float *B, int size_B, int sift_vector_size,
+                              float *result, void *stream);
+/* get_sift_matches<float> (kernels/match.h:40-46, match.cu:141-150): per-row best / second best + ratio test. */
+NM_API int nm_get_sift_matches_f32(const float *distance, int rows, int cols, int buffer_width, int *result,
+                                   float ambiguity, void *stream);
+
+/* compute_sift_matches (sift/siftfunctions.h:19-21, siftfunctions.cu:15-40) on raw descriptor arrays:
+ * A: nA x 128, B: nB x 128 row-major. Fused MFMA path; `distance` (nA x nB) is optional (NULL = do not
+ * materialise; extension). result[i] in {-1, 0..nB-1}, left untouched when the second-best distance is <= 0
+ * (match.cu:107-116). Match decisions are made on distances recomputed exactly in the reference's summation
+ * order. workspace: nm_sift_match_workspace_bytes(nA, nB) bytes of device scratch.                            */
+NM_API size_t nm_sift_match_workspace_bytes(int nA, int nB);
+NM_API int nm_sift_match_f32(const float *A, int nA, const float *B, int nB, float *distance, int *result,
+                             float ambiguity, void *workspace, void *stream);
+/* Multi-GPU building blocks (no reference counterpart: the reference is single-GPU). A shard call scans the local
+ * rows [0,nB_shard) of B and emits, per query row, the exact (min1, index1 + index_offset, min2) of that shard
+ * with the scan semantics of match.cu:91-105. The merge combines n_shards such triples per row, given shard-major
+ * (n_shards x nA), in ascending shard order so that the lowest global index wins ties, and applies the ratio test. */
+NM_API int nm_sift_match_shard_f32(const float *A, int nA, const float *B_shard, int nB_shard, int index_offset,
+                                   float *min1, int *idx1, float *min2, void *workspace, void *stream);
+NM_API int nm_sift_match_merge_f32(const float *min1, const int *idx1, const float *min2, int n_shards, int nA,
+                                   int *result, float ambiguity, void *stream);
+
+/* ---- per-frame driver ---- */
+/* The per-octave client loop the reference leaves to its caller, run entirely on `stream` with no
+ * host synchronisation and no allocation: Gaussian pyramid + DoG + gradients + extrema + ordered compaction +
+ * orientations + descriptors of one grayscale fp32 frame. An arena owns every intermediate buffer
+ * (replaces PyramidData, sift/pyramidata.cu:24-50) and is bound to one stream at a time.                        */
+typedef struct nm_sift_arena nm_sift_arena;
+NM_API int nm_sift_arena_create(int width, int height, int capacity, nm_sift_arena **arena);
+NM_API void nm_sift_arena_destroy(nm_sift_arena *arena);
+NM_API size_t nm_sift_arena_bytes(const nm_sift_arena *arena);
+/* gray: width*height fp32 on the device. Outputs on the device: desc capacity x 128, x,y capacity (full-resolution
+ * coordinates, descriptor.cu:75-77), d_num_items = number of descriptors written (<= capacity,
+ * siftfunctions.cu:165-169). kpts (capacity float4) and orients (capacity float2) are optional (NULL).        */
+NM_API int nm_sift_detect_describe(nm_sift_arena *arena, const float *gray, float *desc, float *x, float *y,
+                                   float *kpts, float *orients, int *d_num_items, void *stream);
+/* Pointers into the arena for stage-level inspection (tests, profiling): Gaussian level l (0..5) and DoG d (0..4)
+ * planes of the LAST processed octave geometry are overwritten per octave, so these are meaningful only after
+ * nm_sift_octave_pyramid().                                                                                      */
+NM_API float *nm_sift_arena_level(nm_sift_arena *arena, int level);
+NM_API float *nm_sift_arena_dog(nm_sift_arena *arena, int dog);
+NM_API float *nm_sift_arena_grad(nm_sift_arena *arena);
+/* Gaussian levels 1..5 + DoG 0..4 + gradients 0..2 of one octave whose level 0 already sits in
+ * nm_sift_arena_level(arena,0) with geometry ow x oh (the fused pyramid stage, timed by bench.py).            */
+NM_API int nm_sift_octave_pyramid(nm_sift_arena *arena, int ow, int oh, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

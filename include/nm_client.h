@@ -1,0 +1,22 @@
+/*
+ * include/nm_client.h -- a reference-style CLIENT of the drop-in C++ API, exported with C linkage so that tests can
+ * drive the headers under niftymatch_amd/nm (SiftParams, PyramidData, SiftData, convolve, downsample_by_2, compute_dog,
+ * compute_gradients, compute_keypoints, compute_orientations, compute_descriptors, compute_sift_matches) exactly the
+ * way an application written against NiftyMatch would (the per-octave loop of SURVEY.md 3.1). Host pointers in/out.
+ */
+#ifndef NM_CLIENT_H
+#define NM_CLIENT_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* gray: width*height fp32 (host). desc: capacity*128, x/y: capacity (host). Returns the number of descriptors or a
+ * negative value on a C++ exception. */
+__attribute__((visibility("default"))) int nm_client_detect_describe(const float *gray, int width, int height,
+                                                                    int capacity, float *desc, float *x, float *y);
+/* A: nA*128, B: nB*128 (host). distance: nA*nB (host) or NULL. result: nA ints, pre-filled by the caller. */
+__attribute__((visibility("default"))) int nm_client_match(const float *A, int nA, const float *B, int nB,
+                                                          float *distance, int *result, float ambiguity);
+#ifdef __cplusplus
+}
+#endif
+#endif

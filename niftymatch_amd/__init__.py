@@ -1,0 +1,327 @@
+"""niftymatch_amd -- MI355X (gfx950) drop-in for NiftyMatch's SIFT detect/describe + brute-force L2 match path.
+
+The product is the HIP library niftymatch_amd/lib/libnm_hip.so (C ABI: include/nm_abi.h) and the C++ headers under
+niftymatch_amd/nm/ that mirror the reference's API. This Python module is host plumbing for tests, bench.py and the
+multi-GPU launcher: it binds the C ABI with ctypes and uses torch only for device memory, streams and
+torch.distributed. There is NO CPU fallback: if the library is missing, every entry point raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnm_hip.so")
+_lib = None
+
+_F = C.c_float
+_I = C.c_int
+_P = C.c_void_p
+_SZ = C.c_size_t
+
+_SIGNATURES = {
+    "DivUp": (_I, [_I, _I]), "DivDown": (_I, [_I, _I]), "AlignUp": (_I, [_I, _I]), "AlignDown": (_I, [_I, _I]),
+    "nm_version": (C.c_char_p, []), "nm_device_count": (_I, [_P]), "nm_set_device": (_I, [_I]),
+    "nm_error_string": (C.c_char_p, [_I]),
+    "nm_fill_u32": (_I, [_P, _SZ, C.c_uint, _P]),
+    "nm_profile_events": (_I, [_I, _P, _P]),
+    "nm_create_kernel_for_sigma": (_I, [_F, _P]),
+    "nm_convolve_f32": (_I, [_P, _P, _P, _I, _I, _P, _I, _P]),
+    "nm_downsample2_f32": (_I, [_P, _I, _I, _P, _I, _I, _P]),
+    "nm_subtract_f32": (_I, [_P, _P, _P, _I, _I, _P]),
+    "nm_gradient_f32": (_I, [_P, _P, _I, _I, _P]),
+    "nm_find_keypoints_f32": (_I, [_P, _P, _P, _I, _I, _F, _F, _F, _F, _I, _I, _P, _P]),
+    "nm_find_keypoints_masked_f32": (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _F, _F, _F, _F, _I, _I, _P, _P]),
+    "nm_compact_workspace_bytes": (_SZ, [_I]),
+    "nm_compact_keypoints": (_I, [_P, _I, _P, _P, _P, _P]),
+    "nm_detect_orientations": (_I, [_P, _P, _I, _I, _I, _F, _F, _P, _P]),
+    "nm_compute_sift_descriptors": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P]),
+    "nm_transpose_f32": (_I, [_P, _P, _I, _I, _P]),
+    "nm_bf_distance_f32": (_I, [_P, _I, _P, _I, _I, _P, _P]),
+    "nm_get_sift_matches_f32": (_I, [_P, _I, _I, _I, _P, _F, _P]),
+    "nm_sift_match_workspace_bytes": (_SZ, [_I, _I]),
+    "nm_sift_match_f32": (_I, [_P, _I, _P, _I, _P, _P, _F, _P, _P]),
+    "nm_sift_match_shard_f32": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "nm_sift_match_merge_f32": (_I, [_P, _P, _P, _I, _I, _P, _F, _P]),
+    "nm_sift_arena_create": (_I, [_I, _I, _I, _P]),
+    "nm_sift_arena_destroy": (None, [_P]),
+    "nm_sift_arena_bytes": (_SZ, [_P]),
+    "nm_sift_detect_describe": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "nm_sift_arena_level": (_P, [_P, _I]), "nm_sift_arena_dog": (_P, [_P, _I]), "nm_sift_arena_grad": (_P, [_P]),
+    "nm_sift_octave_pyramid": (_I, [_P, _I, _I, _P]),
+    "nm_client_detect_describe": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "nm_client_match": (_I, [_P, _I, _P, _I, _P, _P, _F]),
+}
+
+ABI_SYMBOLS = tuple(k for k in _SIGNATURES if not k.startswith("nm_client_"))
+
+
+class NmError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libnm_hip.so (built by `python -m niftymatch_amd.build`). Fails loudly when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NmError("libnm_hip.so not found at %s: build it with `python -m niftymatch_amd.build` "
+                          "(there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(status, what):
+    if status != 0:
+        raise NmError("%s failed: (%d) %s" % (what, status, lib().nm_error_string(status).decode()))
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _stream():
+    return _torch().cuda.current_stream().cuda_stream
+
+
+def _dev(t, dtype=None):
+    torch = _torch()
+    if not t.is_cuda:
+        raise NmError("expected a device tensor")
+    if dtype is not None and t.dtype != dtype:
+        raise NmError("expected dtype %s, got %s" % (dtype, t.dtype))
+    if not t.is_contiguous():
+        raise NmError("expected a contiguous tensor")
+    return t.data_ptr()
+
+
+PROF_MATCH_TOP2 = 0
+PROF_PYRAMID_O0 = 1
+
+
+def profile_events(site, start=None, stop=None):
+    """Register (torch.cuda.Event, torch.cuda.Event) to be recorded around a kernel site; None clears."""
+    _check(lib().nm_profile_events(site, start.cuda_event if start is not None else None,
+                                   stop.cuda_event if stop is not None else None), "nm_profile_events")
+
+
+def create_kernel_for_sigma(sigma):
+    """Host taps of PyramidData::create_kernel_for_sigma -> (numpy float32 taps, radius)."""
+    import numpy as np
+    r = lib().nm_create_kernel_for_sigma(sigma, None)
+    taps = np.zeros(2 * r + 1, np.float32)
+    lib().nm_create_kernel_for_sigma(sigma, taps.ctypes.data)
+    return taps, r
+
+
+# ---- stage wrappers (device tensors in, device tensors out) ----------------------------------------------------
+def convolve(image, taps_dev, radius, want_buffer=False):
+    torch = _torch()
+    h, w = image.shape
+    out = torch.empty_like(image)
+    buf = torch.empty_like(image)
+    _check(lib().nm_convolve_f32(_dev(out), _dev(image, torch.float32), _dev(buf), w, h, _dev(taps_dev), radius,
+                                 _stream()), "nm_convolve_f32")
+    return (out, buf) if want_buffer else out
+
+
+def downsample2(src, rw, rh):
+    torch = _torch()
+    sh, sw = src.shape
+    out = torch.empty((rh, rw), dtype=torch.float32, device=src.device)
+    _check(lib().nm_downsample2_f32(_dev(out), rw, rh, _dev(src, torch.float32), sw, sh, _stream()), "nm_downsample2_f32")
+    return out
+
+
+def subtract(a, b):
+    torch = _torch()
+    out = torch.empty_like(a)
+    _check(lib().nm_subtract_f32(_dev(a, torch.float32), _dev(b, torch.float32), _dev(out), a.shape[1], a.shape[0],
+                                 _stream()), "nm_subtract_f32")
+    return out
+
+
+def gradient(src):
+    torch = _torch()
+    h, w = src.shape
+    out = torch.empty((h, w, 2), dtype=torch.float32, device=src.device)
+    _check(lib().nm_gradient_f32(_dev(src, torch.float32), _dev(out), w, h, _stream()), "nm_gradient_f32")
+    return out
+
+
+def find_keypoints(cur, dn, up, peak, edge, xper, sigma0, num_dogs, level, mask=None):
+    torch = _torch()
+    h, w = cur.shape
+    res = torch.full((h, w, 4), -1.0, dtype=torch.float32, device=cur.device)
+    if mask is None:
+        _check(lib().nm_find_keypoints_f32(_dev(cur), _dev(dn), _dev(up), w, h, peak, edge, xper, sigma0, num_dogs,
+                                           level, _dev(res), _stream()), "nm_find_keypoints_f32")
+    else:
+        mh, mw = mask.shape
+        _check(lib().nm_find_keypoints_masked_f32(_dev(cur), _dev(mask, torch.float32), mw, mh, _dev(dn), _dev(up), w,
+                                                  h, peak, edge, xper, sigma0, num_dogs, level, _dev(res), _stream()),
+               "nm_find_keypoints_masked_f32")
+    return res
+
+
+def compact_keypoints(dense):
+    torch = _torch()
+    flat = dense.reshape(-1, 4)
+    n = flat.shape[0]
+    out = torch.full_like(flat, -1.0)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dense.device)
+    ws = torch.empty(lib().nm_compact_workspace_bytes(n) + 16, dtype=torch.uint8, device=dense.device)
+    _check(lib().nm_compact_keypoints(_dev(flat), n, _dev(out), _dev(cnt), _dev(ws), _stream()), "nm_compact_keypoints")
+    return out[: int(cnt.item())]
+
+
+def detect_orientations(kpts, grad, ow, oh, gauss_factor, xper):
+    torch = _torch()
+    n = kpts.shape[0]
+    res = torch.full((n, 2), -1.0, dtype=torch.float32, device=kpts.device)
+    _check(lib().nm_detect_orientations(_dev(kpts, torch.float32), _dev(grad, torch.float32), n, ow, oh, gauss_factor,
+                                        xper, _dev(res), _stream()), "nm_detect_orientations")
+    return res
+
+
+def compute_sift_descriptors(kpts, orients, grad, ow, oh, num_dogs, xper):
+    torch = _torch()
+    n = kpts.shape[0]
+    desc = torch.zeros((n, 128), dtype=torch.float32, device=kpts.device)
+    x = torch.zeros(n, dtype=torch.float32, device=kpts.device)
+    y = torch.zeros(n, dtype=torch.float32, device=kpts.device)
+    _check(lib().nm_compute_sift_descriptors(_dev(kpts), _dev(orients), _dev(grad), n, ow, oh, num_dogs, xper,
+                                             _dev(desc), _dev(x), _dev(y), _stream()), "nm_compute_sift_descriptors")
+    return desc, x, y
+
+
+def transpose(a):
+    torch = _torch()
+    h, w = a.shape
+    out = torch.empty((w, h), dtype=torch.float32, device=a.device)
+    _check(lib().nm_transpose_f32(_dev(out), _dev(a, torch.float32), w, h, _stream()), "nm_transpose_f32")
+    return out
+
+
+def bf_distance(At, B):
+    torch = _torch()
+    dim, na = At.shape
+    nb = B.shape[0]
+    D = torch.empty((nb, na), dtype=torch.float32, device=At.device)
+    _check(lib().nm_bf_distance_f32(_dev(At, torch.float32), na, _dev(B, torch.float32), nb, dim, _dev(D), _stream()),
+           "nm_bf_distance_f32")
+    return D
+
+
+def get_sift_matches(distance, ambiguity=0.8, prior=None, cols=None):
+    torch = _torch()
+    rows, bw = distance.shape
+    cols = bw if cols is None else cols
+    res = torch.full((rows,), -1, dtype=torch.int32, device=distance.device) if prior is None else prior.clone()
+    _check(lib().nm_get_sift_matches_f32(_dev(distance, torch.float32), rows, cols, bw, _dev(res, torch.int32),
+                                         ambiguity, _stream()), "nm_get_sift_matches_f32")
+    return res
+
+
+class MatchWorkspace:
+    """Device scratch of the fused matcher, sized for (nA, nB); reusable across calls of at most that size."""
+
+    def __init__(self, nA, nB, device):
+        torch = _torch()
+        self.nA, self.nB = nA, nB
+        self.buf = torch.empty(lib().nm_sift_match_workspace_bytes(nA, nB) + 256, dtype=torch.uint8, device=device)
+
+
+def sift_match(A, B, ambiguity=0.8, want_distance=False, prior=None, workspace=None, nA=None, nB=None):
+    """compute_sift_matches on raw descriptor tensors (n x 128). Returns (result int32[nA], distance or None)."""
+    torch = _torch()
+    nA = A.shape[0] if nA is None else nA
+    nB = B.shape[0] if nB is None else nB
+    ws = workspace or MatchWorkspace(nA, nB, A.device)
+    D = torch.empty((nA, nB), dtype=torch.float32, device=A.device) if want_distance else None
+    res = torch.full((nA,), -1, dtype=torch.int32, device=A.device) if prior is None else prior
+    _check(lib().nm_sift_match_f32(_dev(A, torch.float32), nA, _dev(B, torch.float32), nB,
+                                   _dev(D) if D is not None else None, _dev(res, torch.int32), ambiguity,
+                                   _dev(ws.buf), _stream()), "nm_sift_match_f32")
+    return res, D
+
+
+def sift_match_shard(A, B_shard, index_offset, workspace=None):
+    """Exact (min1, idx+offset, min2) of every row of A over the local shard of B."""
+    torch = _torch()
+    nA, nB = A.shape[0], B_shard.shape[0]
+    ws = workspace or MatchWorkspace(nA, nB, A.device)
+    m1 = torch.empty(nA, dtype=torch.float32, device=A.device)
+    ix = torch.empty(nA, dtype=torch.int32, device=A.device)
+    m2 = torch.empty(nA, dtype=torch.float32, device=A.device)
+    _check(lib().nm_sift_match_shard_f32(_dev(A, torch.float32), nA, _dev(B_shard, torch.float32), nB, index_offset,
+                                         _dev(m1), _dev(ix), _dev(m2), _dev(ws.buf), _stream()),
+           "nm_sift_match_shard_f32")
+    return m1, ix, m2
+
+
+def sift_match_merge(m1_all, ix_all, m2_all, ambiguity=0.8, prior=None):
+    """Merge shard-major (n_shards, nA) triples into match indexes."""
+    torch = _torch()
+    n_shards, nA = m1_all.shape
+    res = torch.full((nA,), -1, dtype=torch.int32, device=m1_all.device) if prior is None else prior
+    _check(lib().nm_sift_match_merge_f32(_dev(m1_all, torch.float32), _dev(ix_all, torch.int32),
+                                         _dev(m2_all, torch.float32), n_shards, nA, _dev(res), ambiguity, _stream()),
+           "nm_sift_match_merge_f32")
+    return res
+
+
+class SiftArena:
+    """Per-stream frame arena + outputs of nm_sift_detect_describe (replaces PyramidData + SiftData)."""
+
+    def __init__(self, width, height, capacity=16384, device="cuda"):
+        torch = _torch()
+        self.width, self.height, self.capacity = width, height, capacity
+        self._h = C.c_void_p()
+        _check(lib().nm_sift_arena_create(width, height, capacity, C.byref(self._h)), "nm_sift_arena_create")
+        self.desc = torch.zeros((capacity, 128), dtype=torch.float32, device=device)
+        self.x = torch.zeros(capacity, dtype=torch.float32, device=device)
+        self.y = torch.zeros(capacity, dtype=torch.float32, device=device)
+        self.kpts = torch.zeros((capacity, 4), dtype=torch.float32, device=device)
+        self.orients = torch.zeros((capacity, 2), dtype=torch.float32, device=device)
+        self.num_items = torch.zeros(1, dtype=torch.int32, device=device)
+
+    @property
+    def bytes(self):
+        return lib().nm_sift_arena_bytes(self._h)
+
+    def detect_describe(self, gray):
+        """Enqueue one frame (device fp32 (H,W)) on the current stream; no host synchronisation."""
+        torch = _torch()
+        if tuple(gray.shape) != (self.height, self.width):
+            raise NmError("frame shape %s does not match the arena (%d,%d)" % (tuple(gray.shape), self.height, self.width))
+        _check(lib().nm_sift_detect_describe(self._h, _dev(gray, torch.float32), _dev(self.desc), _dev(self.x),
+                                             _dev(self.y), _dev(self.kpts), _dev(self.orients), _dev(self.num_items),
+                                             _stream()), "nm_sift_detect_describe")
+
+    def octave_pyramid(self, ow, oh):
+        _check(lib().nm_sift_octave_pyramid(self._h, ow, oh, _stream()), "nm_sift_octave_pyramid")
+
+    def level_ptr(self, l):
+        return lib().nm_sift_arena_level(self._h, l)
+
+    def dog_ptr(self, d):
+        return lib().nm_sift_arena_dog(self._h, d)
+
+    def grad_ptr(self):
+        return lib().nm_sift_arena_grad(self._h)
+
+    def close(self):
+        if self._h:
+            lib().nm_sift_arena_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

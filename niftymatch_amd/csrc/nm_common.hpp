@@ -1,0 +1,48 @@
+// nm_common.hpp -- shared host/device helpers for libnm_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define NM_WAVE 64
+
+#define NM_RETURN_IF(expr)                                  \
+    do {                                                    \
+        hipError_t nm_e_ = (expr);                          \
+        if (nm_e_ != hipSuccess) return (int)nm_e_;         \
+    } while (0)
+
+#define NM_LAUNCH_CHECK()                                   \
+    do {                                                    \
+        hipError_t nm_e_ = hipGetLastError();               \
+        if (nm_e_ != hipSuccess) return (int)nm_e_;         \
+    } while (0)
+
+static inline int nm_divup(int a, int b) { return (a + b - 1) / b; }
+static inline hipStream_t nm_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- profiling hook (nm_profile_events) ----
+struct NmProfSite { hipEvent_t start, stop; };
+extern thread_local NmProfSite nm_prof_sites[2];
+static inline void nm_prof_begin(int site, hipStream_t st) { if (nm_prof_sites[site].start) (void)hipEventRecord(nm_prof_sites[site].start, st); }
+static inline void nm_prof_end(int site, hipStream_t st) { if (nm_prof_sites[site].stop) (void)hipEventRecord(nm_prof_sites[site].stop, st); }
+
+// ---- internal launchers shared between translation units (not part of the C ABI) ----
+struct NmGradBatch {            // up to 3 planes per launch (gradient levels 0..2 of one octave)
+    const float *src[3];
+    float *dst[3];
+    int n;
+};
+int nm_launch_gradient_batch(const NmGradBatch &b, int width, int height, hipStream_t stream);
+// Gaussian level + fused DoG (dog = result - image); buffer may be NULL (row pass not materialised).
+int nm_launch_convolve(float *result, const float *image, float *buffer, float *dog, int width, int height,
+                       const float *taps_dev, int radius, hipStream_t stream);
+
+// Device-side record the frame driver shares between its kernels.
+struct NmFrameBook {
+    int num_items;        // descriptors written so far (<= capacity)
+    int oct_base[21];     // first output index of octave o; oct_base[num_octaves] = num_items at the end
+    int lvl_count[20][3]; // accepted keypoints per (octave, level) after the empty-level rule
+    int lvl_base[20][3];  // output index of the first keypoint of (octave, level)
+    int lvl_n[20][3];     // keypoints of (octave, level) that fit under capacity
+};

@@ -1,0 +1,276 @@
+// nm_describe.hip -- keypoint orientation histograms and 128-D descriptors for gfx950, one wavefront per keypoint.
+// Replaces kernels/orientation.cu:11-129,219-230 and kernels/descriptor.cu:32-145,243-255.
+//
+// The reference accumulates its histograms with shared/global float atomicAdd, whose order is undefined. Here the
+// order is fixed (DESIGN.md "fp spec") and implemented without atomics:
+//   orientation: bin b = sum of its votes in raster order of the clipped window (the order of the reference's own
+//                one-thread kernel, orientation.cu:165-176): lane b scans the wave's vote list in LDS.
+//   descriptor : sample p of a 16x16 chunk belongs to partial histogram (p mod 64) = the lane that processes it;
+//                partials accumulate privately in LDS in (chunk, p div 64, dbinx, dbiny, dbint) order and are
+//                combined by a xor-butterfly over lanes (= balanced pairwise tree, strides 1,2,...,32).
+#include "nm_common.hpp"
+#include "nm_fpspec.hpp"
+#include "nm_describe.hpp"
+#include "../../include/nm_abi.h"
+
+using nmfp::fma32;
+using nmfp::fma64;
+
+namespace {
+
+constexpr int ORI_MAXW = 10;                    // 22x22 block of the reference -> W <= 10 (orientation.cu:29-30)
+
+constexpr int ORI_LDS = 448;                    // per-wave slots
+
+// One wave computes the orientation(s) of one keypoint. s_bin/s_val: ORI_LDS entries private to the wave.
+// Returns the number of peaks found (0..2); th0/th1 are valid in every lane.
+__device__ __forceinline__ int orient_wave(const float4 kp, const float2 *__restrict__ grad, int ow, int oh,
+                                           float gauss_factor, float xper, float &th0, float &th1,
+                                           int *s_bin, float *s_val)
+{
+    const int lane = threadIdx.x & 63;
+    th0 = -1.f; th1 = -1.f;
+    if (kp.w < 0) return 0;
+    const float x = kp.x / xper, y = kp.y / xper, s = kp.z / xper;
+    const int xi = (int)((double)x + 0.5), yi = (int)((double)y + 0.5);
+    const float sigma_w = gauss_factor * s;
+    int W = max((int)__builtin_floorf(3 * sigma_w), 1);
+    W = min(ORI_MAXW, W);
+    const float2 *g = grad + (((long)kp.w * oh + yi) * (long)ow + xi);
+    const int xmin = max(-W, -xi), xmax = min(W, ow - 1 - xi);
+    const int ymin = max(-W, -yi), ymax = min(W, oh - 1 - yi);
+    const int nx = xmax - xmin + 1, ny = ymax - ymin + 1;
+    const int n = (nx > 0 && ny > 0) ? nx * ny : 0;
+    const float denom = (2 * sigma_w) * sigma_w;
+    const double r2lim = (double)(W * W) + 0.6;
+
+    for (int p = lane; p < n; p += 64) {
+        const int ry = p / nx, rx = p - ry * nx;
+        const int cx = xmin + rx, cy = ymin + ry;
+        const float dx = (float)(cx + xi) - x, dy = (float)(cy + yi) - y;
+        const float r2 = fma32(dx, dx, dy * dy);
+        int bin = -1;
+        float val = 0.f;
+        if ((double)r2 < r2lim) {
+            const float wgt = nmfp::expf_spec(r2 / denom);
+            const float2 gv = g[(long)cy * ow + cx];
+            const float q = (float)((double)(36.0f * gv.y) / nmfp::TWO_PI_D);
+            bin = ((int)__builtin_floorf(q)) % 36;
+            val = gv.x * wgt;
+        }
+        s_bin[p] = bin;
+        s_val[p] = val;
+    }
+    __builtin_amdgcn_wave_barrier();             // same-wave LDS traffic is in order; this only pins the compiler
+
+    float h = 0.f;                                // lane b < 36 owns bin b
+    for (int p = 0; p < n; ++p) {
+        const int b = s_bin[p];
+        const float v = s_val[p];
+        h += (b == lane) ? v : 0.f;               // +0 leaves h unchanged (h >= +0 always)
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    const int lm = (lane + 35) % 36, lp = (lane + 1) % 36;
+#pragma unroll
+    for (int iter = 0; iter < 6; ++iter) {        // race-free circular 3-tap mean (orientation.cu:181-192)
+        const float prev = __shfl(h, lm), next = __shfl(h, lp);
+        const float nh = (float)((double)((prev + h) + next) / 3.0);
+        h = (lane < 36) ? nh : 0.f;
+    }
+    float m = (lane < 36) ? h : 0.f;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, d));
+    const float threshold = (float)((double)m * 0.8);
+    const float hm = __shfl(h, lm), hp = __shfl(h, lp);
+    const bool peak = (lane < 36) && (h > threshold) && (h > hm) && (h > hp);
+    unsigned long long mask = __ballot(peak);
+    const float di = (float)((-0.5 * (double)(hp - hm)) / (double)((hp + hm) - 2 * h));
+    const float th = (float)((nmfp::TWO_PI_D * ((double)((float)lane + di) + 0.5)) / 36.0);
+    int npk = 0;
+    if (mask) { th0 = __shfl(th, __ffsll((long long)mask) - 1); mask &= mask - 1; npk = 1; }
+    if (mask) { th1 = __shfl(th, __ffsll((long long)mask) - 1); npk = 2; }
+    return npk;
+}
+
+// One wave computes one descriptor. part: 128 x 64 floats of LDS private to the wave, laid out [bin][lane].
+__device__ __forceinline__ void describe_wave(const float4 kp, const float angle0, const float2 *__restrict__ grad,
+                                              int ow, int oh, int num_dogs, float xper, float *__restrict__ desc,
+                                              float *__restrict__ xp, float *__restrict__ yp, float *part)
+{
+    const int lane = threadIdx.x & 63;
+    const float x = kp.x / xper, y = kp.y / xper, s = kp.z / xper;
+    const int xi = (int)((double)x + 0.5), yi = (int)((double)y + 0.5), si = (int)kp.w;
+    if (xi < 0 || xi >= ow || yi < 0 || yi >= oh || si < 0 || si >= num_dogs) return;
+    const float SBP = (float)((double)(3 * s) + 1.e-07);
+    const int W = (int)__builtin_floor(1.41421356237309514547 * (double)SBP * 5 / 2.0 + 0.5);   // sqrt(2.0) in double
+    const int xmin = max(-W, -xi), xmax = min(W, ow - 1 - xi);
+    const int ymin = max(-W, -yi), ymax = min(W, oh - 1 - yi);
+    const int max_dims = max(xmax - xmin, ymax - ymin);
+    const int chunks = (int)__builtin_ceilf((max_dims + 1.f) / 16);
+    if (lane == 0) { *xp = kp.x; *yp = kp.y; }
+    const float2 *gptr = grad + (((long)si * oh + yi) * (long)ow + xi);
+    const double st0 = (double)nmfp::sinf_spec(angle0), ct0 = (double)nmfp::cosf_spec(angle0);
+    const double dSBP = (double)SBP;
+
+#pragma unroll 4
+    for (int b = 0; b < 128; ++b) part[b * 64 + lane] = 0.f;
+    float *mine = part + 80 * 64 + lane;          // origin at the centre bin (descriptor.cu:81)
+
+    for (int c = 0; c < chunks; ++c) {
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {
+            const int p = 64 * q + lane;
+            const int cx = (p & 15) + xmin + 16 * c, cy = (p >> 4) + ymin + 16 * c;
+            if (!(cx <= xmax && cy <= ymax)) continue;
+            const float2 gv = gptr[(long)cy * ow + cx];
+            const float mod = gv.x, ang = gv.y;
+            const float theta = nmfp::mod_2pi_f(ang - angle0);
+            const float dx = (float)(xi + cx) - x, dy = (float)(yi + cy) - y;
+            const float nx = (float)(fma64(ct0, (double)dx, st0 * (double)dy) / dSBP);
+            const float ny = (float)(fma64(-st0, (double)dx, ct0 * (double)dy) / dSBP);
+            const float nt = (float)((double)(8.0f * theta) / nmfp::TWO_PI_D);
+            const float win = (float)nmfp::exp_spec((double)fma32(nx, nx, ny * ny) / 8.0);
+            const int binx = (int)__builtin_floor((double)nx - 0.5);
+            const int biny = (int)__builtin_floor((double)ny - 0.5);
+            const int bint = (int)__builtin_floorf(nt);
+            const float rbinx = (float)((double)nx - ((double)binx + 0.5));
+            const float rbiny = (float)((double)ny - ((double)biny + 0.5));
+            const float rbint = nt - (float)bint;
+            const float wm = win * mod;
+#pragma unroll
+            for (int dbx = 0; dbx < 2; ++dbx)
+#pragma unroll
+                for (int dby = 0; dby < 2; ++dby)
+#pragma unroll
+                    for (int dbt = 0; dbt < 2; ++dbt) {
+                        if (binx + dbx >= -2 && binx + dbx < 2 && biny + dby >= -2 && biny + dby < 2) {
+                            const float wt = wm * __builtin_fabsf((1.f - dbx) - rbinx) *
+                                             __builtin_fabsf((1.f - dby) - rbiny) * __builtin_fabsf((1.f - dbt) - rbint);
+                            const int loc = (binx + dbx) * 8 + (biny + dby) * 32 + ((bint + dbt) % 8);
+                            mine[loc * 64] += wt;
+                        }
+                    }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    float acc0 = 0.f, acc1 = 0.f;
+    for (int b = 0; b < 128; ++b) {
+        float v = part[b * 64 + lane];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) v = v + __shfl_xor(v, d);
+        if (lane == (b & 63)) { if (b < 64) acc0 = v; else acc1 = v; }
+    }
+    desc[lane] = acc0;
+    desc[64 + lane] = acc1;
+}
+
+// ---- API kernels (one octave, one level list per launch) ----
+__global__ __launch_bounds__(256) void orientations_kernel(const float4 *__restrict__ key_pts,
+                                                          const float2 *__restrict__ grad, int num_pts, int ow, int oh,
+                                                          float gauss_factor, float xper, float2 *__restrict__ result)
+{
+    __shared__ int s_bin[4][ORI_LDS];
+    __shared__ float s_val[4][ORI_LDS];
+    const int wave = threadIdx.x >> 6;
+    for (int pt = blockIdx.x * 4 + wave; pt < num_pts; pt += gridDim.x * 4) {
+        float th0, th1;
+        const int npk = orient_wave(key_pts[pt], grad, ow, oh, gauss_factor, xper, th0, th1, s_bin[wave], s_val[wave]);
+        if ((threadIdx.x & 63) == 0) {            // only found peaks are written (orientation.cu:117-128)
+            if (npk >= 1) result[pt].x = th0;
+            if (npk >= 2) result[pt].y = th1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void descriptors_kernel(const float4 *__restrict__ key_pts,
+                                                        const float2 *__restrict__ orients,
+                                                        const float2 *__restrict__ grad, int num_pts, int ow, int oh,
+                                                        int num_dogs, float xper, float *__restrict__ desc,
+                                                        float *__restrict__ xp, float *__restrict__ yp)
+{
+    __shared__ float part[128 * 64];
+    for (int pt = blockIdx.x; pt < num_pts; pt += gridDim.x)
+        describe_wave(key_pts[pt], orients[pt].x, grad, ow, oh, num_dogs, xper, desc + (size_t)pt * 128, xp + pt,
+                      yp + pt, part);
+}
+
+// ---- frame-driver kernels: all octaves of a frame in one launch, counts read from the device-side book ----
+__device__ __forceinline__ int octave_of(const NmFrameBook *book, int num_octaves, int i)
+{
+    int o = 0;
+    while (o + 1 < num_octaves && i >= book->oct_base[o + 1]) ++o;
+    return o;
+}
+
+__global__ __launch_bounds__(256) void frame_orient_kernel(NmDescribeArgs a)
+{
+    __shared__ int s_bin[4][ORI_LDS];
+    __shared__ float s_val[4][ORI_LDS];
+    const int wave = threadIdx.x >> 6;
+    const int n = a.book->num_items;
+    const float4 *kpts = reinterpret_cast<const float4 *>(a.kpts);
+    float2 *orients = reinterpret_cast<float2 *>(a.orients);
+    for (int pt = blockIdx.x * 4 + wave; pt < n; pt += gridDim.x * 4) {
+        const int o = octave_of(a.book, a.num_octaves, pt);
+        float th0, th1;                           // unset components stay -1 (pyramidata.cu:90)
+        orient_wave(kpts[pt], reinterpret_cast<const float2 *>(a.geom[o].grad), a.geom[o].ow, a.geom[o].oh, 1.5f,
+                    a.geom[o].xper, th0, th1, s_bin[wave], s_val[wave]);
+        if ((threadIdx.x & 63) == 0) orients[pt] = make_float2(th0, th1);
+    }
+}
+
+__global__ __launch_bounds__(64) void frame_desc_kernel(NmDescribeArgs a)
+{
+    __shared__ float part[128 * 64];
+    const int n = a.book->num_items;
+    const float4 *kpts = reinterpret_cast<const float4 *>(a.kpts);
+    const float2 *orients = reinterpret_cast<const float2 *>(a.orients);
+    for (int pt = blockIdx.x; pt < n; pt += gridDim.x) {
+        const int o = octave_of(a.book, a.num_octaves, pt);
+        describe_wave(kpts[pt], orients[pt].x, reinterpret_cast<const float2 *>(a.geom[o].grad), a.geom[o].ow,
+                      a.geom[o].oh, a.num_dogs, a.geom[o].xper, a.desc + (size_t)pt * 128, a.x + pt, a.y + pt, part);
+    }
+}
+
+}  // namespace
+
+int nm_launch_frame_describe(const NmDescribeArgs &a, hipStream_t stream)
+{
+    hipLaunchKernelGGL(frame_orient_kernel, dim3(1024), dim3(256), 0, stream, a);
+    NM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(frame_desc_kernel, dim3(1280), dim3(64), 0, stream, a);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" {
+
+int nm_detect_orientations(const float *key_pts, const float *grad, int num_pts, int octave_width, int octave_height,
+                           float gauss_factor, float xper, float *result, void *stream)
+{
+    if (num_pts <= 0) return 0;
+    const int blocks = min(nm_divup(num_pts, 4), 4096);
+    hipLaunchKernelGGL(orientations_kernel, dim3(blocks), dim3(256), 0, nm_stream(stream),
+                       reinterpret_cast<const float4 *>(key_pts), reinterpret_cast<const float2 *>(grad), num_pts,
+                       octave_width, octave_height, gauss_factor, xper, reinterpret_cast<float2 *>(result));
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+int nm_compute_sift_descriptors(const float *key_pts, const float *orients, const float *grad, int num_pts,
+                                int octave_width, int octave_height, int num_dogs, float xper, float *desc, float *x,
+                                float *y, void *stream)
+{
+    if (num_pts <= 0) return 0;
+    const int blocks = min(num_pts, 4096);
+    hipLaunchKernelGGL(descriptors_kernel, dim3(blocks), dim3(64), 0, nm_stream(stream),
+                       reinterpret_cast<const float4 *>(key_pts), reinterpret_cast<const float2 *>(orients),
+                       reinterpret_cast<const float2 *>(grad), num_pts, octave_width, octave_height, num_dogs, xper, desc,
+                       x, y);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,157 @@
+// nm_fpspec.hpp -- device-side floating-point spec of the SIFT kernels (gfx950).
+//
+// The reference's kernels call CUDA's device libm (atan2f, expf, sinf, cosf, exp, pow), which is defined only up
+// to a few ulp. These kernels instead execute ONE fixed sequence of IEEE-754 binary32/binary64 operations per
+// function (Cephes-style reductions, explicit fma), so that results are reproducible run to run and identical to a
+// host evaluation of the same sequence. Translation units that include this header are compiled with
+// -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt; every fused multiply-add is written out.
+//
+// Call sites in the reference: kernels/cudamath.cu:51-52 (atan2f), kernels/orientation.cu:56 (expf),
+// kernels/descriptor.cu:90-91 (sinf, cosf), kernels/descriptor.cu:108 (exp), kernels/keypoint.cu:174 (pow(2,y)).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nmfp {
+
+__device__ __forceinline__ float fma32(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma64(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+__device__ __forceinline__ float pow2i_f(int n) { return __uint_as_float((uint32_t)(n + 127) << 23); }
+__device__ __forceinline__ double pow2i_d(int n) { return __longlong_as_double((long long)((uint64_t)(n + 1023) << 52)); }
+
+constexpr double TWO_PI_D = 6.283185307179586476925286766559;
+constexpr float TWO_PI_F = (float)(2 * 3.14159265358979323846);
+
+// atan(ay/ax), ax > 0, ay >= 0
+__device__ __forceinline__ float atanf_q1(float ay, float ax)
+{
+    const float t = ay / ax;
+    float hi, lo, z;
+    if (t > 2.414213562373095f)       { hi = 1.57079637050628662109375f;  lo = -4.37113900018624283e-8f; z = -(ax / ay); }
+    else if (t > 0.4142135623730950f) { hi = 0.785398185253143310546875f; lo = -2.18556950009312142e-8f; z = (ay - ax) / (ay + ax); }
+    else                              { hi = 0.0f; lo = 0.0f; z = t; }
+    const float zz = z * z;
+    float p = fma32(-0.06459416449069977f, zz, 0.10746313631534576f);
+    p = fma32(p, zz, -0.14264234900474548f);
+    p = fma32(p, zz, 0.1999955028295517f);
+    p = fma32(p, zz, -0.3333333134651184f);
+    p = p * zz;
+    p = fma32(p, z, z);
+    return hi + (p + lo);
+}
+
+__device__ __forceinline__ float atan2f_spec(float y, float x)
+{
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    float r;
+    if (ax == 0.0f) r = (ay == 0.0f) ? 0.0f : 1.57079637050628662109375f;
+    else            r = atanf_q1(ay, ax);
+    if (x < 0.0f) r = (3.1415927410125732421875f - r) + -8.74227800037248566e-8f;
+    if (y < 0.0f) r = -r;
+    return r;
+}
+
+__device__ __forceinline__ float mod_2pi_f(float x)      // kernels/cudamath.h:82-87
+{
+    while (x > TWO_PI_F) x -= TWO_PI_F;
+    while (x < 0.0f) x += TWO_PI_F;
+    return x;
+}
+
+__device__ __forceinline__ float expf_spec(float x)
+{
+    if (x > 88.0f) x = 88.0f;
+    if (x < -87.0f) x = -87.0f;
+    const float z = __builtin_floorf(fma32(1.44269504088896341f, x, 0.5f));
+    const int n = (int)z;
+    float r = fma32(z, -0.693359375f, x);
+    r = fma32(z, 2.12194440e-4f, r);
+    const float rr = r * r;
+    float p = fma32(1.9875691500e-4f, r, 1.3981999507e-3f);
+    p = fma32(p, r, 8.3334519073e-3f);
+    p = fma32(p, r, 4.1665795894e-2f);
+    p = fma32(p, r, 1.6666665459e-1f);
+    p = fma32(p, r, 5.0000001201e-1f);
+    p = fma32(p, rr, r);
+    p = p + 1.0f;
+    return p * pow2i_f(n);
+}
+
+__device__ __forceinline__ void sincos_reduce(float ax, int &j, float &r)
+{
+    int jj = (int)(1.27323954473516f * ax);
+    float y = (float)jj;
+    if (jj & 1) { jj += 1; y += 1.0f; }
+    r = fma32(y, -0.78515625f, ax);
+    r = fma32(y, -2.4187564849853515625e-4f, r);
+    r = fma32(y, -3.77489497744594108e-8f, r);
+    j = jj & 7;
+}
+__device__ __forceinline__ float sinpoly(float r)
+{
+    const float z = r * r;
+    float p = fma32(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    p = fma32(p, z, -1.6666654611e-1f);
+    p = p * z;
+    return fma32(p, r, r);
+}
+__device__ __forceinline__ float cospoly(float r)
+{
+    const float z = r * r;
+    float p = fma32(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    p = fma32(p, z, 4.166664568298827e-2f);
+    p = p * z;
+    p = p * z;
+    p = fma32(-0.5f, z, p);
+    return p + 1.0f;
+}
+__device__ __forceinline__ float sinf_spec(float x)
+{
+    bool neg = x < 0.0f;
+    int j; float r;
+    sincos_reduce(__builtin_fabsf(x), j, r);
+    if (j > 3) { neg = !neg; j -= 4; }
+    const float y = (j == 1 || j == 2) ? cospoly(r) : sinpoly(r);
+    return neg ? -y : y;
+}
+__device__ __forceinline__ float cosf_spec(float x)
+{
+    bool neg = false;
+    int j; float r;
+    sincos_reduce(__builtin_fabsf(x), j, r);
+    if (j > 3) { neg = !neg; j -= 4; }
+    if (j > 1) neg = !neg;
+    const float y = (j == 1 || j == 2) ? sinpoly(r) : cospoly(r);
+    return neg ? -y : y;
+}
+
+__device__ __forceinline__ double exp_spec(double x)
+{
+    if (x > 700.0) x = 700.0;
+    if (x < -700.0) x = -700.0;
+    const double px = __builtin_floor(fma64(1.4426950408889634073599, x, 0.5));
+    const int n = (int)px;
+    x = fma64(px, -6.93145751953125e-1, x);
+    x = fma64(px, -1.42860682030941723212e-6, x);
+    const double xx = x * x;
+    double p = fma64(1.26177193074810590878e-4, xx, 3.02994407707441961300e-2);
+    p = fma64(p, xx, 9.99999999999999999910e-1);
+    p = p * x;
+    double q = fma64(3.00198505138664455042e-6, xx, 2.52448340349684104192e-3);
+    q = fma64(q, xx, 2.27265548208155028766e-1);
+    q = fma64(q, xx, 2.00000000000000000009e0);
+    double r = p / (q - p);
+    r = fma64(2.0, r, 1.0);
+    return r * pow2i_d(n);
+}
+
+__device__ __forceinline__ double exp2_spec(double y)
+{
+    const double n = __builtin_floor(y + 0.5);
+    const double f = y - n;
+    const double r = exp_spec(f * 0.693147180559945309417);
+    return r * pow2i_d((int)n);
+}
+
+}  // namespace nmfp

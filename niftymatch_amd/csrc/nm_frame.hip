@@ -1,0 +1,222 @@
+// nm_frame.hip -- library-level entry points: device helpers, host-side tap generation, and the per-frame driver
+// that runs the reference's implied client loop (orchestration order of sift/siftfunctions.cu:42-181)
+// as one allocation-free, sync-free launch sequence on a stream.
+#include <cmath>
+#include <new>
+#include <vector>
+
+#include "../../include/nm_abi.h"
+#include "../nm/siftparams.h"
+#include "nm_common.hpp"
+#include "nm_describe.hpp"
+#include "nm_keypoint.hpp"
+
+namespace {
+
+__global__ __launch_bounds__(256) void fill_u32_kernel(unsigned int *__restrict__ p, size_t n, unsigned int v)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+}  // namespace
+
+thread_local NmProfSite nm_prof_sites[2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+
+struct nm_sift_arena {
+    int width, height, capacity;
+    SiftParams params;
+    size_t npix;
+    size_t bytes;
+    std::vector<void *> allocs;
+    float *taps_base; int base_radius;
+    float *taps[8]; int radii[8];
+    float *level[6];
+    float *dog[5];
+    float *grad[20];           // per octave: 3 float2 planes
+    float *staging; size_t stage_stride;
+    int *counts, *offsets; int max_blocks;
+    NmFrameBook *book;
+    float *kpts, *orients;     // internal lists used when the caller passes NULL
+
+    template <typename T>
+    int alloc(T **p, size_t n)
+    {
+        void *q = nullptr;
+        const size_t b = n * sizeof(T);
+        hipError_t e = hipMalloc(&q, b ? b : 4);
+        if (e != hipSuccess) return (int)e;
+        allocs.push_back(q);
+        bytes += b;
+        *p = static_cast<T *>(q);
+        return 0;
+    }
+};
+
+extern "C" {
+
+const char *nm_version(void) { return "niftymatch_amd 0.1.0 gfx950"; }
+int nm_device_count(int *count) { return (int)hipGetDeviceCount(count); }
+int nm_set_device(int device) { return (int)hipSetDevice(device); }
+const char *nm_error_string(int status) { return hipGetErrorString((hipError_t)status); }
+
+int nm_profile_events(int site, void *start_event, void *stop_event)
+{
+    if (site < 0 || site >= NM_PROF_SITES) return (int)hipErrorInvalidValue;
+    nm_prof_sites[site].start = static_cast<hipEvent_t>(start_event);
+    nm_prof_sites[site].stop = static_cast<hipEvent_t>(stop_event);
+    return 0;
+}
+
+int nm_fill_u32(void *dst, size_t count, unsigned int pattern, void *stream)
+{
+    if (count == 0) return 0;
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)blocks), dim3(256), 0, nm_stream(stream),
+                       static_cast<unsigned int *>(dst), count, pattern);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+// sift/pyramidata.cu:105-123: radius = ceil(4 sigma); w_j = (float)exp(-0.5 ((j-r)/sigma)^2) with a double exp on the
+// host; normalised by the float running sum.
+int nm_create_kernel_for_sigma(float sigma, float *taps)
+{
+    const int radius = (int)(std::ceil(sigma * 4));
+    const int length = 2 * radius + 1;
+    float sum = 0.f;
+    for (int j = 0; j < length; ++j) {
+        float u = ((float)j - radius) / sigma;
+        u = (float)std::exp(-0.5 * (u * u));
+        if (taps) taps[j] = u;
+        sum += u;
+    }
+    if (taps)
+        for (int j = 0; j < length; ++j) taps[j] = taps[j] / sum;
+    return radius;
+}
+
+int nm_sift_arena_create(int width, int height, int capacity, nm_sift_arena **out)
+{
+    if (!out || width <= 0 || height <= 0 || capacity <= 0) return (int)hipErrorInvalidValue;
+    nm_sift_arena *a = new (std::nothrow) nm_sift_arena();
+    if (!a) return (int)hipErrorOutOfMemory;
+    a->width = width; a->height = height; a->capacity = capacity;
+    a->params = SiftParams(width, height);
+    a->npix = (size_t)width * height;
+    a->bytes = 0;
+    const SiftParams &P = a->params;
+    if (P._num_octaves > 20 || (int)P._sigmas.size() > 8) { delete a; return (int)hipErrorInvalidValue; }
+    int rc = 0;
+    auto upload = [&](float sigma, float **dev, int *radius) -> int {
+        *radius = nm_create_kernel_for_sigma(sigma, nullptr);
+        std::vector<float> h(2 * *radius + 1);
+        nm_create_kernel_for_sigma(sigma, h.data());
+        int e = a->alloc(dev, h.size());
+        if (e) return e;
+        return (int)hipMemcpy(*dev, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
+    };
+    rc = upload(P._base_smooth, &a->taps_base, &a->base_radius);
+    for (size_t i = 0; !rc && i < P._sigmas.size(); ++i) rc = upload(P._sigmas[i], &a->taps[i], &a->radii[i]);
+    for (int i = 0; !rc && i < 6; ++i) rc = a->alloc(&a->level[i], a->npix);
+    for (int i = 0; !rc && i < 5; ++i) rc = a->alloc(&a->dog[i], a->npix);
+    for (int o = 0; !rc && o < P._num_octaves; ++o)
+        rc = a->alloc(&a->grad[o], (size_t)6 * (width >> o) * (height >> o));
+    a->max_blocks = nm_divup((int)a->npix, 256);
+    a->stage_stride = (size_t)a->max_blocks * 256;
+    if (!rc) rc = a->alloc(&a->staging, 3 * a->stage_stride * 4);
+    if (!rc) rc = a->alloc(&a->counts, (size_t)3 * a->max_blocks);
+    if (!rc) rc = a->alloc(&a->offsets, (size_t)3 * a->max_blocks);
+    if (!rc) rc = a->alloc(&a->book, 1);
+    if (!rc) rc = a->alloc(&a->kpts, (size_t)4 * capacity);
+    if (!rc) rc = a->alloc(&a->orients, (size_t)2 * capacity);
+    if (!rc) rc = (int)hipMemset(a->book, 0, sizeof(NmFrameBook));
+    if (!rc) rc = (int)hipDeviceSynchronize();
+    if (rc) { nm_sift_arena_destroy(a); return rc; }
+    *out = a;
+    return 0;
+}
+
+void nm_sift_arena_destroy(nm_sift_arena *a)
+{
+    if (!a) return;
+    for (void *p : a->allocs) (void)hipFree(p);
+    delete a;
+}
+
+size_t nm_sift_arena_bytes(const nm_sift_arena *a) { return a ? a->bytes : 0; }
+float *nm_sift_arena_level(nm_sift_arena *a, int l) { return (a && l >= 0 && l < 6) ? a->level[l] : nullptr; }
+float *nm_sift_arena_dog(nm_sift_arena *a, int d) { return (a && d >= 0 && d < 5) ? a->dog[d] : nullptr; }
+float *nm_sift_arena_grad(nm_sift_arena *a) { return a ? a->grad[0] : nullptr; }
+
+static int octave_pyramid(nm_sift_arena *a, int o, int ow, int oh, hipStream_t st)
+{
+    if (o == 0) nm_prof_begin(NM_PROF_PYRAMID_O0, st);
+    for (int i = 1; i < 6; ++i) {
+        int rc = nm_launch_convolve(a->level[i], a->level[i - 1], nullptr, a->dog[i - 1], ow, oh, a->taps[i - 1],
+                                    a->radii[i - 1], st);
+        if (rc) return rc;
+    }
+    NmGradBatch gb{};
+    const size_t plane = (size_t)ow * oh;
+    for (int l = 0; l < 3; ++l) { gb.src[l] = a->level[l + 1]; gb.dst[l] = a->grad[o] + 2 * l * plane; }
+    gb.n = 3;
+    const int rc = nm_launch_gradient_batch(gb, ow, oh, st);
+    if (o == 0) nm_prof_end(NM_PROF_PYRAMID_O0, st);
+    return rc;
+}
+
+int nm_sift_octave_pyramid(nm_sift_arena *a, int ow, int oh, void *stream)
+{
+    if (!a || ow <= 0 || oh <= 0 || (size_t)ow * oh > a->npix) return (int)hipErrorInvalidValue;
+    return octave_pyramid(a, 0, ow, oh, nm_stream(stream));
+}
+
+int nm_sift_detect_describe(nm_sift_arena *a, const float *gray, float *desc, float *x, float *y, float *kpts,
+                            float *orients, int *d_num_items, void *stream)
+{
+    if (!a || !gray || !desc || !x || !y) return (int)hipErrorInvalidValue;
+    hipStream_t st = nm_stream(stream);
+    const SiftParams &P = a->params;
+    float *kp = kpts ? kpts : a->kpts;
+    float *ori = orients ? orients : a->orients;
+    int rc = nm_launch_convolve(a->level[0], gray, nullptr, nullptr, a->width, a->height, a->taps_base, a->base_radius, st);
+    if (rc) return rc;
+
+    NmDescribeArgs da{};
+    da.num_octaves = P._num_octaves; da.num_dogs = P._num_dog_levels; da.book = a->book;
+    da.kpts = kp; da.orients = ori; da.desc = desc; da.x = x; da.y = y;
+
+    for (int o = 0; o < P._num_octaves; ++o) {
+        const int ow = a->width >> o, oh = a->height >> o;
+        const float xper = (float)std::pow(2.0, o);
+        if (o > 0) {
+            rc = nm_downsample2_f32(a->level[0], ow, oh, a->level[3], a->width >> (o - 1), a->height >> (o - 1), st);
+            if (rc) return rc;
+        }
+        rc = octave_pyramid(a, o, ow, oh, st);
+        if (rc) return rc;
+
+        const int n_blocks = nm_divup(ow * oh, 256);
+        NmDetectArgs d{};
+        for (int i = 0; i < 5; ++i) d.dog[i] = a->dog[i];
+        d.ow = ow; d.oh = oh; d.peak = P._peak_threshold; d.edge = P._edge_threshold; d.xper = xper;
+        d.sigma0 = P._sigma_0; d.num_dogs = P._num_dog_levels; d.staging = a->staging; d.stage_stride = a->stage_stride;
+        d.counts = a->counts; d.n_blocks = n_blocks;
+        NmScanArgs s{};
+        s.counts = a->counts; s.offsets = a->offsets; s.n_blocks = n_blocks; s.octave = o; s.capacity = a->capacity;
+        s.book = a->book; s.d_num_items = d_num_items;
+        NmGatherArgs g{};
+        g.staging = a->staging; g.stage_stride = a->stage_stride; g.counts = a->counts; g.offsets = a->offsets;
+        g.n_blocks = n_blocks; g.octave = o; g.book = a->book; g.kpts = kp;
+        rc = nm_launch_detect_octave(d, s, g, st);
+        if (rc) return rc;
+
+        da.geom[o].grad = a->grad[o]; da.geom[o].ow = ow; da.geom[o].oh = oh; da.geom[o].xper = xper;
+    }
+    return nm_launch_frame_describe(da, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,339 @@
+// nm_keypoint.hip -- DoG extrema, one-shot sub-pixel refinement, ordered (raster) stream compaction for gfx950.
+// Replaces kernels/keypoint.cu:19-251 and the thrust::copy_if of sift/pyramidata.cu:84-91. The reference's texture
+// fetches at (x+0.5,y+0.5) are exact texel loads (utils/cudatex2D.cu:15-19), so planes are read as plain arrays.
+#include "nm_common.hpp"
+#include "nm_fpspec.hpp"
+#include "nm_keypoint.hpp"
+#include "../../include/nm_abi.h"
+
+using nmfp::fma32;
+
+namespace {
+
+template <bool GT>
+__device__ __forceinline__ bool is_extremum(const float *__restrict__ cur, const float *__restrict__ dn,
+                                            const float *__restrict__ up, int x, int y, int w, float cv)
+{
+    const size_t c = (size_t)y * w + x;
+#define NM_CMP(v) if (GT ? !(cv > (v)) : !(cv < (v))) return false;
+    NM_CMP(cur[c - 1]) NM_CMP(cur[c + 1])
+    NM_CMP(cur[c - w - 1]) NM_CMP(cur[c - w]) NM_CMP(cur[c - w + 1])
+    NM_CMP(cur[c + w - 1]) NM_CMP(cur[c + w]) NM_CMP(cur[c + w + 1])
+    NM_CMP(dn[c]) NM_CMP(dn[c - 1]) NM_CMP(dn[c + 1])
+    NM_CMP(dn[c - w - 1]) NM_CMP(dn[c - w]) NM_CMP(dn[c - w + 1])
+    NM_CMP(dn[c + w - 1]) NM_CMP(dn[c + w]) NM_CMP(dn[c + w + 1])
+    NM_CMP(up[c]) NM_CMP(up[c - 1]) NM_CMP(up[c + 1])
+    NM_CMP(up[c - w - 1]) NM_CMP(up[c - w]) NM_CMP(up[c - w + 1])
+    NM_CMP(up[c + w - 1]) NM_CMP(up[c + w]) NM_CMP(up[c + w + 1])
+#undef NM_CMP
+    return true;
+}
+
+// keypoint.cu:108-180. The float/double mix of the reference is kept literally; a*b+c contractions are explicit.
+__device__ __forceinline__ bool refine(const float *__restrict__ cur, const float *__restrict__ dn,
+                                       const float *__restrict__ up, int x, int y, int w, float peak, float edge,
+                                       float xper, float sigma0, int num_dogs, int level, float4 &out)
+{
+    const size_t o = (size_t)y * w + x;
+#define C_(dx, dy) cur[o + (dy) * w + (dx)]
+#define D_(dx, dy) dn[o + (dy) * w + (dx)]
+#define U_(dx, dy) up[o + (dy) * w + (dx)]
+    const float c = C_(0, 0);
+    const float fx = (float)(0.5 * (double)(C_(1, 0) - C_(-1, 0)));
+    const float fy = (float)(0.5 * (double)(C_(0, 1) - C_(0, -1)));
+    const float fs = (float)(0.5 * (double)(U_(0, 0) - D_(0, 0)));
+    const float fxx = (float)((double)(C_(1, 0) + C_(-1, 0)) - 2.0 * (double)c);
+    const float fyy = (float)((double)(C_(0, 1) + C_(0, -1)) - 2.0 * (double)c);
+    const float fss = (float)((double)(U_(0, 0) + D_(0, 0)) - 2.0 * (double)c);
+    const float fxy = (float)(0.25 * (double)(((C_(1, 1) + C_(-1, -1)) - C_(-1, 1)) - C_(1, -1)));
+    const float fxs = (float)(0.25 * (double)(((U_(1, 0) + D_(-1, 0)) - U_(-1, 0)) - D_(1, 0)));
+    const float fys = (float)(0.25 * (double)(((U_(0, 1) + D_(0, -1)) - U_(0, -1)) - D_(0, 1)));
+#undef C_
+#undef D_
+#undef U_
+    float4 A0 = fxx > 0 ? make_float4(fxx, fxy, fxs, -fx) : make_float4(-fxx, -fxy, -fxs, fx);
+    float4 A1 = fxy > 0 ? make_float4(fxy, fyy, fys, -fy) : make_float4(-fxy, -fyy, -fys, fy);
+    float4 A2 = fxs > 0 ? make_float4(fxs, fys, fss, -fs) : make_float4(-fxs, -fys, -fss, fs);
+    float4 t;
+    const float max_a = __builtin_fmaxf(__builtin_fmaxf(A0.x, A1.x), A2.x);
+    if (!((double)max_a >= 1e-10)) return false;
+    if (max_a == A1.x)      { t = A1; A1 = A0; A0 = t; }
+    else if (max_a == A2.x) { t = A2; A2 = A0; A0 = t; }
+    A0.y /= A0.x; A0.z /= A0.x; A0.w /= A0.x;
+    A1.y = fma32(-A1.x, A0.y, A1.y); A1.z = fma32(-A1.x, A0.z, A1.z); A1.w = fma32(-A1.x, A0.w, A1.w);
+    A2.y = fma32(-A2.x, A0.y, A2.y); A2.z = fma32(-A2.x, A0.z, A2.z); A2.w = fma32(-A2.x, A0.w, A2.w);
+    if (__builtin_fabsf(A2.y) > __builtin_fabsf(A1.y)) { t = A2; A2 = A1; A1 = t; }
+    if (!((double)__builtin_fabsf(A1.y) >= 1e-10)) return false;
+    A1.z /= A1.y; A1.w /= A1.y;
+    A2.z = fma32(-A2.y, A1.z, A2.z); A2.w = fma32(-A2.y, A1.w, A2.w);
+    if (!((double)__builtin_fabsf(A2.z) >= 1e-10)) return false;
+    const float ds = A2.w / A2.z;
+    const float dy = fma32(-ds, A1.z, A1.w);
+    const float dx = fma32(-dy, A0.y, fma32(-ds, A0.z, A0.w));
+    const float tt = fma32(ds, fs, fma32(dx, fx, dy * fy));
+    const float v = (float)((double)c + 0.5 * (double)tt);
+    const float tr = fxx + fyy;
+    const float s = (tr * tr) / fma32(fxx, fyy, -(fxy * fxy));
+    const float ethr = ((edge + 1) * (edge + 1)) / edge;
+    if ((__builtin_fabsf(v) > peak) && s < ethr && __builtin_fabsf(dx) < 1 && __builtin_fabsf(dy) < 1 &&
+        __builtin_fabsf(ds) < 1) {
+        out.x = ((float)x + dx) * xper;
+        out.y = ((float)y + dy) * xper;
+        out.z = (float)(((double)sigma0 * nmfp::exp2_spec((double)((float)level + ds) / (double)num_dogs)) * (double)xper);
+        out.w = (float)level;
+        return true;
+    }
+    return false;
+}
+
+// Bilinear, border-addressed, unnormalised fetch of the full-resolution mask (utils/cudatex2D.cu:15-19).
+__device__ __forceinline__ float mask_fetch(const float *__restrict__ mask, int mw, int mh, float u, float v)
+{
+    const float xb = u - 0.5f, yb = v - 0.5f;
+    const float fi = __builtin_floorf(xb), fj = __builtin_floorf(yb);
+    const float a = xb - fi, b = yb - fj;
+    const int i = (int)fi, j = (int)fj;
+    auto T = [&](int ii, int jj) -> float {
+        return (ii >= 0 && ii < mw && jj >= 0 && jj < mh) ? mask[(size_t)jj * mw + ii] : 0.f;
+    };
+    return (1 - a) * (1 - b) * T(i, j) + a * (1 - b) * T(i + 1, j) + (1 - a) * b * T(i, j + 1) + a * b * T(i + 1, j + 1);
+}
+
+// One test + refinement of pixel (x,y); true when accepted.
+__device__ __forceinline__ bool detect_pixel(const float *__restrict__ cur, const float *__restrict__ dn,
+                                             const float *__restrict__ up, int x, int y, int w, int h, float peak,
+                                             float edge, float xper, float sigma0, int num_dogs, int level,
+                                             float4 &kp)
+{
+    if (x < 1 || x > w - 2 || y < 1 || y > h - 2) return false;
+    const float c = cur[(size_t)y * w + x];
+    const float thr = 0.8f * peak;
+    const bool cand = (c <= thr && is_extremum<false>(cur, dn, up, x, y, w, c)) ||
+                      (c >= thr && is_extremum<true>(cur, dn, up, x, y, w, c));
+    if (!cand) return false;
+    return refine(cur, dn, up, x, y, w, peak, edge, xper, sigma0, num_dogs, level, kp);
+}
+
+// ---- API kernels: dense float4 map ----
+__global__ __launch_bounds__(256) void find_keypoints_dense_kernel(const float *__restrict__ cur,
+                                                                  const float *__restrict__ dn,
+                                                                  const float *__restrict__ up,
+                                                                  const float *__restrict__ mask, int mw, int mh,
+                                                                  int w, int h, float peak, float edge, float xper,
+                                                                  float sigma0, int num_dogs, int level,
+                                                                  float4 *__restrict__ result)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    if (mask) {
+        if (x < 1 || x > w - 2 || y < 1 || y > h - 2) return;
+        if (mask_fetch(mask, mw, mh, ((float)x + 0.5f) * xper, ((float)y + 0.5f) * xper) < 1.f) return;
+    }
+    float4 kp;
+    if (detect_pixel(cur, dn, up, x, y, w, h, peak, edge, xper, sigma0, num_dogs, level, kp))
+        result[(size_t)y * w + x] = kp;
+}
+
+// Ordered in-block compaction helper: returns this thread's rank among the block's flagged threads (block-wide,
+// in thread order) and the block total. 256 threads = 4 waves.
+__device__ __forceinline__ int block_rank(bool flag, int &total, int *s_wave /* [4] */)
+{
+    const unsigned long long m = __ballot(flag);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    __syncthreads();
+    int off = 0;
+    total = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = s_wave[i];
+        if (i < wave) off += c;
+        total += c;
+    }
+    return off + rank;
+}
+
+__global__ __launch_bounds__(256) void count_valid_kernel(const float4 *__restrict__ dense, int n,
+                                                         int *__restrict__ counts)
+{
+    __shared__ int s_wave[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool f = (i < n) && (dense[i].w >= 0);
+    int total;
+    block_rank(f, total, s_wave);
+    if (threadIdx.x == 0) counts[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void scatter_valid_kernel(const float4 *__restrict__ dense, int n,
+                                                           const int *__restrict__ offsets,
+                                                           float4 *__restrict__ out)
+{
+    __shared__ int s_wave[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float4 v = make_float4(-1, -1, -1, -1);
+    if (i < n) v = dense[i];
+    const bool f = (i < n) && (v.w >= 0);
+    int total;
+    const int r = block_rank(f, total, s_wave);
+    if (f) out[offsets[blockIdx.x] + r] = v;
+}
+
+// Exclusive scan of n ints by ONE workgroup of 1024 threads; returns the total to every thread.
+__device__ int block_exclusive_scan_1024(const int *__restrict__ in, int *__restrict__ out, int n, int *s /* [1024+1] */)
+{
+    const int t = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int beg = t * per, end = min(beg + per, n);
+    int sum = 0;
+    for (int i = beg; i < end; ++i) sum += in[i];
+    s[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {          // Hillis-Steele inclusive scan
+        int v = 0;
+        if (t >= d) v = s[t - d];
+        __syncthreads();
+        s[t] += v;
+        __syncthreads();
+    }
+    const int total = s[1023];
+    int run = s[t] - sum;
+    for (int i = beg; i < end; ++i) { const int c = in[i]; out[i] = run; run += c; }
+    __syncthreads();
+    return total;
+}
+
+__global__ __launch_bounds__(1024) void scan_counts_kernel(const int *__restrict__ counts, int *__restrict__ offsets,
+                                                          int n, int *__restrict__ total_out)
+{
+    __shared__ int s[1024];
+    const int total = block_exclusive_scan_1024(counts, offsets, n, s);
+    if (threadIdx.x == 0 && total_out) *total_out = total;
+}
+
+// ---- frame-driver kernels: detect 3 levels of one octave straight into per-block staging, then scan + book-keeping,
+//      then gather into the output-ordered keypoint list ----
+__global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
+{
+    __shared__ int s_wave[4];
+    const int level = blockIdx.y;
+    const float *__restrict__ cur = a.dog[level + 1];
+    const float *__restrict__ dn = a.dog[level];
+    const float *__restrict__ up = a.dog[level + 2];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    bool f = false;
+    float4 kp;
+    if (idx < a.ow * a.oh) {
+        const int y = idx / a.ow, x = idx - y * a.ow;
+        f = detect_pixel(cur, dn, up, x, y, a.ow, a.oh, a.peak, a.edge, a.xper, a.sigma0, a.num_dogs, level, kp);
+    }
+    int total;
+    const int r = block_rank(f, total, s_wave);
+    float4 *st = reinterpret_cast<float4 *>(a.staging) + (size_t)level * a.stage_stride + (size_t)blockIdx.x * 256;
+    if (f) st[r] = kp;
+    if (threadIdx.x == 0) a.counts[level * a.n_blocks + blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void scan_book_kernel(NmScanArgs a)
+{
+    __shared__ int s[1024];
+    __shared__ int totals[3];
+    for (int l = 0; l < 3; ++l) {
+        const int tot = block_exclusive_scan_1024(a.counts + l * a.n_blocks, a.offsets + l * a.n_blocks, a.n_blocks, s);
+        if (threadIdx.x == 0) totals[l] = tot;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        NmFrameBook *b = a.book;
+        int num_items = (a.octave == 0) ? 0 : b->num_items;
+        b->oct_base[a.octave] = num_items;
+        bool live = true;                         // sift/siftfunctions.cu:145,160: an empty level ends the octave
+        for (int l = 0; l < 3; ++l) {
+            int cnt = live ? totals[l] : 0;
+            if (cnt == 0) live = false;
+            int n = cnt;
+            if (n + num_items > a.capacity) n = a.capacity - num_items;   // siftfunctions.cu:165-169
+            if (n < 0) n = 0;
+            b->lvl_count[a.octave][l] = cnt;
+            b->lvl_base[a.octave][l] = num_items;
+            b->lvl_n[a.octave][l] = n;
+            num_items += n;
+        }
+        b->num_items = num_items;
+        b->oct_base[a.octave + 1] = num_items;
+        if (a.d_num_items) *a.d_num_items = num_items;
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_stage_kernel(NmGatherArgs a)
+{
+    const int level = blockIdx.y;
+    const int cnt = a.counts[level * a.n_blocks + blockIdx.x];
+    if ((int)threadIdx.x >= cnt) return;
+    const int pos = a.offsets[level * a.n_blocks + blockIdx.x] + threadIdx.x;
+    if (pos >= a.book->lvl_n[a.octave][level]) return;
+    const float4 *st = reinterpret_cast<const float4 *>(a.staging) + (size_t)level * a.stage_stride + (size_t)blockIdx.x * 256;
+    reinterpret_cast<float4 *>(a.kpts)[a.book->lvl_base[a.octave][level] + pos] = st[threadIdx.x];
+}
+
+}  // namespace
+
+int nm_launch_detect_octave(const NmDetectArgs &d, const NmScanArgs &s, const NmGatherArgs &g, hipStream_t stream)
+{
+    if (d.n_blocks <= 0) return 0;
+    hipLaunchKernelGGL(detect_stage_kernel, dim3(d.n_blocks, 3), dim3(256), 0, stream, d);
+    NM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_book_kernel, dim3(1), dim3(1024), 0, stream, s);
+    NM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gather_stage_kernel, dim3(g.n_blocks, 3), dim3(256), 0, stream, g);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" {
+
+int nm_find_keypoints_masked_f32(const float *current, const float *mask, int mask_width, int mask_height,
+                                 const float *down, const float *up, int width, int height, float peak_threshold,
+                                 float edge_threshold, float xper, float sigma_0, int num_dogs, int dog, float *result,
+                                 void *stream)
+{
+    if (width <= 0 || height <= 0) return 0;
+    dim3 grid(nm_divup(width, 64), nm_divup(height, 4));
+    hipLaunchKernelGGL(find_keypoints_dense_kernel, grid, dim3(256), 0, nm_stream(stream), current, down, up, mask,
+                       mask_width, mask_height, width, height, peak_threshold, edge_threshold, xper, sigma_0, num_dogs,
+                       dog, reinterpret_cast<float4 *>(result));
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+int nm_find_keypoints_f32(const float *current, const float *down, const float *up, int width, int height,
+                          float peak_threshold, float edge_threshold, float xper, float sigma_0, int num_dogs, int dog,
+                          float *result, void *stream)
+{
+    return nm_find_keypoints_masked_f32(current, nullptr, 0, 0, down, up, width, height, peak_threshold, edge_threshold,
+                                        xper, sigma_0, num_dogs, dog, result, stream);
+}
+
+size_t nm_compact_workspace_bytes(int num_pixels)
+{
+    const size_t nb = (size_t)nm_divup(num_pixels > 0 ? num_pixels : 1, 256);
+    return 2 * nb * sizeof(int);
+}
+
+int nm_compact_keypoints(const float *dense, int num_pixels, float *out, int *d_count, void *workspace, void *stream)
+{
+    hipStream_t st = nm_stream(stream);
+    if (num_pixels <= 0) return (int)hipMemsetAsync(d_count, 0, sizeof(int), st);
+    const int nb = nm_divup(num_pixels, 256);
+    int *counts = static_cast<int *>(workspace), *offsets = counts + nb;
+    hipLaunchKernelGGL(count_valid_kernel, dim3(nb), dim3(256), 0, st, reinterpret_cast<const float4 *>(dense), num_pixels, counts);
+    NM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, st, counts, offsets, nb, d_count);
+    NM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scatter_valid_kernel, dim3(nb), dim3(256), 0, st, reinterpret_cast<const float4 *>(dense), num_pixels,
+                       offsets, reinterpret_cast<float4 *>(out));
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

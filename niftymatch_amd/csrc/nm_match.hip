@@ -1,0 +1,516 @@
+// nm_match.hip -- brute-force 128-D squared-L2 matcher for gfx950.
+// Replaces kernels/transpose.cu:9-40, kernels/match.cu:14-150 and sift/siftfunctions.cu:15-40.
+//
+// Fused path (nm_sift_match_f32 / nm_sift_match_shard_f32), never materialising the nA x nB matrix:
+//   1. norms_kernel        ||a||^2, ||b||^2
+//   2. match_top2_kernel   fp32 MFMA (v_mfma_f32_32x32x2_f32): d~[j][i] = nb_j + na_i - 2 a_i.b_j as ONE accumulation
+//                          chain (K = 128 products + 1 augmented k-pair carrying the norms); every lane keeps a running
+//                          best/second-best per query over the candidates it sees; partial lists per candidate chunk.
+//   3. match_finalize_kernel  per query: pick the 4 best partial candidates, recompute their distances EXACTLY in the
+//                          reference's order (sum_k fma(t,t,acc), t = a_k - b_k, k ascending: match.cu:36-42), then apply
+//                          the scan semantics of match.cu:91-116 (lowest index wins ties, min2 initial 2139095040.0f,
+//                          result untouched when min2 <= 0).
+// API building blocks (transpose / bf_distance / get_sift_matches) keep the reference's layouts and are exact.
+#include "nm_common.hpp"
+#include "../../include/nm_abi.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int DIM = 128;
+constexpr int KP = 132;            // LDS row pitch (floats): 128 data + norm slot + pad; 132 mod 64 = 4 -> b128 reads conflict-free
+constexpr int TILE_C = 128;        // candidates per LDS tile
+constexpr int QB = 256;            // queries per workgroup (64 per wave, fragments resident in VGPRs)
+constexpr float MIN2_INIT = 2139095040.0f;   // (float)0x7f800000, match.cu:91
+
+struct MatchPlan { int qblocks, S, chunk; };
+
+static MatchPlan make_plan(int nA, int nB)
+{
+    MatchPlan p;
+    p.qblocks = nm_divup(nA > 0 ? nA : 1, QB);
+    const int tiles = nm_divup(nB > 0 ? nB : 1, TILE_C);
+    int S = nm_divup(768, p.qblocks);
+    if (S > tiles) S = tiles;
+    if (S < 1) S = 1;
+    p.chunk = nm_divup(nm_divup(nB > 0 ? nB : 1, S), TILE_C) * TILE_C;
+    p.S = nm_divup(nB > 0 ? nB : 1, p.chunk);
+    return p;
+}
+
+__global__ __launch_bounds__(256) void norms_kernel(const float *__restrict__ X, int n, float *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 *row = reinterpret_cast<const float4 *>(X + (size_t)i * DIM);
+    float acc = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < DIM / 4; ++k) {
+        const float4 v = row[k];
+        acc = __builtin_fmaf(v.x, v.x, acc); acc = __builtin_fmaf(v.y, v.y, acc);
+        acc = __builtin_fmaf(v.z, v.z, acc); acc = __builtin_fmaf(v.w, v.w, acc);
+    }
+    out[i] = acc;
+}
+
+struct Top2 { float m1, m2; int i1, i2; };
+
+__device__ __forceinline__ void top2_insert(Top2 &t, float d, int j)
+{
+    const bool lt1 = d < t.m1, lt2 = d < t.m2;
+    t.m2 = lt1 ? t.m1 : (lt2 ? d : t.m2);
+    t.i2 = lt1 ? t.i1 : (lt2 ? j : t.i2);
+    t.m1 = lt1 ? d : t.m1;
+    t.i1 = lt1 ? j : t.i1;
+}
+
+// grid = (qblocks, S). Dynamic LDS: 2 * TILE_C * KP floats.
+__global__ __launch_bounds__(256, 1) void match_top2_kernel(const float *__restrict__ A, int nA,
+                                                           const float *__restrict__ B, int nB,
+                                                           const float *__restrict__ na, const float *__restrict__ nb,
+                                                           int chunk, int S, float4 *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int i0 = blockIdx.x * QB;
+    const int s = blockIdx.y;
+    const int c0 = s * chunk;
+    const int cend = min(c0 + chunk, nB);
+    const int ntiles = (cend > c0) ? (cend - c0 + TILE_C - 1) / TILE_C : 0;
+    const int srow = tid >> 5, scol = (tid & 31) * 4;     // staging coordinates: 8 rows x 32 float4 per pass
+
+    // ---- prologue: queries -> LDS (coalesced) -> per-lane MFMA fragments in VGPRs ----
+#pragma unroll 4
+    for (int it = 0; it < QB / 8; ++it) {
+        const int row = srow + 8 * it;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i0 + row < nA) v = *reinterpret_cast<const float4 *>(A + (size_t)(i0 + row) * DIM + scol);
+        *reinterpret_cast<float4 *>(&lds[row * KP + scol]) = v;
+    }
+    __syncthreads();
+    float4 qf[2][16];
+    float nq[2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const int row = wave * 64 + 32 * ti + r;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) qf[ti][t] = *reinterpret_cast<const float4 *>(&lds[row * KP + 8 * t + 4 * h]);
+        const int qi = i0 + row;
+        const float nav = (qi < nA) ? na[qi] : 0.f;
+        nq[ti] = (h == 0) ? 1.0f : nav;
+    }
+    __syncthreads();
+
+    Top2 best[2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) { best[ti].m1 = best[ti].m2 = __builtin_inff(); best[ti].i1 = best[ti].i2 = -1; }
+
+    float4 st[16];
+    float stn = 0.f;
+    auto stage_load = [&](int n) {
+        const int jb = c0 + n * TILE_C;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int j = jb + srow + 8 * it;
+            st[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < cend) st[it] = *reinterpret_cast<const float4 *>(B + (size_t)j * DIM + scol);
+        }
+        if (tid < TILE_C) stn = (jb + tid < cend) ? nb[jb + tid] : __builtin_inff();
+    };
+    auto stage_write = [&](float *buf) {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int row = srow + 8 * it;
+            const float4 v = st[it];
+            *reinterpret_cast<float4 *>(&buf[row * KP + scol]) = make_float4(-2.f * v.x, -2.f * v.y, -2.f * v.z, -2.f * v.w);
+        }
+        if (tid < TILE_C) buf[tid * KP + DIM] = stn;
+    };
+
+    if (ntiles > 0) { stage_load(0); stage_write(lds); }
+    __syncthreads();
+
+    for (int n = 0; n < ntiles; ++n) {
+        float *buf = lds + (n & 1) * (TILE_C * KP);
+        if (n + 1 < ntiles) stage_load(n + 1);
+        const int jb = c0 + n * TILE_C;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            f32x16 acc[2][2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[g][ti][e] = 0.f;
+            const float *rowp[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) rowp[g] = buf + (half * 64 + 32 * g + r) * KP;
+            // augmented k-pair: (nb_j * 1) + (1 * na_i)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const float nbv = rowp[g][DIM];
+                const float cn = (h == 0) ? nbv : 1.0f;
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+                    acc[g][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(cn, nq[ti], acc[g][ti], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                float4 cf[2];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) cf[g] = *reinterpret_cast<const float4 *>(rowp[g] + 8 * t + 4 * h);
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int ti = 0; ti < 2; ++ti) {
+                        acc[g][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[g].x, qf[ti][t].x, acc[g][ti], 0, 0, 0);
+                        acc[g][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[g].y, qf[ti][t].y, acc[g][ti], 0, 0, 0);
+                        acc[g][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[g].z, qf[ti][t].z, acc[g][ti], 0, 0, 0);
+                        acc[g][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[g].w, qf[ti][t].w, acc[g][ti], 0, 0, 0);
+                    }
+            }
+            // running best / second best. Within a lane the candidate index increases with (half, g, e).
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float d = acc[g][ti][e];
+                        if (__any(d < best[ti].m2)) {
+                            const int j = jb + half * 64 + 32 * g + (e & 3) + 8 * (e >> 2) + 4 * h;
+                            top2_insert(best[ti], d, j);
+                        }
+                    }
+        }
+        if (n + 1 < ntiles) stage_write(lds + ((n + 1) & 1) * (TILE_C * KP));
+        __syncthreads();
+    }
+
+    // merge the two lane halves (same query, disjoint candidates) and publish
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        Top2 o;
+        o.m1 = __shfl_xor(best[ti].m1, 32); o.m2 = __shfl_xor(best[ti].m2, 32);
+        o.i1 = __shfl_xor(best[ti].i1, 32); o.i2 = __shfl_xor(best[ti].i2, 32);
+        Top2 m = best[ti];
+        if (o.i1 >= 0) top2_insert(m, o.m1, o.i1);
+        if (o.i2 >= 0) top2_insert(m, o.m2, o.i2);
+        const int qi = i0 + wave * 64 + 32 * ti + r;
+        if (h == 0 && qi < nA)
+            partial[(size_t)qi * S + s] = make_float4(m.m1, __int_as_float(m.i1), m.m2, __int_as_float(m.i2));
+    }
+}
+
+__device__ __forceinline__ float exact_dist(const float4 *__restrict__ a, const float4 *__restrict__ b)
+{
+    float acc = 0.0f;
+#pragma unroll 8
+    for (int k = 0; k < DIM / 4; ++k) {
+        const float4 x = a[k], y = b[k];
+        float t;
+        t = x.x - y.x; acc = __builtin_fmaf(t, t, acc);
+        t = x.y - y.y; acc = __builtin_fmaf(t, t, acc);
+        t = x.z - y.z; acc = __builtin_fmaf(t, t, acc);
+        t = x.w - y.w; acc = __builtin_fmaf(t, t, acc);
+    }
+    return acc;
+}
+
+// One thread per query: approximate top-4 of the 2*S partial candidates -> exact distances -> (min1, idx, min2).
+// mode 0: apply the ratio test and write result[i]; mode 1: emit the shard triple (min1, idx + index_offset, min2).
+__global__ __launch_bounds__(256) void match_finalize_kernel(const float *__restrict__ A, int nA,
+                                                            const float *__restrict__ B, int nB, int S,
+                                                            const float4 *__restrict__ partial, int mode,
+                                                            int index_offset, float ambiguity, int *__restrict__ result,
+                                                            float *__restrict__ min1_out, int *__restrict__ idx_out,
+                                                            float *__restrict__ min2_out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nA) return;
+    float cd[4]; int ci[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { cd[k] = __builtin_inff(); ci[k] = -1; }
+    for (int s = 0; s < S; ++s) {
+        const float4 p = partial[(size_t)i * S + s];
+        const float dd[2] = {p.x, p.z};
+        const int jj[2] = {__float_as_int(p.y), __float_as_int(p.w)};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float d = dd[c]; int j = jj[c];
+            if (j < 0) continue;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {            // sorted insertion by (approx distance, index)
+                const bool lt = (d < cd[k]) || (d == cd[k] && j < ci[k]);
+                if (lt) { const float td = cd[k]; const int tj = ci[k]; cd[k] = d; ci[k] = j; d = td; j = tj; }
+            }
+        }
+    }
+    const float4 *a = reinterpret_cast<const float4 *>(A + (size_t)i * DIM);
+    float m1 = 0.f, m2 = MIN2_INIT; int idx = 0; bool have = false;
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+        if (ci[k] < 0) continue;
+        const float d = exact_dist(a, reinterpret_cast<const float4 *>(B + (size_t)ci[k] * DIM));
+        if (!have) { m1 = d; idx = ci[k]; have = true; }
+        else if (d < m1 || (d == m1 && ci[k] < idx)) { m2 = m1; m1 = d; idx = ci[k]; }
+        else if (d < m2) m2 = d;
+    }
+    if (!have) return;
+    if (mode == 1) {
+        min1_out[i] = m1; idx_out[i] = idx + index_offset; min2_out[i] = m2;
+        return;
+    }
+    if (m2 > 0) {
+        const float q = m1 / m2;
+        result[i] = (q < ambiguity) ? idx : -1;
+    }
+}
+
+// Multi-GPU merge: shard-major triples, ascending shard order, strict < so the lowest global index wins ties.
+__global__ __launch_bounds__(256) void match_merge_kernel(const float *__restrict__ min1, const int *__restrict__ idx1,
+                                                         const float *__restrict__ min2, int n_shards, int nA,
+                                                         float ambiguity, int *__restrict__ result)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nA) return;
+    float m1 = min1[i], m2 = min2[i]; int idx = idx1[i];
+    for (int g = 1; g < n_shards; ++g) {
+        const float a1 = min1[(size_t)g * nA + i], a2 = min2[(size_t)g * nA + i];
+        const int ai = idx1[(size_t)g * nA + i];
+        if (a1 < m1) { m2 = (m1 < a2) ? m1 : a2; m1 = a1; idx = ai; }
+        else { const float c = (a1 < m2) ? a1 : m2; m2 = c; }
+    }
+    if (m2 > 0) {
+        const float q = m1 / m2;
+        result[i] = (q < ambiguity) ? idx : -1;
+    }
+}
+
+// ---- exact API building blocks ----
+__global__ __launch_bounds__(256) void transpose_kernel(float *__restrict__ odata, const float *__restrict__ idata,
+                                                       int width, int height)
+{
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    int x = blockIdx.x * 32 + tx;
+    for (int k = 0; k < 32; k += 8) {
+        const int y = blockIdx.y * 32 + ty + k;
+        if (x < width && y < height) tile[ty + k][tx] = idata[(size_t)y * width + x];
+    }
+    __syncthreads();
+    x = blockIdx.y * 32 + tx;                                     // output column = input row
+    for (int k = 0; k < 32; k += 8) {
+        const int y = blockIdx.x * 32 + ty + k;                   // output row = input column
+        if (x < height && y < width) odata[(size_t)y * height + x] = tile[tx][ty + k];
+    }
+}
+
+// Exact squared distances of a 64 (lane side) x 64 (register side) tile: every thread owns one lane-side vector and
+// 16 register-side vectors; k ascending, acc = fma(t, t, acc) with t = a_k - b_k (match.cu:36-42).
+// L: lane-side set (nL vectors), Rm: register-side set. Element (v,k) of a set is X[v*DIM+k], or X[k*n+v] when
+// transposed. out[(lane index)*ldl + (reg index)*ldr].
+template <bool L_TRANSPOSED>
+__global__ __launch_bounds__(256) void exact_distance_kernel(const float *__restrict__ L, int nL,
+                                                            const float *__restrict__ Rm, int nR,
+                                                            float *__restrict__ out, size_t ldl, size_t ldr,
+                                                            bool l_is_a)
+{
+    __shared__ float sL[64 * 129];
+    __shared__ float sR[64 * 129];
+    const int tid = threadIdx.x;
+    const int l0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    if (L_TRANSPOSED) {
+        for (int e = tid; e < 64 * DIM; e += 256) {
+            const int k = e >> 6, v = e & 63;
+            sL[v * 129 + k] = (l0 + v < nL) ? L[(size_t)k * nL + l0 + v] : 0.f;
+        }
+    } else {
+        for (int e = tid; e < 64 * DIM; e += 256) {
+            const int v = e >> 7, k = e & 127;
+            sL[v * 129 + k] = (l0 + v < nL) ? L[(size_t)(l0 + v) * DIM + k] : 0.f;
+        }
+    }
+    for (int e = tid; e < 64 * DIM; e += 256) {
+        const int v = e >> 7, k = e & 127;
+        sR[v * 129 + k] = (r0 + v < nR) ? Rm[(size_t)(r0 + v) * DIM + k] : 0.f;
+    }
+    __syncthreads();
+    const int lv = tid & 63, rg = tid >> 6;
+    float acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    for (int k = 0; k < DIM; ++k) {
+        const float x = sL[lv * 129 + k];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float y = sR[(rg * 16 + q) * 129 + k];
+            const float t = l_is_a ? (x - y) : (y - x);
+            acc[q] = __builtin_fmaf(t, t, acc[q]);
+        }
+    }
+    if (l0 + lv < nL) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int rv = r0 + rg * 16 + q;
+            if (rv < nR) out[(size_t)(l0 + lv) * ldl + (size_t)rv * ldr] = acc[q];
+        }
+    }
+}
+
+// One wave per row: lane-local ascending scan + wave merge of (min1, lowest index, multiset second minimum).
+__global__ __launch_bounds__(256) void set_matches_kernel(int *__restrict__ result, const float *__restrict__ distance,
+                                                         int rows, int cols, int buffer_width, float ambiguity)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *d = distance + (size_t)row * buffer_width;
+    float m1 = __builtin_inff(), m2 = __builtin_inff(); int i1 = 0x7fffffff;
+    for (int j = lane; j < cols; j += 64) {
+        const float c = d[j];
+        if (c < m1) { m2 = m1; m1 = c; i1 = j; }
+        else if (c < m2) m2 = c;
+    }
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const float o1 = __shfl_xor(m1, s), o2 = __shfl_xor(m2, s);
+        const int oi = __shfl_xor(i1, s);
+        const bool take = (o1 < m1) || (o1 == m1 && oi < i1);
+        const float lo = take ? o1 : m1, hi = take ? m1 : o1;        // hi = the larger of the two minima
+        const float s2 = take ? o2 : m2;                              // second of the winner's own list
+        i1 = take ? oi : i1;
+        m1 = lo;
+        m2 = (hi < s2) ? hi : s2;                                     // the loser's own second is >= hi
+    }
+    if (lane == 0) {
+        if (MIN2_INIT < m2) m2 = MIN2_INIT;                           // the scan starts min2 at 2139095040.0f
+        if (m2 > 0) {
+            const float q = m1 / m2;
+            result[row] = (q < ambiguity) ? i1 : -1;
+        }
+    }
+}
+
+struct MatchWs { float *na, *nb; float4 *partial; };
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static MatchWs carve(void *workspace, int nA, int nB, const MatchPlan &p)
+{
+    MatchWs w;
+    char *base = static_cast<char *>(workspace);
+    w.na = reinterpret_cast<float *>(base); base += align256((size_t)nA * 4);
+    w.nb = reinterpret_cast<float *>(base); base += align256((size_t)nB * 4);
+    w.partial = reinterpret_cast<float4 *>(base);
+    (void)p;
+    return w;
+}
+
+static int run_fused(const float *A, int nA, const float *B, int nB, int mode, int index_offset, float ambiguity,
+                     int *result, float *min1, int *idx1, float *min2, void *workspace, hipStream_t st)
+{
+    if (nA <= 0 || nB <= 0) return 0;
+    const MatchPlan p = make_plan(nA, nB);
+    MatchWs w = carve(workspace, nA, nB, p);
+    hipLaunchKernelGGL(norms_kernel, dim3(nm_divup(nA, 256)), dim3(256), 0, st, A, nA, w.na);
+    NM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(norms_kernel, dim3(nm_divup(nB, 256)), dim3(256), 0, st, B, nB, w.nb);
+    NM_LAUNCH_CHECK();
+    const size_t lds_bytes = (size_t)2 * TILE_C * KP * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        NM_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_set = true;
+    }
+    nm_prof_begin(NM_PROF_MATCH_TOP2, st);
+    hipLaunchKernelGGL(match_top2_kernel, dim3(p.qblocks, p.S), dim3(256), lds_bytes, st, A, nA, B, nB, w.na, w.nb,
+                       p.chunk, p.S, w.partial);
+    nm_prof_end(NM_PROF_MATCH_TOP2, st);
+    NM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(match_finalize_kernel, dim3(nm_divup(nA, 256)), dim3(256), 0, st, A, nA, B, nB, p.S, w.partial,
+                       mode, index_offset, ambiguity, result, min1, idx1, min2);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nm_transpose_f32(float *odata, const float *idata, int width, int height, void *stream)
+{
+    if (width <= 0 || height <= 0) return 0;
+    dim3 grid(nm_divup(width, 32), nm_divup(height, 32));
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, nm_stream(stream), odata, idata, width, height);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+int nm_bf_distance_f32(const float *A, int size_A, const float *B, int size_B, int sift_vector_size, float *result,
+                       void *stream)
+{
+    if (sift_vector_size != DIM) return (int)hipErrorInvalidValue;
+    if (size_A <= 0 || size_B <= 0) return 0;
+    // lanes along i (contiguous in the transposed output D[j*size_A + i])
+    dim3 grid(nm_divup(size_A, 64), nm_divup(size_B, 64));
+    hipLaunchKernelGGL(exact_distance_kernel<true>, grid, dim3(256), 0, nm_stream(stream), A, size_A, B, size_B, result,
+                       (size_t)1, (size_t)size_A, true);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+int nm_get_sift_matches_f32(const float *distance, int rows, int cols, int buffer_width, int *result, float ambiguity,
+                            void *stream)
+{
+    if (rows <= 0 || cols <= 0) return 0;
+    hipLaunchKernelGGL(set_matches_kernel, dim3(nm_divup(rows, 4)), dim3(256), 0, nm_stream(stream), result, distance,
+                       rows, cols, buffer_width, ambiguity);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+size_t nm_sift_match_workspace_bytes(int nA, int nB)
+{
+    if (nA < 0) nA = 0;
+    if (nB < 0) nB = 0;
+    const MatchPlan p = make_plan(nA, nB);
+    return align256((size_t)nA * 4) + align256((size_t)nB * 4) + align256((size_t)nA * p.S * sizeof(float4)) + 256;
+}
+
+int nm_sift_match_f32(const float *A, int nA, const float *B, int nB, float *distance, int *result, float ambiguity,
+                      void *workspace, void *stream)
+{
+    if (nA <= 0 || nB <= 0) return 0;
+    hipStream_t st = nm_stream(stream);
+    if (distance) {                     // lanes along j (contiguous in distance[i*nB + j])
+        dim3 grid(nm_divup(nB, 64), nm_divup(nA, 64));
+        hipLaunchKernelGGL(exact_distance_kernel<false>, grid, dim3(256), 0, st, B, nB, A, nA, distance, (size_t)1,
+                           (size_t)nB, false);
+        NM_LAUNCH_CHECK();
+    }
+    return run_fused(A, nA, B, nB, 0, 0, ambiguity, result, nullptr, nullptr, nullptr, workspace, st);
+}
+
+int nm_sift_match_shard_f32(const float *A, int nA, const float *B_shard, int nB_shard, int index_offset, float *min1,
+                            int *idx1, float *min2, void *workspace, void *stream)
+{
+    return run_fused(A, nA, B_shard, nB_shard, 1, index_offset, 0.f, nullptr, min1, idx1, min2, workspace,
+                     nm_stream(stream));
+}
+
+int nm_sift_match_merge_f32(const float *min1, const int *idx1, const float *min2, int n_shards, int nA, int *result,
+                            float ambiguity, void *stream)
+{
+    if (nA <= 0 || n_shards <= 0) return 0;
+    hipLaunchKernelGGL(match_merge_kernel, dim3(nm_divup(nA, 256)), dim3(256), 0, nm_stream(stream), min1, idx1, min2,
+                       n_shards, nA, ambiguity, result);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,278 @@
+// nm_pyramid.hip -- Gaussian pyramid stages for gfx950: separable Gaussian (+ fused DoG), decimation, subtract,
+// gradient. Replaces kernels/convolution.cu:16-159, kernels/downsample.cu:6-29, kernels/cudamath.cu:26-80 of the
+// reference. All kernels are HBM/L2 streaming stencils; arithmetic order is fixed by the fp spec:
+//   conv: taps k = -r..r, sum = fma(x[k], w[r-k], sum) starting from +0, rows first, then columns, zero padding.
+#include "nm_common.hpp"
+#include "nm_fpspec.hpp"
+#include "../../include/nm_abi.h"
+
+using nmfp::fma32;
+
+// ------------------------------------------------------------------------------------------------------------
+// Fused separable Gaussian. One workgroup (256 threads = 4 waves) produces a 64 x TH output tile:
+//   phase 1  global -> LDS: (TH+2R) x (64+2R) input tile, zero outside the image (coalesced 256-B row segments)
+//   phase 2  row pass LDS -> LDS: every thread makes 8 consecutive outputs of one row from 8+2R registers
+//   phase 3  column pass LDS -> global: every thread makes TH/4 vertical outputs of one column; a wave writes
+//            whole 256-B row segments. DoG = output - input centre comes from the LDS tile for free.
+// R is a template parameter so the tap loops unroll and the sliding windows live in VGPRs.
+template <int R, int TH, bool WRITE_BUF, bool WRITE_DOG>
+__global__ __launch_bounds__(256) void conv_sep_kernel(float *__restrict__ result, const float *__restrict__ image,
+                                                      float *__restrict__ buffer, float *__restrict__ dog, int width,
+                                                      int height, const float *__restrict__ taps)
+{
+    constexpr int TW = 64;
+    constexpr int IN_W = TW + 2 * R;
+    constexpr int IN_P = ((IN_W + 3) & ~3) + 4;   // row pitch: multiple of 4 (b128 reads) + 4 (bank skew)
+    constexpr int ROWS = TH + 2 * R;
+    constexpr int NT = 2 * R + 1;
+    __shared__ __attribute__((aligned(16))) float s_in[ROWS * IN_P];
+    __shared__ __attribute__((aligned(16))) float s_mid[ROWS * TW];
+
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+
+    float w[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) w[i] = taps[i];
+
+    // phase 1
+    for (int row = tid >> 6; row < ROWS; row += 4) {
+        const int gy = y0 - R + row;
+        const bool yin = (gy >= 0) && (gy < height);
+        const float *src = image + (size_t)(yin ? gy : 0) * width;
+        for (int c = tid & 63; c < IN_W; c += 64) {
+            const int gx = x0 - R + c;
+            float v = 0.f;
+            if (yin && gx >= 0 && gx < width) v = src[gx];
+            s_in[row * IN_P + c] = v;
+        }
+    }
+    __syncthreads();
+
+    // phase 2: rows
+    {
+        const int xc = tid & 7;
+        for (int row = tid >> 3; row < ROWS; row += 32) {
+            float v[8 + 2 * R];
+            const float *p = &s_in[row * IN_P + xc * 8];
+#pragma unroll
+            for (int j = 0; j < 8 + 2 * R; ++j) v[j] = p[j];
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = 0.f;
+#pragma unroll
+            for (int k = -R; k <= R; ++k) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = fma32(v[i + R + k], w[R - k], o[i]);
+            }
+            float *q = &s_mid[row * TW + xc * 8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q[i] = o[i];
+            if (WRITE_BUF) {
+                const int gy = y0 - R + row;
+                if (row >= R && row < R + TH && gy < height) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int gx = x0 + xc * 8 + i;
+                        if (gx < width) buffer[(size_t)gy * width + gx] = o[i];
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // phase 3: columns
+    {
+        constexpr int NY = TH / 4;
+        const int x = tid & 63, yg = tid >> 6;
+        float v[NY + 2 * R];
+        const float *p = &s_mid[(yg * NY) * TW + x];
+#pragma unroll
+        for (int j = 0; j < NY + 2 * R; ++j) v[j] = p[j * TW];
+        float o[NY];
+#pragma unroll
+        for (int i = 0; i < NY; ++i) o[i] = 0.f;
+#pragma unroll
+        for (int k = -R; k <= R; ++k) {
+#pragma unroll
+            for (int i = 0; i < NY; ++i) o[i] = fma32(v[i + R + k], w[R - k], o[i]);
+        }
+        const int gx = x0 + x;
+        if (gx < width) {
+#pragma unroll
+            for (int i = 0; i < NY; ++i) {
+                const int yy = yg * NY + i;
+                const int gy = y0 + yy;
+                if (gy < height) {
+                    result[(size_t)gy * width + gx] = o[i];
+                    if (WRITE_DOG) dog[(size_t)gy * width + gx] = o[i] - s_in[(yy + R) * IN_P + x + R];
+                }
+            }
+        }
+    }
+}
+
+// Any-radius fallback (two passes through global memory, one thread per pixel). Same arithmetic order.
+__global__ __launch_bounds__(256) void conv_rows_generic(float *__restrict__ out, const float *__restrict__ in,
+                                                        int width, int height, const float *__restrict__ taps, int r)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= width || y >= height) return;
+    const float *row = in + (size_t)y * width;
+    float sum = 0.f;
+    for (int k = -r; k <= r; ++k) {
+        const int xx = x + k;
+        const float v = (xx >= 0 && xx < width) ? row[xx] : 0.f;
+        sum = fma32(v, taps[r - k], sum);
+    }
+    out[(size_t)y * width + x] = sum;
+}
+__global__ __launch_bounds__(256) void conv_cols_generic(float *__restrict__ out, const float *__restrict__ in,
+                                                        float *__restrict__ dog, const float *__restrict__ orig,
+                                                        int width, int height, const float *__restrict__ taps, int r)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= width || y >= height) return;
+    float sum = 0.f;
+    for (int k = -r; k <= r; ++k) {
+        const int yy = y + k;
+        const float v = (yy >= 0 && yy < height) ? in[(size_t)yy * width + x] : 0.f;
+        sum = fma32(v, taps[r - k], sum);
+    }
+    out[(size_t)y * width + x] = sum;
+    if (dog) dog[(size_t)y * width + x] = sum - orig[(size_t)y * width + x];
+}
+
+template <int R>
+static int launch_conv_r(float *result, const float *image, float *buffer, float *dog, int width, int height,
+                         const float *taps, hipStream_t stream)
+{
+    constexpr int TH = 32;
+    dim3 grid(nm_divup(width, 64), nm_divup(height, TH));
+    if (buffer && dog)
+        hipLaunchKernelGGL((conv_sep_kernel<R, TH, true, true>), grid, dim3(256), 0, stream, result, image, buffer, dog, width, height, taps);
+    else if (buffer)
+        hipLaunchKernelGGL((conv_sep_kernel<R, TH, true, false>), grid, dim3(256), 0, stream, result, image, buffer, dog, width, height, taps);
+    else if (dog)
+        hipLaunchKernelGGL((conv_sep_kernel<R, TH, false, true>), grid, dim3(256), 0, stream, result, image, buffer, dog, width, height, taps);
+    else
+        hipLaunchKernelGGL((conv_sep_kernel<R, TH, false, false>), grid, dim3(256), 0, stream, result, image, buffer, dog, width, height, taps);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+int nm_launch_convolve(float *result, const float *image, float *buffer, float *dog, int width, int height,
+                       const float *taps, int radius, hipStream_t stream)
+{
+    if (width <= 0 || height <= 0) return 0;
+    if (radius < 0) return (int)hipErrorInvalidValue;
+    switch (radius) {
+        case 5: return launch_conv_r<5>(result, image, buffer, dog, width, height, taps, stream);
+        case 7: return launch_conv_r<7>(result, image, buffer, dog, width, height, taps, stream);
+        case 8: return launch_conv_r<8>(result, image, buffer, dog, width, height, taps, stream);
+        case 10: return launch_conv_r<10>(result, image, buffer, dog, width, height, taps, stream);
+        case 12: return launch_conv_r<12>(result, image, buffer, dog, width, height, taps, stream);
+        case 13: return launch_conv_r<13>(result, image, buffer, dog, width, height, taps, stream);
+        case 16: return launch_conv_r<16>(result, image, buffer, dog, width, height, taps, stream);
+        default: break;
+    }
+    // generic radius: the row pass needs a real intermediate. Without a caller buffer there is none to use.
+    if (!buffer) return (int)hipErrorInvalidValue;
+    dim3 grid(nm_divup(width, 64), nm_divup(height, 4));
+    hipLaunchKernelGGL(conv_rows_generic, grid, dim3(256), 0, stream, buffer, image, width, height, taps, radius);
+    NM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(conv_cols_generic, grid, dim3(256), 0, stream, result, buffer, dog, image, width, height, taps, radius);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void downsample2_kernel(float *__restrict__ result, int rw, int rh,
+                                                         const float *__restrict__ source, int sw)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= rw || y >= rh) return;
+    result[(size_t)y * rw + x] = source[(size_t)(y * 2) * sw + (x * 2)];
+}
+
+__global__ __launch_bounds__(256) void subtract_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                      float *__restrict__ C, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) C[i] = A[i] - B[i];
+}
+
+// gradient: g = 0.5*sqrt(dx^2+dy^2), theta = mod_2pi(atan2(dy,dx) + 2pi) in (0, 2pi], 0 when g == 0; border = (0,0).
+__global__ __launch_bounds__(256) void gradient_kernel(NmGradBatch b, int width, int height)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= width || y >= height) return;
+    const float *__restrict__ src = b.src[blockIdx.z];
+    float2 *__restrict__ dst = reinterpret_cast<float2 *>(b.dst[blockIdx.z]);
+    float g = 0.f, r = 0.f;
+    if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1) {
+        const size_t c = (size_t)y * width + x;
+        const float dx = src[c + 1] - src[c - 1];
+        const float dy = src[c + width] - src[c - width];
+        g = (float)(0.5 * (double)__builtin_sqrtf(fma32(dx, dx, dy * dy)));
+        if (g != 0.0f) r = nmfp::mod_2pi_f((float)((double)nmfp::atan2f_spec(dy, dx) + nmfp::TWO_PI_D));
+    }
+    dst[(size_t)y * width + x] = make_float2(g, r);
+}
+
+int nm_launch_gradient_batch(const NmGradBatch &b, int width, int height, hipStream_t stream)
+{
+    if (width <= 0 || height <= 0 || b.n <= 0) return 0;
+    dim3 grid(nm_divup(width, 64), nm_divup(height, 4), b.n);
+    hipLaunchKernelGGL(gradient_kernel, grid, dim3(256), 0, stream, b, width, height);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// C ABI
+extern "C" {
+
+int DivUp(int a, int b) { return ((a % b) != 0) ? (a / b + 1) : (a / b); }
+int DivDown(int a, int b) { return a / b; }
+int AlignUp(int a, int b) { return ((a % b) != 0) ? (a - a % b + b) : a; }
+int AlignDown(int a, int b) { return a - a % b; }
+
+int nm_convolve_f32(float *result, const float *image, float *buffer, int width, int height, const float *kernel,
+                    int kernel_radius, void *stream)
+{
+    if (!result || !image || !buffer || !kernel) return (int)hipErrorInvalidValue;
+    return nm_launch_convolve(result, image, buffer, nullptr, width, height, kernel, kernel_radius, nm_stream(stream));
+}
+
+int nm_downsample2_f32(float *result, int rw, int rh, const float *source, int sw, int sh, void *stream)
+{
+    (void)sh;
+    if (rw <= 0 || rh <= 0) return 0;
+    dim3 grid(nm_divup(rw, 64), nm_divup(rh, 4));
+    hipLaunchKernelGGL(downsample2_kernel, grid, dim3(256), 0, nm_stream(stream), result, rw, rh, source, sw);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+int nm_subtract_f32(const float *A, const float *B, float *C, int width, int height, void *stream)
+{
+    const size_t n = (size_t)width * height;
+    if (n == 0) return 0;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(subtract_kernel, dim3(blocks), dim3(256), 0, nm_stream(stream), A, B, C, n);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+int nm_gradient_f32(const float *source, float *result, int width, int height, void *stream)
+{
+    NmGradBatch b{};
+    b.src[0] = source; b.dst[0] = result; b.n = 1;
+    return nm_launch_gradient_batch(b, width, height, nm_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,107 @@
+// device_vector.h -- minimal owning device array used where the reference exposes thrust::device_vector members
+// (sift/pyramidata.h:60-110, sift/siftdata.h:25-40). Documented deviation: no Thrust, no CUDA-compat shim.
+// Interface subset: size/empty/clear/assign/resize/data/begin/end, construction from count (+ fill value) and from a
+// host std::vector, deep copy, copy back to host. All operations use the current HIP device and the NULL stream and
+// are synchronous, like thrust::device_vector's.
+#ifndef __NM_DEVICE_VECTOR_H__
+#define __NM_DEVICE_VECTOR_H__
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+#include <cstring>
+#include <vector>
+
+#include "exception.h"
+
+extern "C" int nm_fill_u32(void *dst, size_t count, unsigned int pattern, void *stream);
+
+namespace nm {
+
+template <typename T>
+class device_vector {
+    static_assert(sizeof(T) % 4 == 0, "device_vector<T>: T must be a multiple of 4 bytes");
+
+public:
+    device_vector() : _p(nullptr), _n(0) {}
+    explicit device_vector(size_t n) : _p(nullptr), _n(0) { allocate(n); zero(); }
+    device_vector(size_t n, const T &value) : _p(nullptr), _n(0) { allocate(n); fill(value); }
+    explicit device_vector(const std::vector<T> &host) : _p(nullptr), _n(0)
+    {
+        allocate(host.size());
+        if (_n) nm_check((int)hipMemcpy(_p, host.data(), _n * sizeof(T), hipMemcpyHostToDevice), "device_vector H2D");
+    }
+    device_vector(const device_vector &o) : _p(nullptr), _n(0) { copy_from(o); }
+    device_vector(device_vector &&o) noexcept : _p(o._p), _n(o._n) { o._p = nullptr; o._n = 0; }
+    device_vector &operator=(const device_vector &o) { if (this != &o) copy_from(o); return *this; }
+    device_vector &operator=(device_vector &&o) noexcept
+    {
+        if (this != &o) { release(); _p = o._p; _n = o._n; o._p = nullptr; o._n = 0; }
+        return *this;
+    }
+    ~device_vector() { release(); }
+
+    size_t size() const { return _n; }
+    bool empty() const { return _n == 0; }
+    T *data() { return _p; }
+    const T *data() const { return _p; }
+    T *begin() { return _p; }
+    T *end() { return _p + _n; }
+    const T *begin() const { return _p; }
+    const T *end() const { return _p + _n; }
+    void clear() { release(); }
+    void assign(size_t n, const T &value) { release(); allocate(n); fill(value); }
+    void resize(size_t n) { if (n != _n) { release(); allocate(n); zero(); } }
+
+    void fill(const T &value)
+    {
+        if (!_n) return;
+        unsigned int w[sizeof(T) / 4];
+        std::memcpy(w, &value, sizeof(T));
+        bool uniform = true;
+        for (size_t i = 1; i < sizeof(T) / 4; ++i) uniform = uniform && (w[i] == w[0]);
+        if (uniform) {
+            nm_check(nm_fill_u32(_p, _n * (sizeof(T) / 4), w[0], nullptr), "device_vector fill");
+            nm_check((int)hipStreamSynchronize(nullptr), "device_vector fill sync");
+        } else {
+            std::vector<T> h(_n, value);
+            nm_check((int)hipMemcpy(_p, h.data(), _n * sizeof(T), hipMemcpyHostToDevice), "device_vector fill H2D");
+        }
+    }
+    std::vector<T> to_host() const
+    {
+        std::vector<T> h(_n);
+        if (_n) nm_check((int)hipMemcpy(h.data(), _p, _n * sizeof(T), hipMemcpyDeviceToHost), "device_vector D2H");
+        return h;
+    }
+
+private:
+    void allocate(size_t n)
+    {
+        _n = n;
+        _p = nullptr;
+        if (n) nm_check((int)hipMalloc(reinterpret_cast<void **>(&_p), n * sizeof(T)), "device_vector alloc");
+    }
+    void zero()
+    {
+        if (_n) nm_check((int)hipMemset(_p, 0, _n * sizeof(T)), "device_vector zero");
+    }
+    void release()
+    {
+        if (_p) (void)hipFree(_p);
+        _p = nullptr;
+        _n = 0;
+    }
+    void copy_from(const device_vector &o)
+    {
+        release();
+        allocate(o._n);
+        if (_n) nm_check((int)hipMemcpy(_p, o._p, _n * sizeof(T), hipMemcpyDeviceToDevice), "device_vector D2D");
+    }
+    T *_p;
+    size_t _n;
+};
+
+}  // namespace nm
+
+#endif

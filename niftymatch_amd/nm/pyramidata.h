@@ -1,0 +1,51 @@
+// pyramidata.h -- per-frame scale-space buffers (drop-in for NiftyMatch src/gpu/sift/pyramidata.h:14-131).
+// thrust::device_vector members are nm::device_vector (see device_vector.h).
+#ifndef __PYRAMID_DATA_H__
+#define __PYRAMID_DATA_H__
+
+#include <hip/hip_runtime_api.h>
+#include <hip/hip_vector_types.h>
+
+#include <vector>
+
+#include "device_vector.h"
+#include "siftparams.h"
+
+#define MAX_KERNEL_LENGTH 91
+
+class PyramidData {
+public:
+    PyramidData() : _base_radius(0), _num_octaves(0), _num_dogs(0), _num_kernels(0) {}
+    PyramidData(const SiftParams &params);
+    ~PyramidData() {}
+
+    void initialize(const SiftParams &params);
+    void clear();
+    //! Stable compaction of the valid entries among the first \c num_pixels of _key_pts[level] into
+    //! _collated_kpts[level]; _orientations[level] is re-created with one (-1,-1) per surviving keypoint.
+    void gpu_collate_keypoints_for_level(int level, int num_pixels);
+
+public:
+    nm::device_vector<float> _octave[20];          //!< Gaussian levels of the current octave
+    nm::device_vector<float> _dog[19];             //!< differences of Gaussians
+    nm::device_vector<float4> _key_pts[19];        //!< dense keypoint maps
+    nm::device_vector<float2> _orientations[19];   //!< per collated keypoint
+    nm::device_vector<float> _base_kernel;
+    int _base_radius;
+    nm::device_vector<float> _kernels[20];
+    std::vector<int> _kernel_radii;
+    nm::device_vector<float> _buffer;
+    nm::device_vector<float2> _grad;
+    nm::device_vector<float4> _collated_kpts[19];
+    int _num_octaves;   //!< (sic) number of Gaussian levels per octave
+    int _num_dogs;
+    int _num_kernels;
+
+private:
+    void generate_kernels(const SiftParams &params);
+    void create_kernel_for_sigma(float sigma, nm::device_vector<float> &result, int &radius);
+    nm::device_vector<int> _count;        // device-side counter + scratch of the compaction
+    nm::device_vector<int> _compact_ws;
+};
+
+#endif

@@ -1,0 +1,30 @@
+// siftdata.h -- keypoint / descriptor / match container (drop-in for NiftyMatch src/gpu/sift/siftdata.h:20-111).
+#ifndef __SIFTPOINT_H__
+#define __SIFTPOINT_H__
+
+#include "device_vector.h"
+
+#define SIFT_VECTOR_SIZE 128
+#define MAX_DESCRIPTORS 2048
+
+struct SiftData {
+    nm::device_vector<float> _desc;          //!< capacity x 128
+    nm::device_vector<int> _match_indexes;   //!< capacity, -1 = no match
+    nm::device_vector<float> _x;
+    nm::device_vector<float> _y;
+    float *_x_ptr;
+    float *_y_ptr;
+    int *_match_indexes_ptr;
+    int _num_items;
+    int _capacity;
+
+    SiftData() : _x_ptr(nullptr), _y_ptr(nullptr), _match_indexes_ptr(nullptr), _num_items(0), _capacity(0) {}
+    SiftData(int capacity);      //!< throws std::runtime_error for capacity <= 0
+    ~SiftData();
+
+    void copy_from(const SiftData &in);                   //!< deep copy of all vectors
+    void initialize_data(int capacity = MAX_DESCRIPTORS);
+    void clear_data();
+};
+
+#endif

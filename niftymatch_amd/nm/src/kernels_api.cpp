@@ -1,0 +1,112 @@
+// kernels_api.cpp -- C++ launchers of the `kernels` library: the reference's L2 signatures on top of the C ABI.
+// Error convention: a failing launch prints file:line + the HIP error and exit()s, as helper_cuda.h's
+// getLastCudaError does in the reference (e.g. kernels/convolution.cu:152,158, kernels/match.cu:134).
+#include "../../../include/nm_abi.h"
+#include "../convolution.h"
+#include "../cudamath.h"
+#include "../descriptor.h"
+#include "../downsample.h"
+#include "../exception.h"
+#include "../keypoint.h"
+#include "../match.h"
+#include "../orientation.h"
+#include "../transpose.h"
+
+template <typename TYPE>
+void convolve(TYPE *result, const TYPE *image, TYPE *buffer, const int width, const int height, const float *kernel,
+              const int kernel_radius, hipStream_t stream)
+{
+    nm_check(nm_convolve_f32(result, image, buffer, width, height, kernel, kernel_radius, stream), "Convolution failed");
+}
+template void convolve<float>(float *, const float *, float *, const int, const int, const float *, const int, hipStream_t);
+
+template <typename DataType>
+void downsample_by_2(DataType *result, const int result_width, const int result_height, const DataType *source,
+                     const int source_width, const int source_height, hipStream_t stream)
+{
+    nm_check(nm_downsample2_f32(result, result_width, result_height, source, source_width, source_height, stream),
+             "Downsampling kernel failed");
+}
+template void downsample_by_2<float>(float *, const int, const int, const float *, const int, const int, hipStream_t);
+
+template <typename TYPE>
+void subtract(const TYPE *A, const TYPE *B, TYPE *C, const int width, const int height, hipStream_t stream)
+{
+    nm_check(nm_subtract_f32(A, B, C, width, height, stream), "Subtract launch failed");
+}
+template void subtract<float>(const float *, const float *, float *, const int, const int, hipStream_t);
+
+template <typename TYPE>
+void gradient(const TYPE *source, float2 *result, const int width, const int height, hipStream_t stream)
+{
+    nm_check(nm_gradient_f32(source, reinterpret_cast<float *>(result), width, height, stream),
+             "Set gradient launch failed");
+}
+template void gradient<float>(const float *, float2 *, const int, const int, hipStream_t);
+
+void find_keypoints(const float *current, const float *down, const float *up, const int width, const int height,
+                    const float peak_threshold, const float edge_threshold, const float xper, const float sigma_0,
+                    const int num_dogs, const int dog, float4 *result, hipStream_t stream)
+{
+    nm_check(nm_find_keypoints_f32(current, down, up, width, height, peak_threshold, edge_threshold, xper, sigma_0,
+                                   num_dogs, dog, reinterpret_cast<float *>(result), stream),
+             "Keypoint detection launch failed");
+}
+
+void find_keypoints(const float *current, const float *mask, const int mask_width, const int mask_height,
+                    const float *down, const float *up, const int width, const int height, const float peak_threshold,
+                    const float edge_threshold, const float xper, const float sigma_0, const int num_dogs, const int dog,
+                    float4 *result, hipStream_t stream)
+{
+    nm_check(nm_find_keypoints_masked_f32(current, mask, mask_width, mask_height, down, up, width, height,
+                                          peak_threshold, edge_threshold, xper, sigma_0, num_dogs, dog,
+                                          reinterpret_cast<float *>(result), stream),
+             "Keypoint detection launch failed");
+}
+
+void detect_orientations(const float4 *key_pts, const float2 *grad, const int num_pts, const int octave_width,
+                         const int octave_height, float gauss_factor, const float xper, float2 *result,
+                         hipStream_t stream)
+{
+    nm_check(nm_detect_orientations(reinterpret_cast<const float *>(key_pts), reinterpret_cast<const float *>(grad),
+                                    num_pts, octave_width, octave_height, gauss_factor, xper,
+                                    reinterpret_cast<float *>(result), stream),
+             "Orientation histogram launch failed");
+}
+
+void compute_sift_descriptors(const float4 *key_pts, const float2 *orients, const float2 *grad, const int num_pts,
+                              const int octave_width, const int octave_height, const int num_dogs, const float xper,
+                              float *desc, float *x, float *y, hipStream_t stream)
+{
+    nm_check(nm_compute_sift_descriptors(reinterpret_cast<const float *>(key_pts),
+                                         reinterpret_cast<const float *>(orients),
+                                         reinterpret_cast<const float *>(grad), num_pts, octave_width, octave_height,
+                                         num_dogs, xper, desc, x, y, stream),
+             "SIFT descriptor detection launch failed");
+}
+
+template <typename TYPE>
+void transpose(TYPE *odata, const TYPE *idata, int width, int height, hipStream_t stream)
+{
+    nm_check(nm_transpose_f32(odata, idata, width, height, stream), "Transpose kernel failed");
+}
+template void transpose<float>(float *, const float *, int, int, hipStream_t);
+
+template <typename TYPE>
+void compute_brute_force_distance(const TYPE *A, const int size_A, const TYPE *B, const int size_B,
+                                  const int sift_vector_size, TYPE *result, hipStream_t stream)
+{
+    nm_check(nm_bf_distance_f32(A, size_A, B, size_B, sift_vector_size, result, stream),
+             "Brute force distance computation launch failed");
+}
+template void compute_brute_force_distance<float>(const float *, const int, const float *, const int, const int,
+                                                  float *, hipStream_t);
+
+template <typename TYPE>
+void get_sift_matches(const TYPE *distance, const int rows, const int cols, const int buffer_width, int *result,
+                      float ambiguity, hipStream_t stream)
+{
+    nm_check(nm_get_sift_matches_f32(distance, rows, cols, buffer_width, result, ambiguity, stream),
+             "Set matches launch failed");
+}
+template void get_sift_matches<float>(const float *, const int, const int, const int, int *, float, hipStream_t);

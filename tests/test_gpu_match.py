@@ -1,0 +1,130 @@
+"""GPU parity of the matcher: fused MFMA path, exact API building blocks, shard + merge, edge cases (KAT-12)."""
+import numpy as np
+import pytest
+
+import helpers as H
+from test_gpu_stages import _eq, _t
+
+pytestmark = pytest.mark.gpu
+
+
+def _match(nm, cuda, A, B, amb=0.8, want_distance=False, prior=None):
+    import torch
+    pr = None if prior is None else _t(np.asarray(prior, np.int32), cuda)
+    res, D = nm.sift_match(_t(A, cuda), _t(B, cuda), amb, want_distance=want_distance, prior=pr)
+    torch.cuda.synchronize()
+    return res.cpu().numpy(), (None if D is None else D.cpu().numpy())
+
+
+@pytest.mark.parametrize("na,nb", [(1024, 1024), (1000, 777), (300, 2500), (5, 3), (257, 129)])
+def test_fused_match_random(nm, oracle, cuda, na, nb):
+    A = H.synth.descriptors(1, na)
+    B = H.synth.descriptors(2, nb)
+    ref, Dref, _ = oracle.sift_matches(A, B, 0.8)
+    got, D = _match(nm, cuda, A, B, want_distance=True)
+    assert np.array_equal(got, ref)
+    _eq(D, Dref, "distance matrix (exact summation order)")
+    got2, _ = _match(nm, cuda, A, B, want_distance=False)
+    assert np.array_equal(got2, ref)
+    assert (ref >= 0).sum() >= 0
+
+
+def test_fused_match_sift_descriptors(nm, oracle, cuda):
+    """Real (un-normalised, Q12) descriptors of two frames, incl. a shifted copy: true matches, cancellation hazard."""
+    f0 = H.blurred_frame(0, 640, 480)
+    f1 = np.roll(f0, (2, 3), axis=(0, 1)).copy()
+    a = oracle.sift_detect_describe(f0, 8192)["desc"]
+    b = oracle.sift_detect_describe(f1, 8192)["desc"]
+    ref, _, _ = oracle.sift_matches(a, b, 0.8, want_distance=False)
+    got, _ = _match(nm, cuda, a, b)
+    assert np.array_equal(got, ref)
+    assert (ref >= 0).mean() > 0.3
+
+
+def test_match_hard_near_duplicates(nm, oracle, cuda):
+    rng = np.random.default_rng(5)
+    A = H.synth.descriptors(3, 2000)
+    B = H.synth.descriptors(4, 2000)
+    idx = rng.choice(2000, 200, replace=False)
+    B[idx] = A[idx] + (1e-3 * rng.standard_normal((200, 128))).astype(np.float32)
+    B[7] = A[9]                      # exact duplicate: min1 = 0, min2 > 0 -> ratio 0 -> matched
+    ref, _, _ = oracle.sift_matches(A, B, 0.8, want_distance=False)
+    got, _ = _match(nm, cuda, A, B)
+    assert np.array_equal(got, ref)
+    assert ref[9] == 7 and (ref[idx] == idx).mean() > 0.95
+
+
+def test_match_kat12_edge_cases(nm, oracle, cuda):
+    base = H.synth.descriptors(8, 6)
+    # two exact duplicates of A[0] in B: min2 == 0 -> result left untouched (prior value)
+    B = base.copy(); A = base[:2].copy()
+    B[3] = A[0]; B[5] = A[0]
+    prior = np.array([42, 17], np.int32)
+    ref, _, _ = oracle.sift_matches(A, B, 0.8, want_distance=False, prior=prior)
+    got, _ = _match(nm, cuda, A, B, prior=prior)
+    assert np.array_equal(got, ref) and ref[0] == 42
+    # M = 1: min2 stays 2139095040.0f -> ratio ~ 0 -> index 0
+    ref, _, _ = oracle.sift_matches(A, base[4:5], 0.8, want_distance=False)
+    got, _ = _match(nm, cuda, A, base[4:5])
+    assert np.array_equal(got, ref) and (ref == 0).all()
+    # tie for the minimum: lowest index wins, ratio 1 -> -1 at 0.8, matched at ambiguity 1.5
+    B = base.copy(); B[4] = B[1]; A = (B[1:2] + 0.01).astype(np.float32)
+    for amb in (0.8, 1.5):
+        ref, _, _ = oracle.sift_matches(A, B, amb, want_distance=False)
+        got, _ = _match(nm, cuda, A, B, amb=amb)
+        assert np.array_equal(got, ref)
+    assert ref[0] == 1
+
+
+def test_api_building_blocks(nm, oracle, cuda):
+    import torch
+    A = H.synth.descriptors(1, 333)
+    B = H.synth.descriptors(2, 200)
+    At = nm.transpose(_t(A, cuda))
+    _eq(At, oracle.transpose(A), "transpose")
+    Dt = nm.bf_distance(At, _t(B, cuda))
+    Dt_ref = oracle.bf_distance(oracle.transpose(A), B)
+    _eq(Dt, Dt_ref, "bf_distance (transposed layout)")
+    D = nm.transpose(Dt)
+    res = nm.get_sift_matches(D, 0.8)
+    torch.cuda.synchronize()
+    ref = oracle.get_sift_matches(oracle.transpose(Dt_ref), 0.8)
+    assert np.array_equal(res.cpu().numpy(), ref)
+    # buffer_width > cols and a prior that must survive min2 <= 0
+    M = np.zeros((3, 8), np.float32); M[0, :4] = [5, 1, 3, 1]; M[1, :4] = [0, 0, 2, 2]; M[2, :4] = [4, 9, 8, 7]
+    ref = oracle.get_sift_matches(M, 0.8, prior=np.array([9, 9, 9], np.int32), cols=4)
+    got = nm.get_sift_matches(_t(M, cuda), 0.8, prior=_t(np.array([9, 9, 9], np.int32), cuda), cols=4)
+    assert np.array_equal(got.cpu().numpy(), ref) and ref[1] == 9
+
+
+def test_shard_and_merge_equals_unsharded(nm, oracle, cuda):
+    import torch
+    A = H.synth.descriptors(1, 1500)
+    B = H.synth.descriptors(2, 2100)
+    B[100] = B[1900]                                     # cross-shard tie: the lower global index must win
+    ref, _, (m1r, ixr, m2r) = oracle.sift_matches(A, B, 0.8, want_distance=False)
+    bounds = [0, 700, 1400, 2100]
+    m1s, ixs, m2s = [], [], []
+    for g in range(3):
+        m1, ix, m2 = nm.sift_match_shard(_t(A, cuda), _t(B[bounds[g]:bounds[g + 1]], cuda), bounds[g])
+        m1s.append(m1); ixs.append(ix); m2s.append(m2)
+    res = nm.sift_match_merge(torch.stack(m1s), torch.stack(ixs), torch.stack(m2s), 0.8)
+    torch.cuda.synchronize()
+    assert np.array_equal(res.cpu().numpy(), ref)
+    one = nm.sift_match_shard(_t(A, cuda), _t(B, cuda), 0)
+    _eq(one[0], m1r, "min1"); assert np.array_equal(one[1].cpu().numpy(), ixr); _eq(one[2], m2r, "min2")
+
+
+def test_full_size_properties_12k(nm, cuda):
+    """BASELINE config-3 size (12k x 12k): size-independent properties instead of an oracle run."""
+    import torch
+    A = _t(H.synth.descriptors(1, 12223), cuda)
+    perm = torch.randperm(12223, device=cuda, generator=torch.Generator(device=cuda).manual_seed(0))
+    B = A[perm].contiguous()
+    res, _ = nm.sift_match(A, B, 0.8)                    # every row has an exact duplicate in B: distance 0, ratio 0
+    inv = torch.empty_like(perm); inv[perm] = torch.arange(12223, device=cuda)
+    assert torch.equal(res.long(), inv)
+    res2, _ = nm.sift_match(A, B, 0.8)                   # idempotent / run-to-run deterministic
+    assert torch.equal(res, res2)
+    m1, ix, m2 = nm.sift_match_shard(A, B, 0)
+    assert float(m1.abs().max()) == 0.0 and torch.equal(ix.long(), inv) and bool((m2 > 0).all())

@@ -1,0 +1,131 @@
+"""GPU parity, stage by stage: every C-ABI launcher against the CPU oracle on the same seeded inputs. Bit-exact."""
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, cuda):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+
+
+def _eq(got, ref, what):
+    got = got.detach().cpu().numpy() if hasattr(got, "detach") else np.asarray(got)
+    ref = np.asarray(ref)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    same = got.view(np.uint32) == ref.view(np.uint32) if got.dtype == np.float32 else got == ref
+    assert same.all(), "%s: %d of %d elements differ (max abs diff %g)" % (
+        what, (~same).sum(), same.size, np.nanmax(np.abs(got.astype(np.float64) - ref.astype(np.float64))))
+
+
+@pytest.mark.parametrize("wh", [(200, 150), (640, 480), (60, 33)])
+def test_convolve_all_sift_kernels(nm, oracle, cuda, wh):
+    w, h = wh
+    img = H.synth.noise_frame(7, w, h)
+    p = oracle.sift_params(1920, 1080)
+    sigmas = [p.base_smooth] + list(p.sigmas)[:5] + [3.0, 4.0, 0.6]     # radii 7,5,7,8,10,13,12,16 + generic 3
+    for s in sigmas:
+        taps, r = oracle.create_kernel_for_sigma(s)
+        t2, r2 = nm.create_kernel_for_sigma(s)
+        assert r2 == r and np.array_equal(t2, taps)
+        ref, refbuf = oracle.convolve(img, taps, r)
+        out, buf = nm.convolve(_t(img, cuda), _t(taps, cuda), r, want_buffer=True)
+        _eq(out, ref, "convolve sigma=%g" % s)
+        _eq(buf, refbuf, "convolve row pass sigma=%g" % s)
+
+
+def test_downsample_subtract_gradient(nm, oracle, cuda):
+    a = H.blurred_frame(1, 270, 135)
+    b = H.blurred_frame(2, 270, 135)
+    _eq(nm.downsample2(_t(a, cuda), 135, 67), oracle.downsample2(a, 135, 67), "downsample")
+    _eq(nm.subtract(_t(a, cuda), _t(b, cuda)), oracle.subtract(a, b), "subtract")
+    _eq(nm.gradient(_t(a, cuda)), oracle.gradient(a), "gradient")
+    ramp = np.tile(np.arange(64, dtype=np.float32) * 2.0, (48, 1))       # dy = 0, dx > 0: theta = (float)(2 pi)
+    g = nm.gradient(_t(ramp, cuda)).cpu().numpy()
+    _eq(g, oracle.gradient(ramp), "gradient ramp")
+    assert g[10, 10, 1] == np.float32(2 * np.pi) and g[0, 0, 0] == 0 and g[0, 0, 1] == 0
+    flat = np.full((40, 40), 3.0, np.float32)
+    assert not nm.gradient(_t(flat, cuda)).cpu().numpy().any()
+
+
+def _octave(oracle, w, h, seed):
+    lv0 = H.blurred_frame(seed, w, h, sigma=2.0)
+    return oracle.octave_pyramid(lv0, 1920, 1080)
+
+
+def test_octave_pyramid_fused(nm, oracle, cuda):
+    import torch
+    w, h = 320, 200
+    levels, dogs, grad = _octave(oracle, w, h, 3)
+    arena = nm.SiftArena(w, h, 1024)
+    n = w * h
+
+    def view(ptr, count):
+        # wrap arena memory for read-back
+        buf = torch.empty(count, dtype=torch.float32, device=cuda)
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        assert hip.hipMemcpy(buf.data_ptr(), ptr, count * 4, 3) == 0
+        return buf
+
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    lv0 = _t(levels[0], cuda)
+    assert hip.hipMemcpy(arena.level_ptr(0), lv0.data_ptr(), n * 4, 3) == 0
+    arena.octave_pyramid(w, h)
+    torch.cuda.synchronize()
+    for l in range(1, 6):
+        _eq(view(arena.level_ptr(l), n).reshape(h, w), levels[l], "level %d" % l)
+    for d in range(5):
+        _eq(view(arena.dog_ptr(d), n).reshape(h, w), dogs[d], "dog %d" % d)
+    _eq(view(arena.grad_ptr(), 6 * n).reshape(3, h, w, 2), grad, "grad")
+    arena.close()
+
+
+@pytest.mark.parametrize("wh", [(320, 200), (135, 67)])
+def test_keypoints_orientations_descriptors(nm, oracle, cuda, wh):
+    w, h = wh
+    levels, dogs, grad = _octave(oracle, w, h, 5)
+    p = oracle.sift_params(1920, 1080)
+    xper = 2.0
+    total = 0
+    for lvl in range(3):
+        ref = oracle.find_keypoints(dogs[lvl + 1], dogs[lvl], dogs[lvl + 2], 0.0, 10.0, xper, p.sigma_0, 3, lvl)
+        got = nm.find_keypoints(_t(dogs[lvl + 1], cuda), _t(dogs[lvl], cuda), _t(dogs[lvl + 2], cuda), 0.0, 10.0, xper,
+                                p.sigma_0, 3, lvl)
+        _eq(got, ref, "dense keypoint map level %d" % lvl)
+        kp_ref = oracle.compact_keypoints(ref)
+        kp = nm.compact_keypoints(got)
+        _eq(kp, kp_ref, "compaction level %d" % lvl)
+        total += len(kp_ref)
+        if len(kp_ref) == 0:
+            continue
+        ori_ref = oracle.detect_orientations(kp_ref, grad, w, h, 1.5, xper)
+        ori = nm.detect_orientations(kp, _t(grad, cuda), w, h, 1.5, xper)
+        _eq(ori, ori_ref, "orientations level %d" % lvl)
+        d_ref, x_ref, y_ref = oracle.compute_sift_descriptors(kp_ref, ori_ref, grad, w, h, 3, xper)
+        d, x, y = nm.compute_sift_descriptors(kp, ori, _t(grad, cuda), w, h, 3, xper)
+        _eq(d, d_ref, "descriptors level %d" % lvl)
+        _eq(x, x_ref, "x")
+        _eq(y, y_ref, "y")
+    assert total > 20
+
+
+def test_masked_keypoints(nm, oracle, cuda):
+    w, h = 160, 120
+    levels, dogs, grad = _octave(oracle, w, h, 9)
+    p = oracle.sift_params(640, 480)
+    for xper, mw, mh in ((1.0, w, h), (2.0, 2 * w, 2 * h)):
+        mask = np.zeros((mh, mw), np.float32)
+        mask[mh // 4: 3 * mh // 4, mw // 3:] = 1.0
+        ref = oracle.find_keypoints(dogs[2], dogs[1], dogs[3], 0.0, 10.0, xper, p.sigma_0, 3, 1, mask=mask)
+        got = nm.find_keypoints(_t(dogs[2], cuda), _t(dogs[1], cuda), _t(dogs[3], cuda), 0.0, 10.0, xper, p.sigma_0, 3,
+                                1, mask=_t(mask, cuda))
+        _eq(got, ref, "masked map xper=%g" % xper)
+        full = oracle.find_keypoints(dogs[2], dogs[1], dogs[3], 0.0, 10.0, xper, p.sigma_0, 3, 1)
+        assert 0 < (ref[..., 3] >= 0).sum() < (full[..., 3] >= 0).sum()
