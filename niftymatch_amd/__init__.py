@@ -65,6 +65,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise NmError("libnm_hip.so not found at %s: build it with `python -m niftymatch_amd.build` "
                           "(there is no CPU fallback)" % LIB_PATH)
+        # torch bundles its own HIP runtime (same SONAME libamdhip64.so.7). Import it FIRST so that the dynamic loader
+        # binds libnm_hip.so to that copy: two HIP runtimes in one process cannot both own the device.
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)
