@@ -5,9 +5,10 @@
 // order is fixed (DESIGN.md "fp spec") and implemented without atomics:
 //   orientation: bin b = sum of its votes in raster order of the clipped window (the order of the reference's own
 //                one-thread kernel, orientation.cu:165-176): lane b scans the wave's vote list in LDS.
-//   descriptor : sample p of a 16x16 chunk belongs to partial histogram (p mod 64) = the lane that processes it;
-//                partials accumulate privately in LDS in (chunk, p div 64, dbinx, dbiny, dbint) order and are
-//                combined by a xor-butterfly over lanes (= balanced pairwise tree, strides 1,2,...,32).
+//   descriptor : the samples of column tx (0..15) of a 16x16 chunk vote into partial histogram tx in increasing cy
+//                (4 rows per wave pass, issued as 4 exec-masked read-add-write groups in row order: LDS executes a
+//                wave's instructions in order), 8 votes per sample in (dbinx, dbiny, dbint) order; the 16 partials
+//                are combined by a balanced pairwise tree (strides 1,2,4,8) by the lane that owns the bin.
 #include "nm_common.hpp"
 #include "nm_fpspec.hpp"
 #include "nm_describe.hpp"
@@ -93,7 +94,10 @@ __device__ __forceinline__ int orient_wave(const float4 kp, const float2 *__rest
     return npk;
 }
 
-// One wave computes one descriptor. part: 128 x 64 floats of LDS private to the wave, laid out [bin][lane].
+constexpr int DESC_PITCH = 20;                  // floats per bin row: 16 partials + 4 pad (conflict-free b128 reads)
+constexpr int DESC_LDS = 128 * DESC_PITCH;      // floats of LDS per wave (10 KB)
+
+// One wave computes one descriptor. part: DESC_LDS floats of LDS private to the wave, laid out [bin][partial].
 __device__ __forceinline__ void describe_wave(const float4 kp, const float angle0, const float2 *__restrict__ grad,
                                               int ow, int oh, int num_dogs, float xper, float *__restrict__ desc,
                                               float *__restrict__ xp, float *__restrict__ yp, float *part)
@@ -112,19 +116,35 @@ __device__ __forceinline__ void describe_wave(const float4 kp, const float angle
     const float2 *gptr = grad + (((long)si * oh + yi) * (long)ow + xi);
     const double st0 = (double)nmfp::sinf_spec(angle0), ct0 = (double)nmfp::cosf_spec(angle0);
     const double dSBP = (double)SBP;
+    const int tx = lane & 15, tyg = lane >> 4;
 
-#pragma unroll 4
-    for (int b = 0; b < 128; ++b) part[b * 64 + lane] = 0.f;
-    float *mine = part + 80 * 64 + lane;          // origin at the centre bin (descriptor.cu:81)
+    {   // zero the wave's partial histograms with 16-byte stores
+        float4 *z = reinterpret_cast<float4 *>(part);
+#pragma unroll
+        for (int i = 0; i < DESC_LDS / 4 / 64; ++i) z[i * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float *mine = part + 80 * DESC_PITCH + tx;    // origin at the centre bin (descriptor.cu:81), partial tx
 
-    for (int c = 0; c < chunks; ++c) {
-#pragma unroll 1
+    // Gradient samples of a chunk are fetched together (4 independent loads per lane) and the next chunk's loads are
+    // issued before the current chunk is processed, so the gather latency is paid once, not per sample.
+    float2 cur[4], nxt[4];
+    auto fetch = [&](int c, float2 (&dst)[4]) {
+#pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int p = 64 * q + lane;
-            const int cx = (p & 15) + xmin + 16 * c, cy = (p >> 4) + ymin + 16 * c;
-            if (!(cx <= xmax && cy <= ymax)) continue;
-            const float2 gv = gptr[(long)cy * ow + cx];
-            const float mod = gv.x, ang = gv.y;
+            const int cx = tx + xmin + 16 * c, cy = 4 * q + tyg + ymin + 16 * c;
+            dst[q] = make_float2(0.f, 0.f);
+            if (cx <= xmax && cy <= ymax) dst[q] = gptr[(long)cy * ow + cx];
+        }
+    };
+    if (chunks > 0) fetch(0, cur);
+    for (int c = 0; c < chunks; ++c) {
+        if (c + 1 < chunks) fetch(c + 1, nxt);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cx = tx + xmin + 16 * c, cy = 4 * q + tyg + ymin + 16 * c;
+            const bool inwin = (cx <= xmax && cy <= ymax);
+            const float2 gq = cur[q];
+            const float mod = inwin ? gq.x : 0.f, ang = gq.y;
             const float theta = nmfp::mod_2pi_f(ang - angle0);
             const float dx = (float)(xi + cx) - x, dy = (float)(yi + cy) - y;
             const float nx = (float)(fma64(ct0, (double)dx, st0 * (double)dy) / dSBP);
@@ -138,32 +158,50 @@ __device__ __forceinline__ void describe_wave(const float4 kp, const float angle
             const float rbiny = (float)((double)ny - ((double)biny + 0.5));
             const float rbint = nt - (float)bint;
             const float wm = win * mod;
+            // votes outside the 4x4 grid (or outside the window) become +0 into the row's pad word, so the 8 addresses
+            // of a sample never collide and the read-add-write below can be issued as 8 loads, 8 adds, 8 stores
+            float wt[8];
+            int loc[8];
+            const int dummy = 16 - 80 * DESC_PITCH - tx;
 #pragma unroll
             for (int dbx = 0; dbx < 2; ++dbx)
 #pragma unroll
                 for (int dby = 0; dby < 2; ++dby)
 #pragma unroll
                     for (int dbt = 0; dbt < 2; ++dbt) {
-                        if (binx + dbx >= -2 && binx + dbx < 2 && biny + dby >= -2 && biny + dby < 2) {
-                            const float wt = wm * __builtin_fabsf((1.f - dbx) - rbinx) *
-                                             __builtin_fabsf((1.f - dby) - rbiny) * __builtin_fabsf((1.f - dbt) - rbint);
-                            const int loc = (binx + dbx) * 8 + (biny + dby) * 32 + ((bint + dbt) % 8);
-                            mine[loc * 64] += wt;
-                        }
+                        const int j = dbx * 4 + dby * 2 + dbt;
+                        const bool ok = inwin && binx + dbx >= -2 && binx + dbx < 2 && biny + dby >= -2 && biny + dby < 2;
+                        const float w3 = wm * __builtin_fabsf((1.f - dbx) - rbinx) * __builtin_fabsf((1.f - dby) - rbiny) *
+                                         __builtin_fabsf((1.f - dbt) - rbint);
+                        wt[j] = ok ? w3 : 0.f;
+                        loc[j] = ok ? ((binx + dbx) * 8 + (biny + dby) * 32 + ((bint + dbt) % 8)) * DESC_PITCH : dummy;
                     }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {          // rows of this pass in increasing cy: 16 lanes per group, LDS in order
+                if (tyg == k) {
+                    float o[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = mine[loc[j]];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) mine[loc[j]] = o[j] + wt[j];
+                }
+            }
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
     }
     __builtin_amdgcn_wave_barrier();
 
-    float acc0 = 0.f, acc1 = 0.f;
-    for (int b = 0; b < 128; ++b) {
-        float v = part[b * 64 + lane];
+    // lane b owns bins b and b+64: pairwise tree over the 16 partials (strides 1,2,4,8), all in registers
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) v = v + __shfl_xor(v, d);
-        if (lane == (b & 63)) { if (b < 64) acc0 = v; else acc1 = v; }
+    for (int hb = 0; hb < 2; ++hb) {
+        const float4 *row = reinterpret_cast<const float4 *>(part + (lane + 64 * hb) * DESC_PITCH);
+        const float4 a = row[0], b = row[1], c = row[2], d = row[3];
+        const float s01 = a.x + a.y, s23 = a.z + a.w, s45 = b.x + b.y, s67 = b.z + b.w;
+        const float s89 = c.x + c.y, sab = c.z + c.w, scd = d.x + d.y, sef = d.z + d.w;
+        const float t0 = s01 + s23, t1 = s45 + s67, t2 = s89 + sab, t3 = scd + sef;
+        desc[lane + 64 * hb] = (t0 + t1) + (t2 + t3);
     }
-    desc[lane] = acc0;
-    desc[64 + lane] = acc1;
 }
 
 // ---- API kernels (one octave, one level list per launch) ----
@@ -190,7 +228,7 @@ __global__ __launch_bounds__(64) void descriptors_kernel(const float4 *__restric
                                                         int num_dogs, float xper, float *__restrict__ desc,
                                                         float *__restrict__ xp, float *__restrict__ yp)
 {
-    __shared__ float part[128 * 64];
+    __shared__ __attribute__((aligned(16))) float part[DESC_LDS];
     for (int pt = blockIdx.x; pt < num_pts; pt += gridDim.x)
         describe_wave(key_pts[pt], orients[pt].x, grad, ow, oh, num_dogs, xper, desc + (size_t)pt * 128, xp + pt,
                       yp + pt, part);
@@ -223,7 +261,7 @@ __global__ __launch_bounds__(256) void frame_orient_kernel(NmDescribeArgs a)
 
 __global__ __launch_bounds__(64) void frame_desc_kernel(NmDescribeArgs a)
 {
-    __shared__ float part[128 * 64];
+    __shared__ __attribute__((aligned(16))) float part[DESC_LDS];
     const int n = a.book->num_items;
     const float4 *kpts = reinterpret_cast<const float4 *>(a.kpts);
     const float2 *orients = reinterpret_cast<const float2 *>(a.orients);
@@ -240,7 +278,7 @@ int nm_launch_frame_describe(const NmDescribeArgs &a, hipStream_t stream)
 {
     hipLaunchKernelGGL(frame_orient_kernel, dim3(1024), dim3(256), 0, stream, a);
     NM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(frame_desc_kernel, dim3(1280), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(frame_desc_kernel, dim3(4096), dim3(64), 0, stream, a);
     NM_LAUNCH_CHECK();
     return 0;
 }

@@ -21,7 +21,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int DIM = 128;
 constexpr int KP = 132;            // LDS row pitch (floats): 128 data + norm slot + pad; 132 mod 64 = 4 -> b128 reads conflict-free
 constexpr int TILE_C = 128;        // candidates per LDS tile
-constexpr int QB = 256;            // queries per workgroup (64 per wave, fragments resident in VGPRs)
+constexpr int QB = 256;            // queries per workgroup (32 per wave, fragments resident in VGPRs)
 constexpr float MIN2_INIT = 2139095040.0f;   // (float)0x7f800000, match.cu:91
 
 struct MatchPlan { int qblocks, S, chunk; };
@@ -65,8 +65,12 @@ __device__ __forceinline__ void top2_insert(Top2 &t, float d, int j)
     t.i1 = lt1 ? j : t.i1;
 }
 
-// grid = (qblocks, S). Dynamic LDS: 2 * TILE_C * KP floats.
-__global__ __launch_bounds__(256, 1) void match_top2_kernel(const float *__restrict__ A, int nA,
+// grid = (qblocks, S), 512 threads = 8 waves (2 per SIMD, so one wave's epilogue / staging overlaps the other's MFMAs).
+// Wave w owns queries i0 + 32 w .. +31 with their MFMA fragments resident in VGPRs; candidate tiles of 128 rows stream
+// through a double-buffered LDS image (row pitch KP). Dynamic LDS: 2 * TILE_C * KP floats.
+// MFMA orientation: rows (accumulator registers) = candidates, columns (lanes) = queries, so every lane scans its own
+// query's candidates in increasing index order and the running best/second-best never crosses lanes in the loop.
+__global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restrict__ A, int nA,
                                                            const float *__restrict__ B, int nB,
                                                            const float *__restrict__ na, const float *__restrict__ nb,
                                                            int chunk, int S, float4 *__restrict__ partial)
@@ -79,41 +83,35 @@ __global__ __launch_bounds__(256, 1) void match_top2_kernel(const float *__restr
     const int c0 = s * chunk;
     const int cend = min(c0 + chunk, nB);
     const int ntiles = (cend > c0) ? (cend - c0 + TILE_C - 1) / TILE_C : 0;
-    const int srow = tid >> 5, scol = (tid & 31) * 4;     // staging coordinates: 8 rows x 32 float4 per pass
+    const int srow = tid >> 5, scol = (tid & 31) * 4;     // staging coordinates: 16 rows x 32 float4 per pass
 
     // ---- prologue: queries -> LDS (coalesced) -> per-lane MFMA fragments in VGPRs ----
 #pragma unroll 4
-    for (int it = 0; it < QB / 8; ++it) {
-        const int row = srow + 8 * it;
+    for (int it = 0; it < QB / 16; ++it) {
+        const int row = srow + 16 * it;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i0 + row < nA) v = *reinterpret_cast<const float4 *>(A + (size_t)(i0 + row) * DIM + scol);
         *reinterpret_cast<float4 *>(&lds[row * KP + scol]) = v;
     }
     __syncthreads();
-    float4 qf[2][16];
-    float nq[2];
+    float4 qf[16];
+    const int qi = i0 + wave * 32 + r;
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
-        const int row = wave * 64 + 32 * ti + r;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) qf[ti][t] = *reinterpret_cast<const float4 *>(&lds[row * KP + 8 * t + 4 * h]);
-        const int qi = i0 + row;
-        const float nav = (qi < nA) ? na[qi] : 0.f;
-        nq[ti] = (h == 0) ? 1.0f : nav;
-    }
+    for (int t = 0; t < 16; ++t) qf[t] = *reinterpret_cast<const float4 *>(&lds[(wave * 32 + r) * KP + 8 * t + 4 * h]);
+    const float nav = (qi < nA) ? na[qi] : 0.f;
+    const float nq = (h == 0) ? 1.0f : nav;
     __syncthreads();
 
-    Top2 best[2];
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti) { best[ti].m1 = best[ti].m2 = __builtin_inff(); best[ti].i1 = best[ti].i2 = -1; }
+    Top2 best;
+    best.m1 = best.m2 = __builtin_inff(); best.i1 = best.i2 = -1;
 
-    float4 st[16];
+    float4 st[8];
     float stn = 0.f;
     auto stage_load = [&](int n) {
         const int jb = c0 + n * TILE_C;
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int j = jb + srow + 8 * it;
+        for (int it = 0; it < 8; ++it) {
+            const int j = jb + srow + 16 * it;
             st[it] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (j < cend) st[it] = *reinterpret_cast<const float4 *>(B + (size_t)j * DIM + scol);
         }
@@ -121,8 +119,8 @@ __global__ __launch_bounds__(256, 1) void match_top2_kernel(const float *__restr
     };
     auto stage_write = [&](float *buf) {
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int row = srow + 8 * it;
+        for (int it = 0; it < 8; ++it) {
+            const int row = srow + 16 * it;
             const float4 v = st[it];
             *reinterpret_cast<float4 *>(&buf[row * KP + scol]) = make_float4(-2.f * v.x, -2.f * v.y, -2.f * v.z, -2.f * v.w);
         }
@@ -138,13 +136,11 @@ __global__ __launch_bounds__(256, 1) void match_top2_kernel(const float *__restr
         const int jb = c0 + n * TILE_C;
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
-            f32x16 acc[2][2];
+            f32x16 acc[2];
 #pragma unroll
             for (int g = 0; g < 2; ++g)
 #pragma unroll
-                for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[g][ti][e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
             const float *rowp[2];
 #pragma unroll
             for (int g = 0; g < 2; ++g) rowp[g] = buf + (half * 64 + 32 * g + r) * KP;
@@ -153,9 +149,7 @@ __global__ __launch_bounds__(256, 1) void match_top2_kernel(const float *__restr
             for (int g = 0; g < 2; ++g) {
                 const float nbv = rowp[g][DIM];
                 const float cn = (h == 0) ? nbv : 1.0f;
-#pragma unroll
-                for (int ti = 0; ti < 2; ++ti)
-                    acc[g][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(cn, nq[ti], acc[g][ti], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(cn, nq, acc[g], 0, 0, 0);
             }
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
@@ -163,43 +157,40 @@ __global__ __launch_bounds__(256, 1) void match_top2_kernel(const float *__restr
 #pragma unroll
                 for (int g = 0; g < 2; ++g) cf[g] = *reinterpret_cast<const float4 *>(rowp[g] + 8 * t + 4 * h);
 #pragma unroll
-                for (int g = 0; g < 2; ++g)
-#pragma unroll
-                    for (int ti = 0; ti < 2; ++ti) {
-                        acc[g][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[g].x, qf[ti][t].x, acc[g][ti], 0, 0, 0);
-                        acc[g][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[g].y, qf[ti][t].y, acc[g][ti], 0, 0, 0);
-                        acc[g][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[g].z, qf[ti][t].z, acc[g][ti], 0, 0, 0);
-                        acc[g][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[g].w, qf[ti][t].w, acc[g][ti], 0, 0, 0);
-                    }
+                for (int g = 0; g < 2; ++g) {
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[g].x, qf[t].x, acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[g].y, qf[t].y, acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[g].z, qf[t].z, acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[g].w, qf[t].w, acc[g], 0, 0, 0);
+                }
             }
             // running best / second best. Within a lane the candidate index increases with (half, g, e).
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
+            for (int g = 0; g < 2; ++g) {
+                float mn = __builtin_fminf(acc[g][0], acc[g][1]);
 #pragma unroll
-                for (int ti = 0; ti < 2; ++ti)
+                for (int e = 2; e < 16; e += 2) mn = __builtin_fminf(mn, __builtin_fminf(acc[g][e], acc[g][e + 1]));
+                if (__any(mn < best.m2)) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        const float d = acc[g][ti][e];
-                        if (__any(d < best[ti].m2)) {
-                            const int j = jb + half * 64 + 32 * g + (e & 3) + 8 * (e >> 2) + 4 * h;
-                            top2_insert(best[ti], d, j);
-                        }
+                        const int j = jb + half * 64 + 32 * g + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        top2_insert(best, acc[g][e], j);
                     }
+                }
+            }
         }
         if (n + 1 < ntiles) stage_write(lds + ((n + 1) & 1) * (TILE_C * KP));
         __syncthreads();
     }
 
     // merge the two lane halves (same query, disjoint candidates) and publish
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
+    {
         Top2 o;
-        o.m1 = __shfl_xor(best[ti].m1, 32); o.m2 = __shfl_xor(best[ti].m2, 32);
-        o.i1 = __shfl_xor(best[ti].i1, 32); o.i2 = __shfl_xor(best[ti].i2, 32);
-        Top2 m = best[ti];
+        o.m1 = __shfl_xor(best.m1, 32); o.m2 = __shfl_xor(best.m2, 32);
+        o.i1 = __shfl_xor(best.i1, 32); o.i2 = __shfl_xor(best.i2, 32);
+        Top2 m = best;
         if (o.i1 >= 0) top2_insert(m, o.m1, o.i1);
         if (o.i2 >= 0) top2_insert(m, o.m2, o.i2);
-        const int qi = i0 + wave * 64 + 32 * ti + r;
         if (h == 0 && qi < nA)
             partial[(size_t)qi * S + s] = make_float4(m.m1, __int_as_float(m.i1), m.m2, __int_as_float(m.i2));
     }
@@ -428,7 +419,7 @@ static int run_fused(const float *A, int nA, const float *B, int nB, int mode, i
         attr_set = true;
     }
     nm_prof_begin(NM_PROF_MATCH_TOP2, st);
-    hipLaunchKernelGGL(match_top2_kernel, dim3(p.qblocks, p.S), dim3(256), lds_bytes, st, A, nA, B, nB, w.na, w.nb,
+    hipLaunchKernelGGL(match_top2_kernel, dim3(p.qblocks, p.S), dim3(512), lds_bytes, st, A, nA, B, nB, w.na, w.nb,
                        p.chunk, p.S, w.partial);
     nm_prof_end(NM_PROF_MATCH_TOP2, st);
     NM_LAUNCH_CHECK();

@@ -361,10 +361,10 @@ NMO_API void nmo_detect_orientations(const float *key_pts, const float *grad, in
 /* ---------------------------------------------------------------------------------------------------------- */
 /* descriptors -- kernels/descriptor.cu:32-145, Q12. Only the DIAGONAL 16x16 chunks of the window vote (cx and
  * cy advance together, :142-143); exp(+...) window; no normalisation; first orientation only.
- * FIXED ORDER (the reference's global atomicAdd order is undefined): the 256 positions of a chunk are indexed
- * p = ty*16+tx; position p belongs to partial histogram L = p mod 64. Each partial accumulates its votes in the
- * order (chunk, p div 64, dbinx, dbiny, dbint). bin = balanced pairwise tree over L = 0..63:
- * stride 1,2,4,...,32: v[i] += v[i+stride].                                                                 */
+ * FIXED ORDER (the reference's global atomicAdd order is undefined): within a chunk, the samples of column
+ * tx = cx - chunk origin (0..15) vote into partial histogram tx in increasing cy, each sample's 8 votes in
+ * (dbinx, dbiny, dbint) order; chunks in increasing order. bin = balanced pairwise tree over the 16 partials:
+ * stride 1,2,4,8: v[i] += v[i+stride].                                                                      */
 NMO_API void nmo_compute_sift_descriptors(const float *key_pts, const float *orients, const float *grad,
                                           int num_pts, int ow, int oh, int num_dogs, float xper, float *desc,
                                           float *xp, float *yp)
@@ -387,7 +387,7 @@ NMO_API void nmo_compute_sift_descriptors(const float *key_pts, const float *ori
         const float *gptr = grad + 2 * (((long)si * oh + yi) * ow + xi);
         const float angle0 = orients[2 * (size_t)pt];
         const double st0 = (double)nmo_sinf(angle0), ct0 = (double)nmo_cosf(angle0);
-        std::vector<float> part(64 * 128, 0.f);           /* part[L*128 + (80 + loc)] */
+        std::vector<float> part(16 * 128, 0.f);           /* part[tx*128 + (80 + loc)] */
         for (int c = 0; c < chunks; ++c)
             for (int q = 0; q < 4; ++q)
                 for (int L = 0; L < 64; ++L) {
@@ -417,12 +417,12 @@ NMO_API void nmo_compute_sift_descriptors(const float *key_pts, const float *ori
                                                      std::fabs((1.f - dby) - rbiny) * std::fabs((1.f - dbt) - rbint);
                                     const int loc = (binx + dbx) * binxo + (biny + dby) * binyo +
                                                     ((bint + dbt) * binto) % NBO;
-                                    part[L * 128 + 80 + loc] += wt;
+                                    part[(p & 15) * 128 + 80 + loc] += wt;
                                 }
                             }
                 }
-        for (int stride = 1; stride < 64; stride *= 2)
-            for (int i = 0; i < 64; i += 2 * stride)
+        for (int stride = 1; stride < 16; stride *= 2)
+            for (int i = 0; i < 16; i += 2 * stride)
                 for (int b = 0; b < 128; ++b) part[i * 128 + b] += part[(i + stride) * 128 + b];
         std::memcpy(desc + 128 * (size_t)pt, part.data(), 128 * sizeof(float));
     }
