@@ -124,7 +124,7 @@ int nm_sift_arena_create(int width, int height, int capacity, nm_sift_arena **ou
     for (int i = 0; !rc && i < 5; ++i) rc = a->alloc(&a->dog[i], a->npix);
     for (int o = 0; !rc && o < P._num_octaves; ++o)
         rc = a->alloc(&a->grad[o], (size_t)6 * (width >> o) * (height >> o));
-    a->max_blocks = nm_divup((int)a->npix, 256);
+    a->max_blocks = height * nm_divup(width, 256);
     a->stage_stride = (size_t)a->max_blocks * 256;
     if (!rc) rc = a->alloc(&a->staging, 3 * a->stage_stride * 4);
     if (!rc) rc = a->alloc(&a->counts, (size_t)3 * a->max_blocks);
@@ -199,12 +199,13 @@ int nm_sift_detect_describe(nm_sift_arena *a, const float *gray, float *desc, fl
         rc = octave_pyramid(a, o, ow, oh, st);
         if (rc) return rc;
 
-        const int n_blocks = nm_divup(ow * oh, 256);
+        const int nseg = nm_divup(ow, 256);
+        const int n_blocks = oh * nseg;
         NmDetectArgs d{};
         for (int i = 0; i < 5; ++i) d.dog[i] = a->dog[i];
         d.ow = ow; d.oh = oh; d.peak = P._peak_threshold; d.edge = P._edge_threshold; d.xper = xper;
         d.sigma0 = P._sigma_0; d.num_dogs = P._num_dog_levels; d.staging = a->staging; d.stage_stride = a->stage_stride;
-        d.counts = a->counts; d.n_blocks = n_blocks;
+        d.counts = a->counts; d.n_blocks = n_blocks; d.nseg = nseg;
         NmScanArgs s{};
         s.counts = a->counts; s.offsets = a->offsets; s.n_blocks = n_blocks; s.octave = o; s.capacity = a->capacity;
         s.book = a->book; s.d_num_items = d_num_items;

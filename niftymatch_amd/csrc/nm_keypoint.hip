@@ -211,27 +211,80 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(const int *__restrict
     if (threadIdx.x == 0 && total_out) *total_out = total;
 }
 
-// ---- frame-driver kernels: detect 3 levels of one octave straight into per-block staging, then scan + book-keeping,
+// ---- frame-driver kernels: detect 3 levels of one octave straight into per-unit staging, then scan + book-keeping,
 //      then gather into the output-ordered keypoint list ----
+// A unit is a 256-pixel segment of one image row (units in raster order: u = y * nseg + seg). One workgroup per unit,
+// one pixel per thread. Every lane loads its own column of the 3 rows x 5 DoG planes (15 coalesced 256-B row segments
+// per wave); horizontal neighbours come from the adjacent lanes by DPP wave shifts, the two segment-edge lanes fetch
+// their halo explicitly. The 26-neighbour strict extremum test is branch-free: per plane, max3/min3 of each row, then
+//   is_max(level l) = c > max(M9[l], M9[l+2], M8[l+1]),  M9 = max of a plane's 3x3, M8 = the 3x3 without its centre.
+// Only accepted candidates (rare) run the divergent sub-pixel refinement from global memory.
+__device__ __forceinline__ float dpp_from_lower(float own, float edge)   // lane i <- lane i-1, lane 0 <- edge
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(own), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_from_upper(float own, float edge)   // lane i <- lane i+1, lane 63 <- edge
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(own), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+__device__ __forceinline__ float min3f(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
+
 __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
 {
     __shared__ int s_wave[4];
-    const int level = blockIdx.y;
-    const float *__restrict__ cur = a.dog[level + 1];
-    const float *__restrict__ dn = a.dog[level];
-    const float *__restrict__ up = a.dog[level + 2];
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    bool f = false;
-    float4 kp;
-    if (idx < a.ow * a.oh) {
-        const int y = idx / a.ow, x = idx - y * a.ow;
-        f = detect_pixel(cur, dn, up, x, y, a.ow, a.oh, a.peak, a.edge, a.xper, a.sigma0, a.num_dogs, level, kp);
+    const int unit = blockIdx.x;
+    const int y = unit / a.nseg, seg = unit - y * a.nseg;
+    const int x = seg * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int ow = a.ow, oh = a.oh;
+    const bool xin = x < ow;
+    const int xc = xin ? x : ow - 1;                       // clamped column for safe addressing
+    const int xe = (lane == 0) ? max(xc - 1, 0) : min(xc + 1, ow - 1);
+    const bool edge_lane = (lane == 0) || (lane == 63);
+
+    float c[5], m9[5], n9[5], m8[5], n8[5];
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+        const float *__restrict__ pl = a.dog[p];
+        float rmax[3], rmin[3], mid1 = 0.f, l1 = 0.f, r1 = 0.f;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = min(max(y + dy, 0), oh - 1);
+            const float *row = pl + (size_t)yy * ow;
+            const float mid = row[xc];
+            float ev = 0.f;
+            if (edge_lane) ev = row[xe];
+            const float lf = dpp_from_lower(mid, ev), rt = dpp_from_upper(mid, ev);
+            rmax[dy + 1] = max3f(lf, mid, rt);
+            rmin[dy + 1] = min3f(lf, mid, rt);
+            if (dy == 0) { mid1 = mid; l1 = lf; r1 = rt; }
+        }
+        c[p] = mid1;
+        m9[p] = max3f(rmax[0], rmax[1], rmax[2]);
+        n9[p] = min3f(rmin[0], rmin[1], rmin[2]);
+        m8[p] = max3f(rmax[0], rmax[2], __builtin_fmaxf(l1, r1));
+        n8[p] = min3f(rmin[0], rmin[2], __builtin_fminf(l1, r1));
     }
-    int total;
-    const int r = block_rank(f, total, s_wave);
-    float4 *st = reinterpret_cast<float4 *>(a.staging) + (size_t)level * a.stage_stride + (size_t)blockIdx.x * 256;
-    if (f) st[r] = kp;
-    if (threadIdx.x == 0) a.counts[level * a.n_blocks + blockIdx.x] = total;
+    const bool interior = xin && x >= 1 && x <= ow - 2 && y >= 1 && y <= oh - 2;
+    const float thr = 0.8f * a.peak;
+#pragma unroll
+    for (int level = 0; level < 3; ++level) {
+        const float cv = c[level + 1];
+        const bool is_max = cv > max3f(m9[level], m9[level + 2], m8[level + 1]);
+        const bool is_min = cv < min3f(n9[level], n9[level + 2], n8[level + 1]);
+        bool f = interior && ((cv <= thr && is_min) || (cv >= thr && is_max));
+        float4 kp = make_float4(-1.f, -1.f, -1.f, -1.f);
+        if (f)
+            f = refine(a.dog[level + 1], a.dog[level], a.dog[level + 2], x, y, ow, a.peak, a.edge, a.xper, a.sigma0,
+                       a.num_dogs, level, kp);
+        int total;
+        const int r = block_rank(f, total, s_wave);
+        float4 *st = reinterpret_cast<float4 *>(a.staging) + (size_t)level * a.stage_stride + (size_t)unit * 256;
+        if (f) st[r] = kp;
+        if (threadIdx.x == 0) a.counts[level * a.n_blocks + unit] = total;
+        __syncthreads();                                   // s_wave is reused by the next level
+    }
 }
 
 __global__ __launch_bounds__(1024) void scan_book_kernel(NmScanArgs a)
@@ -281,7 +334,7 @@ __global__ __launch_bounds__(256) void gather_stage_kernel(NmGatherArgs a)
 int nm_launch_detect_octave(const NmDetectArgs &d, const NmScanArgs &s, const NmGatherArgs &g, hipStream_t stream)
 {
     if (d.n_blocks <= 0) return 0;
-    hipLaunchKernelGGL(detect_stage_kernel, dim3(d.n_blocks, 3), dim3(256), 0, stream, d);
+    hipLaunchKernelGGL(detect_stage_kernel, dim3(d.n_blocks), dim3(256), 0, stream, d);
     NM_LAUNCH_CHECK();
     hipLaunchKernelGGL(scan_book_kernel, dim3(1), dim3(1024), 0, stream, s);
     NM_LAUNCH_CHECK();

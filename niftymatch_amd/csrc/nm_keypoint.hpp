@@ -10,7 +10,8 @@ struct NmDetectArgs {
     float *staging;        // 3 x stage_stride float4: block b of level l writes its survivors at [l][b*256 ...]
     size_t stage_stride;   // in float4 elements
     int *counts;           // 3 x n_blocks
-    int n_blocks;          // ceil(ow*oh / 256): blocks are consecutive 256-pixel raster segments
+    int n_blocks;          // oh * nseg units: a unit is one 256-pixel segment of one row, units in raster order
+    int nseg;              // ceil(ow / 256)
 };
 
 struct NmScanArgs {

@@ -15,14 +15,16 @@ using nmfp::fma32;
 //   phase 3  column pass LDS -> global: every thread makes TH/4 vertical outputs of one column; a wave writes
 //            whole 256-B row segments. DoG = output - input centre comes from the LDS tile for free.
 // R is a template parameter so the tap loops unroll and the sliding windows live in VGPRs.
-template <int R, int TH, bool WRITE_BUF, bool WRITE_DOG>
+template <int R, int TH, bool WRITE_BUF, bool WRITE_DOG, bool VEC>
 __global__ __launch_bounds__(256) void conv_sep_kernel(float *__restrict__ result, const float *__restrict__ image,
                                                       float *__restrict__ buffer, float *__restrict__ dog, int width,
                                                       int height, const float *__restrict__ taps)
 {
     constexpr int TW = 64;
-    constexpr int IN_W = TW + 2 * R;
-    constexpr int IN_P = ((IN_W + 3) & ~3) + 4;   // row pitch: multiple of 4 (b128 reads) + 4 (bank skew)
+    constexpr int RA = (R + 3) & ~3;              // halo rounded up to 4 columns: 16-byte aligned row segments
+    constexpr int IN_W = TW + 2 * RA;             // columns staged in LDS (image x = x0 - RA + c)
+    constexpr int IN_P = IN_W + 4;                // row pitch: multiple of 4 (b128 reads) + 4 (bank skew)
+    constexpr int OFF = RA - R;                   // first column the row pass reads
     constexpr int ROWS = TH + 2 * R;
     constexpr int NT = 2 * R + 1;
     __shared__ __attribute__((aligned(16))) float s_in[ROWS * IN_P];
@@ -35,16 +37,44 @@ __global__ __launch_bounds__(256) void conv_sep_kernel(float *__restrict__ resul
 #pragma unroll
     for (int i = 0; i < NT; ++i) w[i] = taps[i];
 
-    // phase 1
-    for (int row = tid >> 6; row < ROWS; row += 4) {
-        const int gy = y0 - R + row;
-        const bool yin = (gy >= 0) && (gy < height);
-        const float *src = image + (size_t)(yin ? gy : 0) * width;
-        for (int c = tid & 63; c < IN_W; c += 64) {
-            const int gx = x0 - R + c;
-            float v = 0.f;
-            if (yin && gx >= 0 && gx < width) v = src[gx];
-            s_in[row * IN_P + c] = v;
+    // phase 1: all of a thread's loads are issued before the first LDS store (one exposed memory latency per tile)
+    if (VEC) {                                    // width % 4 == 0 and 16-byte aligned planes
+        constexpr int V_PER_ROW = IN_W / 4;
+        constexpr int NV = ROWS * V_PER_ROW;
+        constexpr int PER = (NV + 255) / 256;
+        float4 v[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / V_PER_ROW, c4 = idx - row * V_PER_ROW;
+            const int gy = y0 - R + row, gx = x0 - RA + 4 * c4;
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < NV && gy >= 0 && gy < height && gx >= 0 && gx < width)
+                v[i] = *reinterpret_cast<const float4 *>(image + (size_t)gy * width + gx);
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / V_PER_ROW, c4 = idx - row * V_PER_ROW;
+            if (idx < NV) *reinterpret_cast<float4 *>(&s_in[row * IN_P + 4 * c4]) = v[i];
+        }
+    } else {
+        constexpr int NE = ROWS * IN_W;
+        constexpr int PER = (NE + 255) / 256;
+        float v[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / IN_W, c = idx - row * IN_W;
+            const int gy = y0 - R + row, gx = x0 - RA + c;
+            v[i] = 0.f;
+            if (idx < NE && gy >= 0 && gy < height && gx >= 0 && gx < width) v[i] = image[(size_t)gy * width + gx];
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / IN_W, c = idx - row * IN_W;
+            if (idx < NE) s_in[row * IN_P + c] = v[i];
         }
     }
     __syncthreads();
@@ -53,17 +83,17 @@ __global__ __launch_bounds__(256) void conv_sep_kernel(float *__restrict__ resul
     {
         const int xc = tid & 7;
         for (int row = tid >> 3; row < ROWS; row += 32) {
-            float v[8 + 2 * R];
+            float v[8 + 2 * RA];                  // 16-byte aligned window; the taps use v[OFF .. OFF + 8 + 2R)
             const float *p = &s_in[row * IN_P + xc * 8];
 #pragma unroll
-            for (int j = 0; j < 8 + 2 * R; ++j) v[j] = p[j];
+            for (int j = 0; j < 8 + 2 * RA; ++j) v[j] = p[j];
             float o[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = 0.f;
 #pragma unroll
             for (int k = -R; k <= R; ++k) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) o[i] = fma32(v[i + R + k], w[R - k], o[i]);
+                for (int i = 0; i < 8; ++i) o[i] = fma32(v[OFF + i + R + k], w[R - k], o[i]);
             }
             float *q = &s_mid[row * TW + xc * 8];
 #pragma unroll
@@ -106,7 +136,7 @@ __global__ __launch_bounds__(256) void conv_sep_kernel(float *__restrict__ resul
                 const int gy = y0 + yy;
                 if (gy < height) {
                     result[(size_t)gy * width + gx] = o[i];
-                    if (WRITE_DOG) dog[(size_t)gy * width + gx] = o[i] - s_in[(yy + R) * IN_P + x + R];
+                    if (WRITE_DOG) dog[(size_t)gy * width + gx] = o[i] - s_in[(yy + R) * IN_P + x + RA];
                 }
             }
         }
@@ -144,22 +174,31 @@ __global__ __launch_bounds__(256) void conv_cols_generic(float *__restrict__ out
     if (dog) dog[(size_t)y * width + x] = sum - orig[(size_t)y * width + x];
 }
 
-template <int R>
-static int launch_conv_r(float *result, const float *image, float *buffer, float *dog, int width, int height,
-                         const float *taps, hipStream_t stream)
+template <int R, bool VEC>
+static int launch_conv_rv(float *result, const float *image, float *buffer, float *dog, int width, int height,
+                          const float *taps, hipStream_t stream)
 {
     constexpr int TH = 32;
     dim3 grid(nm_divup(width, 64), nm_divup(height, TH));
     if (buffer && dog)
-        hipLaunchKernelGGL((conv_sep_kernel<R, TH, true, true>), grid, dim3(256), 0, stream, result, image, buffer, dog, width, height, taps);
+        hipLaunchKernelGGL((conv_sep_kernel<R, TH, true, true, VEC>), grid, dim3(256), 0, stream, result, image, buffer, dog, width, height, taps);
     else if (buffer)
-        hipLaunchKernelGGL((conv_sep_kernel<R, TH, true, false>), grid, dim3(256), 0, stream, result, image, buffer, dog, width, height, taps);
+        hipLaunchKernelGGL((conv_sep_kernel<R, TH, true, false, VEC>), grid, dim3(256), 0, stream, result, image, buffer, dog, width, height, taps);
     else if (dog)
-        hipLaunchKernelGGL((conv_sep_kernel<R, TH, false, true>), grid, dim3(256), 0, stream, result, image, buffer, dog, width, height, taps);
+        hipLaunchKernelGGL((conv_sep_kernel<R, TH, false, true, VEC>), grid, dim3(256), 0, stream, result, image, buffer, dog, width, height, taps);
     else
-        hipLaunchKernelGGL((conv_sep_kernel<R, TH, false, false>), grid, dim3(256), 0, stream, result, image, buffer, dog, width, height, taps);
+        hipLaunchKernelGGL((conv_sep_kernel<R, TH, false, false, VEC>), grid, dim3(256), 0, stream, result, image, buffer, dog, width, height, taps);
     NM_LAUNCH_CHECK();
     return 0;
+}
+
+template <int R>
+static int launch_conv_r(float *result, const float *image, float *buffer, float *dog, int width, int height,
+                         const float *taps, hipStream_t stream)
+{
+    const bool vec = (width % 4 == 0) && ((reinterpret_cast<uintptr_t>(image) & 15) == 0);
+    return vec ? launch_conv_rv<R, true>(result, image, buffer, dog, width, height, taps, stream)
+               : launch_conv_rv<R, false>(result, image, buffer, dog, width, height, taps, stream);
 }
 
 int nm_launch_convolve(float *result, const float *image, float *buffer, float *dog, int width, int height,
