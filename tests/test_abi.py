@@ -1,0 +1,65 @@
+"""CPU-side checks of the drop-in boundary: libnm_hip.so loads without a GPU and exports every symbol that
+include/nm_abi.h declares; host-only entry points behave like the reference's."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    names = []
+    for hdr in ("nm_abi.h", "nm_client.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        for m in re.finditer(r"(?:NM_API|visibility\(\"default\"\)\)\))\s+[\w\s\*]+?\b(\w+)\s*\(", text):
+            names.append(m.group(1))
+    return names
+
+
+def test_library_exports_every_declared_symbol(nm):
+    lib = nm.lib()
+    declared = _declared()
+    assert len(declared) >= 35 and "nm_sift_match_f32" in declared and "DivUp" in declared
+    missing = [n for n in declared if not hasattr(lib, n)]
+    assert not missing, missing
+    assert set(nm.ABI_SYMBOLS) <= set(declared)
+
+
+def test_integer_helpers(nm):
+    lib = nm.lib()            # kernels/cudamath.cu:5-23
+    assert [lib.DivUp(5, 2), lib.DivUp(4, 2), lib.DivDown(5, 2)] == [3, 2, 2]
+    assert [lib.AlignUp(5, 4), lib.AlignUp(8, 4), lib.AlignDown(5, 4)] == [8, 8, 4]
+    assert lib.nm_version().startswith(b"niftymatch_amd")
+
+
+def test_host_taps_equal_oracle(nm, oracle):
+    for s in (1.5198684, 1.2262735, 1.5450078, 1.9465879, 2.4525473, 3.0900159, 4.0, 0.3):
+        t, r = nm.create_kernel_for_sigma(s)
+        to, ro = oracle.create_kernel_for_sigma(s)
+        assert r == ro and np.array_equal(t, to)
+
+
+def test_cpp_headers_mirror_reference_names():
+    """Every header a client of the hot path includes by name exists, flat, like ${prefix}/include/nm."""
+    need = ["macros.h", "exception.h", "siftparams.h", "pyramidata.h", "siftdata.h", "siftfunctions.h", "convolution.h",
+            "downsample.h", "cudamath.h", "keypoint.h", "orientation.h", "descriptor.h", "match.h", "transpose.h",
+            "cudatimer.h", "cudautils.h"]
+    have = os.listdir(os.path.join(ROOT, "niftymatch_amd", "nm"))
+    assert not [h for h in need if h not in have]
+    cfg = open(os.path.join(ROOT, "niftymatch_amd", "cmake", "NiftyMatchConfig.cmake")).read()
+    for var in ("NiftyMatch_INCLUDE_DIR", "NiftyMatch_LIBS", "NiftyMatch_gpuutils_LIB", "NiftyMatch_kernels_LIB",
+                "NiftyMatch_sift_LIB"):
+        assert var in cfg
+
+
+def test_no_cpu_fallback_when_library_missing(monkeypatch, nm):
+    monkeypatch.setattr(nm, "_lib", None)
+    monkeypatch.setattr(nm, "LIB_PATH", "/nonexistent/libnm_hip.so")
+    try:
+        nm.lib()
+        raise AssertionError("expected NmError")
+    except nm.NmError as e:
+        assert "no CPU fallback" in str(e)
