@@ -63,3 +63,36 @@ def test_no_cpu_fallback_when_library_missing(monkeypatch, nm):
         raise AssertionError("expected NmError")
     except nm.NmError as e:
         assert "no CPU fallback" in str(e)
+
+
+def test_cmake_find_package_dropin(tmp_path, nm):
+    """A client CMakeLists written against the reference (FIND_PACKAGE(NiftyMatch CONFIG), NiftyMatch_LIBS,
+    NiftyMatch_INCLUDE_DIR, flat includes) configures, builds and links against the installed drop-in."""
+    import shutil
+    import subprocess
+    if shutil.which("cmake") is None or not os.path.exists(os.path.join(ROOT, "niftymatch_amd", "lib", "nm", "libsift.a")):
+        import pytest
+        pytest.skip("cmake or the static libraries are not available")
+    prefix = tmp_path / "prefix"
+    subprocess.check_call([os.path.join(ROOT, "tools", "install_prefix.sh"), str(prefix)], stdout=subprocess.DEVNULL)
+    for f in ("macros.h", "siftfunctions.h", "NiftyMatchConfig.cmake"):
+        assert (prefix / "include" / "nm" / f).exists()
+    src = tmp_path / "client"
+    src.mkdir()
+    (src / "CMakeLists.txt").write_text(
+        "CMAKE_MINIMUM_REQUIRED(VERSION 3.10)\nPROJECT(client CXX)\nSET(CMAKE_CXX_STANDARD 17)\n"
+        "FIND_PACKAGE(NiftyMatch CONFIG REQUIRED)\nINCLUDE_DIRECTORIES(${NiftyMatch_INCLUDE_DIR} /opt/rocm/include)\n"
+        "ADD_DEFINITIONS(-D__HIP_PLATFORM_AMD__)\nADD_EXECUTABLE(app main.cpp)\n"
+        "TARGET_LINK_LIBRARIES(app ${NiftyMatch_LIBS})\n")
+    (src / "main.cpp").write_text(
+        '#include "siftfunctions.h"\n#include "convolution.h"\n#include "match.h"\n#include "macros.h"\n#include <cstdio>\n'
+        "int main() { SiftParams p(1920, 1080); std::printf(\"%d %zu %d\\n\", p._num_octaves, p._sigmas.size(), DivUp(7, 2));\n"
+        "  if (p._num_octaves < 0) { PyramidData py(p); SiftData d(16); compute_dog(py, 8, 8); compute_sift_matches(&d, &d, nullptr); }\n"
+        "  return 0; }\n")
+    build = tmp_path / "build"
+    build.mkdir()
+    subprocess.check_call(["cmake", "-DNiftyMatch_DIR=%s" % (prefix / "include" / "nm"), str(src)], cwd=build,
+                          stdout=subprocess.DEVNULL)
+    subprocess.check_call(["cmake", "--build", "."], cwd=build, stdout=subprocess.DEVNULL)
+    out = subprocess.check_output([str(build / "app")]).decode().split()
+    assert out == ["6", "5", "4"]
