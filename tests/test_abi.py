@@ -85,7 +85,7 @@ def test_cmake_find_package_dropin(tmp_path, nm):
         "ADD_DEFINITIONS(-D__HIP_PLATFORM_AMD__)\nADD_EXECUTABLE(app main.cpp)\n"
         "TARGET_LINK_LIBRARIES(app ${NiftyMatch_LIBS})\n")
     (src / "main.cpp").write_text(
-        '#include "siftfunctions.h"\n#include "convolution.h"\n#include "match.h"\n#include "macros.h"\n#include <cstdio>\n'
+        '#include "siftfunctions.h"\n#include "convolution.h"\n#include "match.h"\n#include "cudamath.h"\n#include "macros.h"\n#include <cstdio>\n'
         "int main() { SiftParams p(1920, 1080); std::printf(\"%d %zu %d\\n\", p._num_octaves, p._sigmas.size(), DivUp(7, 2));\n"
         "  if (p._num_octaves < 0) { PyramidData py(p); SiftData d(16); compute_dog(py, 8, 8); compute_sift_matches(&d, &d, nullptr); }\n"
         "  return 0; }\n")
