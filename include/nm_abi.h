@@ -49,7 +49,7 @@ NM_API int nm_fill_u32(void *dst, size_t count, unsigned int pattern, void *stre
  * While a (start, stop) hipEvent_t pair is registered for `site`, the launcher records start immediately before and
  * stop immediately after that kernel (sequence) on the stream it launches on. Pass NULLs to clear. Per host thread.
  *   NM_PROF_MATCH_TOP2 : the MFMA top-2 kernel inside nm_sift_match_f32 / nm_sift_match_shard_f32
- *   NM_PROF_PYRAMID_O0 : the octave-0 pyramid sequence (5 fused Gaussian+DoG launches + gradients) inside
+ *   NM_PROF_PYRAMID_O0 : the octave-0 pyramid sequence (5 fused Gaussian + DoG + gradient launches) inside
  *                        nm_sift_detect_describe / nm_sift_octave_pyramid                                       */
 #define NM_PROF_MATCH_TOP2 0
 #define NM_PROF_PYRAMID_O0 1

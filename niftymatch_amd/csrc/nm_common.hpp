@@ -34,9 +34,10 @@ struct NmGradBatch {            // up to 3 planes per launch (gradient levels 0.
     int n;
 };
 int nm_launch_gradient_batch(const NmGradBatch &b, int width, int height, hipStream_t stream);
-// Gaussian level + fused DoG (dog = result - image); buffer may be NULL (row pass not materialised).
-int nm_launch_convolve(float *result, const float *image, float *buffer, float *dog, int width, int height,
-                       const float *taps_dev, int radius, hipStream_t stream);
+// Gaussian level + fused DoG (dog = result - image) + fused gradient of `image` (float2 plane); buffer, dog and grad
+// may be NULL. buffer (the materialised row pass of the API path) excludes dog/grad.
+int nm_launch_convolve(float *result, const float *image, float *buffer, float *dog, float *grad, int width,
+                       int height, const float *taps_dev, int radius, hipStream_t stream);
 
 // Device-side record the frame driver shares between its kernels.
 struct NmFrameBook {

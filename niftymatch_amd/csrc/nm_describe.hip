@@ -3,8 +3,9 @@
 //
 // The reference accumulates its histograms with shared/global float atomicAdd, whose order is undefined. Here the
 // order is fixed (DESIGN.md "fp spec") and implemented without atomics:
-//   orientation: bin b = sum of its votes in raster order of the clipped window (the order of the reference's own
-//                one-thread kernel, orientation.cu:165-176): lane b scans the wave's vote list in LDS.
+//   orientation: the clipped window (<= 21 x 21) is cut into 63 strips (column rx, row third ry/7), one per lane; a
+//                lane sums its <= 7 votes per bin in increasing cy into a private LDS histogram; lane b then adds
+//                the 63 partials of bin b in strip order.
 //   descriptor : the samples of column tx (0..15) of a 16x16 chunk vote into partial histogram tx in increasing cy
 //                (4 rows per wave pass, issued as 4 exec-masked read-add-write groups in row order: LDS executes a
 //                wave's instructions in order), 8 votes per sample in (dbinx, dbiny, dbint) order; the 16 partials
@@ -20,14 +21,13 @@ using nmfp::fma64;
 namespace {
 
 constexpr int ORI_MAXW = 10;                    // 22x22 block of the reference -> W <= 10 (orientation.cu:29-30)
+constexpr int ORI_PITCH = 65;                   // floats per bin row: 64 strip partials + 1 (bank skew for the column sum)
+constexpr int ORI_LDS = 36 * ORI_PITCH;         // floats of LDS per wave (9.4 KB)
 
-constexpr int ORI_LDS = 448;                    // per-wave slots
-
-// One wave computes the orientation(s) of one keypoint. s_bin/s_val: ORI_LDS entries private to the wave.
+// One wave computes the orientation(s) of one keypoint. part: ORI_LDS floats private to the wave, [bin][strip].
 // Returns the number of peaks found (0..2); th0/th1 are valid in every lane.
 __device__ __forceinline__ int orient_wave(const float4 kp, const float2 *__restrict__ grad, int ow, int oh,
-                                           float gauss_factor, float xper, float &th0, float &th1,
-                                           int *s_bin, float *s_val)
+                                           float gauss_factor, float xper, float &th0, float &th1, float *part)
 {
     const int lane = threadIdx.x & 63;
     th0 = -1.f; th1 = -1.f;
@@ -40,35 +40,44 @@ __device__ __forceinline__ int orient_wave(const float4 kp, const float2 *__rest
     const float2 *g = grad + (((long)kp.w * oh + yi) * (long)ow + xi);
     const int xmin = max(-W, -xi), xmax = min(W, ow - 1 - xi);
     const int ymin = max(-W, -yi), ymax = min(W, oh - 1 - yi);
-    const int nx = xmax - xmin + 1, ny = ymax - ymin + 1;
-    const int n = (nx > 0 && ny > 0) ? nx * ny : 0;
     const float denom = (2 * sigma_w) * sigma_w;
     const double r2lim = (double)(W * W) + 0.6;
 
-    for (int p = lane; p < n; p += 64) {
-        const int ry = p / nx, rx = p - ry * nx;
-        const int cx = xmin + rx, cy = ymin + ry;
+#pragma unroll
+    for (int i = lane; i < ORI_LDS; i += 64) part[i] = 0.f;
+
+    // strip of this lane: column rx = lane % 21, rows 7*rg .. 7*rg+6 with rg = lane / 21 (lane 63 idles)
+    const int rg = lane / 21, rx = lane - 21 * rg;
+    const int cx = xmin + rx;
+    const bool col_ok = (lane < 63) && (cx <= xmax);
+    float2 gv[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {                // all 7 gathers in flight together
+        const int cy = ymin + 7 * rg + j;
+        gv[j] = make_float2(0.f, 0.f);
+        if (col_ok && cy <= ymax) gv[j] = g[(long)cy * ow + cx];
+    }
+    float *mine = part + lane;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int cy = ymin + 7 * rg + j;
         const float dx = (float)(cx + xi) - x, dy = (float)(cy + yi) - y;
         const float r2 = fma32(dx, dx, dy * dy);
-        int bin = -1;
-        float val = 0.f;
-        if ((double)r2 < r2lim) {
+        if (col_ok && cy <= ymax && (double)r2 < r2lim) {
             const float wgt = nmfp::expf_spec(r2 / denom);
-            const float2 gv = g[(long)cy * ow + cx];
-            const float q = (float)((double)(36.0f * gv.y) / nmfp::TWO_PI_D);
-            bin = ((int)__builtin_floorf(q)) % 36;
-            val = gv.x * wgt;
+            const float q = (float)((double)(36.0f * gv[j].y) / nmfp::TWO_PI_D);
+            const int bin = ((int)__builtin_floorf(q)) % 36;
+            mine[bin * ORI_PITCH] += gv[j].x * wgt;   // lane-private word: plain read-add-write, program order
         }
-        s_bin[p] = bin;
-        s_val[p] = val;
     }
     __builtin_amdgcn_wave_barrier();             // same-wave LDS traffic is in order; this only pins the compiler
 
-    float h = 0.f;                                // lane b < 36 owns bin b
-    for (int p = 0; p < n; ++p) {
-        const int b = s_bin[p];
-        const float v = s_val[p];
-        h += (b == lane) ? v : 0.f;               // +0 leaves h unchanged (h >= +0 always)
+    float h = 0.f;                                // lane b < 36 owns bin b: partials in strip order
+    if (lane < 36) {
+        const float *row = part + lane * ORI_PITCH;
+        h = row[0];
+#pragma unroll 9
+        for (int p = 1; p < 63; ++p) h += row[p];
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -209,12 +218,11 @@ __global__ __launch_bounds__(256) void orientations_kernel(const float4 *__restr
                                                           const float2 *__restrict__ grad, int num_pts, int ow, int oh,
                                                           float gauss_factor, float xper, float2 *__restrict__ result)
 {
-    __shared__ int s_bin[4][ORI_LDS];
-    __shared__ float s_val[4][ORI_LDS];
+    __shared__ float s_part[4][ORI_LDS];
     const int wave = threadIdx.x >> 6;
     for (int pt = blockIdx.x * 4 + wave; pt < num_pts; pt += gridDim.x * 4) {
         float th0, th1;
-        const int npk = orient_wave(key_pts[pt], grad, ow, oh, gauss_factor, xper, th0, th1, s_bin[wave], s_val[wave]);
+        const int npk = orient_wave(key_pts[pt], grad, ow, oh, gauss_factor, xper, th0, th1, s_part[wave]);
         if ((threadIdx.x & 63) == 0) {            // only found peaks are written (orientation.cu:117-128)
             if (npk >= 1) result[pt].x = th0;
             if (npk >= 2) result[pt].y = th1;
@@ -244,8 +252,7 @@ __device__ __forceinline__ int octave_of(const NmFrameBook *book, int num_octave
 
 __global__ __launch_bounds__(256) void frame_orient_kernel(NmDescribeArgs a)
 {
-    __shared__ int s_bin[4][ORI_LDS];
-    __shared__ float s_val[4][ORI_LDS];
+    __shared__ float s_part[4][ORI_LDS];
     const int wave = threadIdx.x >> 6;
     const int n = a.book->num_items;
     const float4 *kpts = reinterpret_cast<const float4 *>(a.kpts);
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(256) void frame_orient_kernel(NmDescribeArgs a)
         const int o = octave_of(a.book, a.num_octaves, pt);
         float th0, th1;                           // unset components stay -1 (pyramidata.cu:90)
         orient_wave(kpts[pt], reinterpret_cast<const float2 *>(a.geom[o].grad), a.geom[o].ow, a.geom[o].oh, 1.5f,
-                    a.geom[o].xper, th0, th1, s_bin[wave], s_val[wave]);
+                    a.geom[o].xper, th0, th1, s_part[wave]);
         if ((threadIdx.x & 63) == 0) orients[pt] = make_float2(th0, th1);
     }
 }

@@ -154,16 +154,15 @@ float *nm_sift_arena_grad(nm_sift_arena *a) { return a ? a->grad[0] : nullptr; }
 static int octave_pyramid(nm_sift_arena *a, int o, int ow, int oh, hipStream_t st)
 {
     if (o == 0) nm_prof_begin(NM_PROF_PYRAMID_O0, st);
-    for (int i = 1; i < 6; ++i) {
-        int rc = nm_launch_convolve(a->level[i], a->level[i - 1], nullptr, a->dog[i - 1], ow, oh, a->taps[i - 1],
-                                    a->radii[i - 1], st);
-        if (rc) return rc;
-    }
-    NmGradBatch gb{};
     const size_t plane = (size_t)ow * oh;
-    for (int l = 0; l < 3; ++l) { gb.src[l] = a->level[l + 1]; gb.dst[l] = a->grad[o] + 2 * l * plane; }
-    gb.n = 3;
-    const int rc = nm_launch_gradient_batch(gb, ow, oh, st);
+    int rc = 0;
+    for (int i = 1; i < 6 && !rc; ++i) {
+        // the launch that blurs level i-1 into level i also emits DoG i-1 and, for i-1 in 1..3, the gradient plane
+        // i-2 of level i-1 (compute_gradients: level l from octave[l+1], sift/siftfunctions.cu:53-63)
+        float *grad = (i >= 2 && i <= 4) ? a->grad[o] + 2 * (size_t)(i - 2) * plane : nullptr;
+        rc = nm_launch_convolve(a->level[i], a->level[i - 1], nullptr, a->dog[i - 1], grad, ow, oh, a->taps[i - 1],
+                                a->radii[i - 1], st);
+    }
     if (o == 0) nm_prof_end(NM_PROF_PYRAMID_O0, st);
     return rc;
 }
@@ -182,7 +181,7 @@ int nm_sift_detect_describe(nm_sift_arena *a, const float *gray, float *desc, fl
     const SiftParams &P = a->params;
     float *kp = kpts ? kpts : a->kpts;
     float *ori = orients ? orients : a->orients;
-    int rc = nm_launch_convolve(a->level[0], gray, nullptr, nullptr, a->width, a->height, a->taps_base, a->base_radius, st);
+    int rc = nm_launch_convolve(a->level[0], gray, nullptr, nullptr, nullptr, a->width, a->height, a->taps_base, a->base_radius, st);
     if (rc) return rc;
 
     NmDescribeArgs da{};

@@ -11,6 +11,8 @@
 //                          the scan semantics of match.cu:91-116 (lowest index wins ties, min2 initial 2139095040.0f,
 //                          result untouched when min2 <= 0).
 // API building blocks (transpose / bf_distance / get_sift_matches) keep the reference's layouts and are exact.
+#include <cstdlib>
+
 #include "nm_common.hpp"
 #include "../../include/nm_abi.h"
 
@@ -70,6 +72,7 @@ __device__ __forceinline__ void top2_insert(Top2 &t, float d, int j)
 // through a double-buffered LDS image (row pitch KP). Dynamic LDS: 2 * TILE_C * KP floats.
 // MFMA orientation: rows (accumulator registers) = candidates, columns (lanes) = queries, so every lane scans its own
 // query's candidates in increasing index order and the running best/second-best never crosses lanes in the loop.
+template <int DBG>
 __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restrict__ A, int nA,
                                                            const float *__restrict__ B, int nB,
                                                            const float *__restrict__ na, const float *__restrict__ nb,
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
 
     for (int n = 0; n < ntiles; ++n) {
         float *buf = lds + (n & 1) * (TILE_C * KP);
-        if (n + 1 < ntiles) stage_load(n + 1);
+        if (DBG != 2) { if (n + 1 < ntiles) stage_load(n + 1); }
         const int jb = c0 + n * TILE_C;
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
@@ -165,6 +168,7 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
                 }
             }
             // running best / second best. Within a lane the candidate index increases with (half, g, e).
+            if (DBG == 1) { best.m1 = __builtin_fminf(best.m1, acc[0][0] + acc[1][5]); continue; }
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 float mn = __builtin_fminf(acc[g][0], acc[g][1]);
@@ -179,8 +183,8 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
                 }
             }
         }
-        if (n + 1 < ntiles) stage_write(lds + ((n + 1) & 1) * (TILE_C * KP));
-        __syncthreads();
+        if (DBG != 2) { if (n + 1 < ntiles) stage_write(lds + ((n + 1) & 1) * (TILE_C * KP)); }
+        if (DBG != 3) __syncthreads();
     }
 
     // merge the two lane halves (same query, disjoint candidates) and publish
@@ -413,13 +417,29 @@ static int run_fused(const float *A, int nA, const float *B, int nB, int mode, i
     NM_LAUNCH_CHECK();
     const size_t lds_bytes = (size_t)2 * TILE_C * KP * sizeof(float);
     static bool attr_set = false;
+    static int dbg = 0;
     if (!attr_set) {
-        NM_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_kernel),
+        const char *e = getenv("NM_MATCH_DEBUG");
+        dbg = e ? atoi(e) : 0;
+        NM_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_kernel<0>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        NM_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_kernel<1>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        NM_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_kernel<2>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        NM_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_kernel<3>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_set = true;
     }
     nm_prof_begin(NM_PROF_MATCH_TOP2, st);
-    hipLaunchKernelGGL(match_top2_kernel, dim3(p.qblocks, p.S), dim3(512), lds_bytes, st, A, nA, B, nB, w.na, w.nb,
+    if (dbg == 1)
+        hipLaunchKernelGGL(match_top2_kernel<1>, dim3(p.qblocks, p.S), dim3(512), lds_bytes, st, A, nA, B, nB, w.na, w.nb, p.chunk, p.S, w.partial);
+    else if (dbg == 2)
+        hipLaunchKernelGGL(match_top2_kernel<2>, dim3(p.qblocks, p.S), dim3(512), lds_bytes, st, A, nA, B, nB, w.na, w.nb, p.chunk, p.S, w.partial);
+    else if (dbg == 3)
+        hipLaunchKernelGGL(match_top2_kernel<3>, dim3(p.qblocks, p.S), dim3(512), lds_bytes, st, A, nA, B, nB, w.na, w.nb, p.chunk, p.S, w.partial);
+    else
+    hipLaunchKernelGGL(match_top2_kernel<0>, dim3(p.qblocks, p.S), dim3(512), lds_bytes, st, A, nA, B, nB, w.na, w.nb,
                        p.chunk, p.S, w.partial);
     nm_prof_end(NM_PROF_MATCH_TOP2, st);
     NM_LAUNCH_CHECK();

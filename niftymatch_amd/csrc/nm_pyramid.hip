@@ -2,6 +2,8 @@
 // gradient. Replaces kernels/convolution.cu:16-159, kernels/downsample.cu:6-29, kernels/cudamath.cu:26-80 of the
 // reference. All kernels are HBM/L2 streaming stencils; arithmetic order is fixed by the fp spec:
 //   conv: taps k = -r..r, sum = fma(x[k], w[r-k], sum) starting from +0, rows first, then columns, zero padding.
+#include <cstdlib>
+
 #include "nm_common.hpp"
 #include "nm_fpspec.hpp"
 #include "../../include/nm_abi.h"
@@ -9,16 +11,22 @@
 using nmfp::fma32;
 
 // ------------------------------------------------------------------------------------------------------------
-// Fused separable Gaussian. One workgroup (256 threads = 4 waves) produces a 64 x TH output tile:
-//   phase 1  global -> LDS: (TH+2R) x (64+2R) input tile, zero outside the image (coalesced 256-B row segments)
-//   phase 2  row pass LDS -> LDS: every thread makes 8 consecutive outputs of one row from 8+2R registers
+// Fused separable Gaussian. A workgroup (256 threads = 4 waves) walks over 64 x TH output tiles:
+//   fetch    global -> VGPRs: the (TH+2R) x (64+2RA) input tile of the NEXT tile is requested (float4, all loads in
+//            flight together) before the current tile is computed, so HBM latency hides behind the FMA phases
+//   phase 1  VGPRs -> LDS (zero outside the image)
+//   phase 2  row pass LDS -> LDS: every thread makes 8 consecutive outputs of one row from registers
 //   phase 3  column pass LDS -> global: every thread makes TH/4 vertical outputs of one column; a wave writes
-//            whole 256-B row segments. DoG = output - input centre comes from the LDS tile for free.
-// R is a template parameter so the tap loops unroll and the sliding windows live in VGPRs.
-template <int R, int TH, bool WRITE_BUF, bool WRITE_DOG, bool VEC>
+//            whole 256-B row segments. DoG = output - input centre comes from the LDS tile for free, and so does
+//            the gradient (magnitude, angle) of the INPUT level (kernels/cudamath.cu:38-54), whose 4-neighbourhood is
+//            inside the staged halo: levels 1..3 get their gradients from the launch that blurs them into level+1.
+// Tiles are dealt so that workgroups sharing an XCD (blockIdx % 8) walk one contiguous band of the image: halo rows
+// re-read by vertical neighbours hit that XCD's L2. R is a template parameter: tap loops unroll, windows live in VGPRs.
+template <int R, int TH, bool WRITE_BUF, bool WRITE_DOG, bool WRITE_GRAD, bool VEC>
 __global__ __launch_bounds__(256) void conv_sep_kernel(float *__restrict__ result, const float *__restrict__ image,
-                                                      float *__restrict__ buffer, float *__restrict__ dog, int width,
-                                                      int height, const float *__restrict__ taps)
+                                                      float *__restrict__ buffer, float *__restrict__ dog,
+                                                      float2 *__restrict__ grad, int width, int height,
+                                                      const float *__restrict__ taps, int tiles_x, int ntiles)
 {
     constexpr int TW = 64;
     constexpr int RA = (R + 3) & ~3;              // halo rounded up to 4 columns: 16-byte aligned row segments
@@ -27,119 +35,141 @@ __global__ __launch_bounds__(256) void conv_sep_kernel(float *__restrict__ resul
     constexpr int OFF = RA - R;                   // first column the row pass reads
     constexpr int ROWS = TH + 2 * R;
     constexpr int NT = 2 * R + 1;
+    constexpr int V_PER_ROW = IN_W / 4;
+    constexpr int NE = VEC ? ROWS * V_PER_ROW : ROWS * IN_W;     // staged elements (float4 or float)
+    constexpr int PER = (NE + 255) / 256;
     __shared__ __attribute__((aligned(16))) float s_in[ROWS * IN_P];
     __shared__ __attribute__((aligned(16))) float s_mid[ROWS * TW];
 
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-
     float w[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) w[i] = taps[i];
 
-    // phase 1: all of a thread's loads are issued before the first LDS store (one exposed memory latency per tile)
-    if (VEC) {                                    // width % 4 == 0 and 16-byte aligned planes
-        constexpr int V_PER_ROW = IN_W / 4;
-        constexpr int NV = ROWS * V_PER_ROW;
-        constexpr int PER = (NV + 255) / 256;
-        float4 v[PER];
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int idx = tid + 256 * i;
-            const int row = idx / V_PER_ROW, c4 = idx - row * V_PER_ROW;
-            const int gy = y0 - R + row, gx = x0 - RA + 4 * c4;
-            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < NV && gy >= 0 && gy < height && gx >= 0 && gx < width)
-                v[i] = *reinterpret_cast<const float4 *>(image + (size_t)gy * width + gx);
-        }
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int idx = tid + 256 * i;
-            const int row = idx / V_PER_ROW, c4 = idx - row * V_PER_ROW;
-            if (idx < NV) *reinterpret_cast<float4 *>(&s_in[row * IN_P + 4 * c4]) = v[i];
-        }
-    } else {
-        constexpr int NE = ROWS * IN_W;
-        constexpr int PER = (NE + 255) / 256;
-        float v[PER];
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int idx = tid + 256 * i;
-            const int row = idx / IN_W, c = idx - row * IN_W;
-            const int gy = y0 - R + row, gx = x0 - RA + c;
-            v[i] = 0.f;
-            if (idx < NE && gy >= 0 && gy < height && gx >= 0 && gx < width) v[i] = image[(size_t)gy * width + gx];
-        }
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int idx = tid + 256 * i;
-            const int row = idx / IN_W, c = idx - row * IN_W;
-            if (idx < NE) s_in[row * IN_P + c] = v[i];
-        }
-    }
-    __syncthreads();
+    // tile schedule: XCD-contiguous bands
+    const int nxcd = 8;
+    const int xcd = blockIdx.x % nxcd, slot = blockIdx.x / nxcd, per_xcd = gridDim.x / nxcd;   // gridDim.x % 8 == 0
+    const int band = (ntiles + nxcd - 1) / nxcd;
+    const int t_begin = xcd * band, t_end = min(t_begin + band, ntiles);
 
-    // phase 2: rows
-    {
-        const int xc = tid & 7;
-        for (int row = tid >> 3; row < ROWS; row += 32) {
-            float v[8 + 2 * RA];                  // 16-byte aligned window; the taps use v[OFF .. OFF + 8 + 2R)
-            const float *p = &s_in[row * IN_P + xc * 8];
+    float4 pf4[VEC ? PER : 1];
+    float pf1[VEC ? 1 : PER];
+    auto fetch = [&](int tile) {
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int x0 = tx * TW, y0 = ty * TH;
 #pragma unroll
-            for (int j = 0; j < 8 + 2 * RA; ++j) v[j] = p[j];
-            float o[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] = 0.f;
-#pragma unroll
-            for (int k = -R; k <= R; ++k) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) o[i] = fma32(v[OFF + i + R + k], w[R - k], o[i]);
+        for (int i = 0; i < PER; ++i) {
+            const int idx = tid + 256 * i;
+            if (VEC) {
+                const int row = idx / V_PER_ROW, c4 = idx - row * V_PER_ROW;
+                const int gy = y0 - R + row, gx = x0 - RA + 4 * c4;
+                pf4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < NE && gy >= 0 && gy < height && gx >= 0 && gx < width)
+                    pf4[i] = *reinterpret_cast<const float4 *>(image + (size_t)gy * width + gx);
+            } else {
+                const int row = idx / IN_W, c = idx - row * IN_W;
+                const int gy = y0 - R + row, gx = x0 - RA + c;
+                pf1[i] = 0.f;
+                if (idx < NE && gy >= 0 && gy < height && gx >= 0 && gx < width) pf1[i] = image[(size_t)gy * width + gx];
             }
-            float *q = &s_mid[row * TW + xc * 8];
+        }
+    };
+
+    int tile = t_begin + slot;
+    if (tile < t_end) fetch(tile);
+    for (; tile < t_end; tile += per_xcd) {
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int x0 = tx * TW, y0 = ty * TH;
+
+        // phase 1: registers -> LDS
 #pragma unroll
-            for (int i = 0; i < 8; ++i) q[i] = o[i];
-            if (WRITE_BUF) {
-                const int gy = y0 - R + row;
-                if (row >= R && row < R + TH && gy < height) {
+        for (int i = 0; i < PER; ++i) {
+            const int idx = tid + 256 * i;
+            if (VEC) {
+                const int row = idx / V_PER_ROW, c4 = idx - row * V_PER_ROW;
+                if (idx < NE) *reinterpret_cast<float4 *>(&s_in[row * IN_P + 4 * c4]) = pf4[i];
+            } else {
+                const int row = idx / IN_W, c = idx - row * IN_W;
+                if (idx < NE) s_in[row * IN_P + c] = pf1[i];
+            }
+        }
+        __syncthreads();
+        if (tile + per_xcd < t_end) fetch(tile + per_xcd);        // next tile's loads fly during phases 2 and 3
+
+        // phase 2: rows
+        {
+            const int xc = tid & 7;
+            for (int row = tid >> 3; row < ROWS; row += 32) {
+                float v[8 + 2 * RA];                  // 16-byte aligned window; the taps use v[OFF .. OFF + 8 + 2R)
+                const float *p = &s_in[row * IN_P + xc * 8];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int gx = x0 + xc * 8 + i;
-                        if (gx < width) buffer[(size_t)gy * width + gx] = o[i];
+                for (int j = 0; j < 8 + 2 * RA; ++j) v[j] = p[j];
+                float o[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = 0.f;
+#pragma unroll
+                for (int k = -R; k <= R; ++k) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o[i] = fma32(v[OFF + i + R + k], w[R - k], o[i]);
+                }
+                float *q = &s_mid[row * TW + xc * 8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) q[i] = o[i];
+                if (WRITE_BUF) {
+                    const int gy = y0 - R + row;
+                    if (row >= R && row < R + TH && gy < height) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int gx = x0 + xc * 8 + i;
+                            if (gx < width) buffer[(size_t)gy * width + gx] = o[i];
+                        }
                     }
                 }
             }
         }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // phase 3: columns
-    {
-        constexpr int NY = TH / 4;
-        const int x = tid & 63, yg = tid >> 6;
-        float v[NY + 2 * R];
-        const float *p = &s_mid[(yg * NY) * TW + x];
+        // phase 3: columns
+        {
+            constexpr int NY = TH / 4;
+            const int x = tid & 63, yg = tid >> 6;
+            float v[NY + 2 * R];
+            const float *p = &s_mid[(yg * NY) * TW + x];
 #pragma unroll
-        for (int j = 0; j < NY + 2 * R; ++j) v[j] = p[j * TW];
-        float o[NY];
+            for (int j = 0; j < NY + 2 * R; ++j) v[j] = p[j * TW];
+            float o[NY];
 #pragma unroll
-        for (int i = 0; i < NY; ++i) o[i] = 0.f;
+            for (int i = 0; i < NY; ++i) o[i] = 0.f;
 #pragma unroll
-        for (int k = -R; k <= R; ++k) {
+            for (int k = -R; k <= R; ++k) {
 #pragma unroll
-            for (int i = 0; i < NY; ++i) o[i] = fma32(v[i + R + k], w[R - k], o[i]);
-        }
-        const int gx = x0 + x;
-        if (gx < width) {
+                for (int i = 0; i < NY; ++i) o[i] = fma32(v[i + R + k], w[R - k], o[i]);
+            }
+            const int gx = x0 + x;
+            if (gx < width) {
 #pragma unroll
-            for (int i = 0; i < NY; ++i) {
-                const int yy = yg * NY + i;
-                const int gy = y0 + yy;
-                if (gy < height) {
-                    result[(size_t)gy * width + gx] = o[i];
-                    if (WRITE_DOG) dog[(size_t)gy * width + gx] = o[i] - s_in[(yy + R) * IN_P + x + RA];
+                for (int i = 0; i < NY; ++i) {
+                    const int yy = yg * NY + i;
+                    const int gy = y0 + yy;
+                    if (gy < height) {
+                        result[(size_t)gy * width + gx] = o[i];
+                        const float *cin = &s_in[(yy + R) * IN_P + x + RA];
+                        if (WRITE_DOG) dog[(size_t)gy * width + gx] = o[i] - cin[0];
+                        if (WRITE_GRAD) {        // gradient of the INPUT level: its tile (+halo) is already in LDS
+                            float g = 0.f, r = 0.f;
+                            if (gx >= 1 && gx < width - 1 && gy >= 1 && gy < height - 1) {
+                                const float dx = cin[1] - cin[-1], dy = cin[IN_P] - cin[-IN_P];
+                                g = (float)(0.5 * (double)__builtin_sqrtf(fma32(dx, dx, dy * dy)));
+                                if (g != 0.0f)
+                                    r = nmfp::mod_2pi_f((float)((double)nmfp::atan2f_spec(dy, dx) + nmfp::TWO_PI_D));
+                            }
+                            grad[(size_t)gy * width + gx] = make_float2(g, r);
+                        }
+                    }
                 }
             }
         }
+        __syncthreads();                              // s_in / s_mid are rewritten by the next tile
     }
 }
 
@@ -175,45 +205,62 @@ __global__ __launch_bounds__(256) void conv_cols_generic(float *__restrict__ out
 }
 
 template <int R, bool VEC>
-static int launch_conv_rv(float *result, const float *image, float *buffer, float *dog, int width, int height,
-                          const float *taps, hipStream_t stream)
+static int launch_conv_rv(float *result, const float *image, float *buffer, float *dog, float *grad, int width,
+                          int height, const float *taps, hipStream_t stream)
 {
     constexpr int TH = 32;
-    dim3 grid(nm_divup(width, 64), nm_divup(height, TH));
-    if (buffer && dog)
-        hipLaunchKernelGGL((conv_sep_kernel<R, TH, true, true, VEC>), grid, dim3(256), 0, stream, result, image, buffer, dog, width, height, taps);
-    else if (buffer)
-        hipLaunchKernelGGL((conv_sep_kernel<R, TH, true, false, VEC>), grid, dim3(256), 0, stream, result, image, buffer, dog, width, height, taps);
-    else if (dog)
-        hipLaunchKernelGGL((conv_sep_kernel<R, TH, false, true, VEC>), grid, dim3(256), 0, stream, result, image, buffer, dog, width, height, taps);
-    else
-        hipLaunchKernelGGL((conv_sep_kernel<R, TH, false, false, VEC>), grid, dim3(256), 0, stream, result, image, buffer, dog, width, height, taps);
+    const int tiles_x = nm_divup(width, 64), tiles_y = nm_divup(height, TH);
+    const int ntiles = tiles_x * tiles_y;
+    // one tile per workgroup up to the chip's residency; grid is a multiple of 8 (XCDs). (Measured on MI355X: more
+    // tiles per workgroup with register prefetch is slower than more resident workgroups.)
+    static int tpb = 0;
+    if (tpb == 0) { const char *e = getenv("NM_CONV_TPB"); tpb = e ? atoi(e) : 1; if (tpb < 1) tpb = 1; }
+    int blocks = (ntiles >= 256 * tpb) ? (ntiles + tpb - 1) / tpb : ntiles;
+    blocks = ((blocks + 7) / 8) * 8;
+    dim3 grid(blocks);
+    float2 *g2 = reinterpret_cast<float2 *>(grad);
+#define NM_CONV_LAUNCH(BUF, DOG, GRAD)                                                                              \
+    hipLaunchKernelGGL((conv_sep_kernel<R, TH, BUF, DOG, GRAD, VEC>), grid, dim3(256), 0, stream, result, image,    \
+                       buffer, dog, g2, width, height, taps, tiles_x, ntiles)
+    if (buffer) {
+        if (dog || grad) return (int)hipErrorInvalidValue;      // the API path never asks for the fused outputs
+        NM_CONV_LAUNCH(true, false, false);
+    } else if (dog && grad) {
+        NM_CONV_LAUNCH(false, true, true);
+    } else if (dog) {
+        NM_CONV_LAUNCH(false, true, false);
+    } else if (grad) {
+        return (int)hipErrorInvalidValue;
+    } else {
+        NM_CONV_LAUNCH(false, false, false);
+    }
+#undef NM_CONV_LAUNCH
     NM_LAUNCH_CHECK();
     return 0;
 }
 
 template <int R>
-static int launch_conv_r(float *result, const float *image, float *buffer, float *dog, int width, int height,
-                         const float *taps, hipStream_t stream)
+static int launch_conv_r(float *result, const float *image, float *buffer, float *dog, float *grad, int width,
+                         int height, const float *taps, hipStream_t stream)
 {
     const bool vec = (width % 4 == 0) && ((reinterpret_cast<uintptr_t>(image) & 15) == 0);
-    return vec ? launch_conv_rv<R, true>(result, image, buffer, dog, width, height, taps, stream)
-               : launch_conv_rv<R, false>(result, image, buffer, dog, width, height, taps, stream);
+    return vec ? launch_conv_rv<R, true>(result, image, buffer, dog, grad, width, height, taps, stream)
+               : launch_conv_rv<R, false>(result, image, buffer, dog, grad, width, height, taps, stream);
 }
 
-int nm_launch_convolve(float *result, const float *image, float *buffer, float *dog, int width, int height,
-                       const float *taps, int radius, hipStream_t stream)
+int nm_launch_convolve(float *result, const float *image, float *buffer, float *dog, float *grad, int width,
+                       int height, const float *taps, int radius, hipStream_t stream)
 {
     if (width <= 0 || height <= 0) return 0;
     if (radius < 0) return (int)hipErrorInvalidValue;
     switch (radius) {
-        case 5: return launch_conv_r<5>(result, image, buffer, dog, width, height, taps, stream);
-        case 7: return launch_conv_r<7>(result, image, buffer, dog, width, height, taps, stream);
-        case 8: return launch_conv_r<8>(result, image, buffer, dog, width, height, taps, stream);
-        case 10: return launch_conv_r<10>(result, image, buffer, dog, width, height, taps, stream);
-        case 12: return launch_conv_r<12>(result, image, buffer, dog, width, height, taps, stream);
-        case 13: return launch_conv_r<13>(result, image, buffer, dog, width, height, taps, stream);
-        case 16: return launch_conv_r<16>(result, image, buffer, dog, width, height, taps, stream);
+        case 5: return launch_conv_r<5>(result, image, buffer, dog, grad, width, height, taps, stream);
+        case 7: return launch_conv_r<7>(result, image, buffer, dog, grad, width, height, taps, stream);
+        case 8: return launch_conv_r<8>(result, image, buffer, dog, grad, width, height, taps, stream);
+        case 10: return launch_conv_r<10>(result, image, buffer, dog, grad, width, height, taps, stream);
+        case 12: return launch_conv_r<12>(result, image, buffer, dog, grad, width, height, taps, stream);
+        case 13: return launch_conv_r<13>(result, image, buffer, dog, grad, width, height, taps, stream);
+        case 16: return launch_conv_r<16>(result, image, buffer, dog, grad, width, height, taps, stream);
         default: break;
     }
     // generic radius: the row pass needs a real intermediate. Without a caller buffer there is none to use.
@@ -223,6 +270,11 @@ int nm_launch_convolve(float *result, const float *image, float *buffer, float *
     NM_LAUNCH_CHECK();
     hipLaunchKernelGGL(conv_cols_generic, grid, dim3(256), 0, stream, result, buffer, dog, image, width, height, taps, radius);
     NM_LAUNCH_CHECK();
+    if (grad) {
+        NmGradBatch b{};
+        b.src[0] = image; b.dst[0] = grad; b.n = 1;
+        return nm_launch_gradient_batch(b, width, height, stream);
+    }
     return 0;
 }
 
@@ -283,7 +335,7 @@ int nm_convolve_f32(float *result, const float *image, float *buffer, int width,
                     int kernel_radius, void *stream)
 {
     if (!result || !image || !buffer || !kernel) return (int)hipErrorInvalidValue;
-    return nm_launch_convolve(result, image, buffer, nullptr, width, height, kernel, kernel_radius, nm_stream(stream));
+    return nm_launch_convolve(result, image, buffer, nullptr, nullptr, width, height, kernel, kernel_radius, nm_stream(stream));
 }
 
 int nm_downsample2_f32(float *result, int rw, int rh, const float *source, int sw, int sh, void *stream)

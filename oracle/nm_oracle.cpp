@@ -296,10 +296,11 @@ NMO_API int nmo_compact_keypoints(const float *dense, int num_pixels, float *out
 
 /* ---------------------------------------------------------------------------------------------------------- */
 /* orientations -- kernels/orientation.cu:11-129 (semantics), :132-216 (intent of the racy parts), Q10/Q11.
- * FIXED ORDER: histogram votes are summed per bin in raster order of the clipped window (ys outer, xs inner),
- * which is the order of the reference's own one-thread kernel (:165-176). Smoothing is the race-free circular
- * 3-tap mean of :181-192. `result` is float2 per keypoint and must be pre-filled with (-1,-1) by the caller
- * (pyramidata.cu:90).                                                                                       */
+ * FIXED ORDER (the reference's shared-memory atomicAdd order is undefined): the clipped window (at most 21 x 21)
+ * is cut into 63 strips: strip p = rx + 21 * (ry / 7), rx = cx - xmin, ry = cy - ymin. Each strip sums its (at most
+ * 7) votes per bin in increasing cy; a bin is the sum of its 63 strip partials taken in increasing p, starting
+ * from the first. Smoothing is the race-free circular 3-tap mean of :181-192. `result` is float2 per keypoint and
+ * must be pre-filled with (-1,-1) by the caller (pyramidata.cu:90).                                           */
 NMO_API void nmo_detect_orientations(const float *key_pts, const float *grad, int num_pts, int ow, int oh,
                                      float gauss_factor, float xper, float *result)
 {
@@ -316,7 +317,8 @@ NMO_API void nmo_detect_orientations(const float *key_pts, const float *grad, in
         const long grad_index = ((long)kp[3] * oh + yi) * ow + xi; /* Q10: integer arithmetic */
         const float *g = grad + 2 * grad_index;
         float hist[NBINS];
-        for (int i = 0; i < NBINS; ++i) hist[i] = 0.f;
+        float part[63][NBINS];
+        for (int p = 0; p < 63; ++p) for (int i = 0; i < NBINS; ++i) part[p][i] = 0.f;
         const int xmin = std::max(-W, -xi), xmax = std::min(W, ow - 1 - xi);
         const int ymin = std::max(-W, -yi), ymax = std::min(W, oh - 1 - yi);
         const float denom = (2 * sigma_w) * sigma_w;
@@ -329,8 +331,13 @@ NMO_API void nmo_detect_orientations(const float *key_pts, const float *grad, in
                 const float *gp = g + 2 * ((long)cy * ow + cx);
                 const float q = (float)((double)(36.0f * gp[1]) / NMO_2PI_D);
                 const int bin = (int)std::floor(q);
-                hist[bin % NBINS] += gp[0] * wgt;
+                part[(cx - xmin) + 21 * ((cy - ymin) / 7)][bin % NBINS] += gp[0] * wgt;
             }
+        for (int i = 0; i < NBINS; ++i) {
+            float h = part[0][i];
+            for (int p = 1; p < 63; ++p) h += part[p][i];
+            hist[i] = h;
+        }
         for (int iter = 0; iter < 6; ++iter) {
             float prev = hist[NBINS - 1];
             const float first = hist[0];
