@@ -184,6 +184,13 @@ def main():
         p_ms = sum(pyr_ms) / len(pyr_ms)
         flops = 256.0 * nA * nB                         # 2*N*M*128
         pyr_bytes = 136.0 * W * H                       # octave 0, levels 1..5: 40 (Gaussian) + 60 (DoG) + 36 (gradients) B/px
+        traffic = {}
+        try:
+            traffic = json.load(open(os.path.join(_ROOT, "profiles", "pmc_traffic.json")))
+        except Exception:
+            pass
+        t_match = traffic.get("match_top2_kernel", {}).get("hbm_bytes_per_launch")
+        t_pyr = traffic.get("pyramid_o0", {}).get("hbm_bytes_per_sequence")
         out = {
             "metric": METRIC, "value": round(pairs_total / dt, 3), "unit": "frame-pairs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
@@ -195,12 +202,13 @@ def main():
             "descriptor_comparisons_per_s": round(cmp_all * args.steps / dt, 1),
             "roofline": {"kernel": "match_top2_kernel", "bound": "mfma", "achieved": round(flops / (m_ms * 1e-3) / 1e12, 3),
                          "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(flops / (m_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(flops / (m_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": t_match,
+                         "traffic_note": "HBM bytes per launch from the rocprofv3 PMC passes in profiles/ (not live)",
                          "avg_ms": round(m_ms, 4), "launch_shape": [nA, nB, 128]},
             "roofline_pyramid": {"kernel": "octave-0 pyramid sequence (5x conv_sep_kernel: Gaussian+DoG+gradient fused)", "bound": "hbm",
                                  "achieved": round(pyr_bytes / (p_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": round(pyr_bytes / (p_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                 "traffic": None, "avg_ms": round(p_ms, 4)},
+                                 "traffic": t_pyr, "algorithmic_bytes": pyr_bytes, "avg_ms": round(p_ms, 4)},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
