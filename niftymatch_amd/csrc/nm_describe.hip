@@ -65,7 +65,7 @@ __device__ __forceinline__ int orient_wave(const float4 kp, const float2 *__rest
         const float r2 = fma32(dx, dx, dy * dy);
         if (col_ok && cy <= ymax && (double)r2 < r2lim) {
             const float wgt = nmfp::expf_spec(r2 / denom);
-            const float q = (float)((double)(36.0f * gv[j].y) / nmfp::TWO_PI_D);
+            const float q = nmfp::div_to_f32((double)(36.0f * gv[j].y), nmfp::TWO_PI_D, nmfp::INV_TWO_PI_D);
             const int bin = ((int)__builtin_floorf(q)) % 36;
             mine[bin * ORI_PITCH] += gv[j].x * wgt;   // lane-private word: plain read-add-write, program order
         }
@@ -124,7 +124,7 @@ __device__ __forceinline__ void describe_wave(const float4 kp, const float angle
     if (lane == 0) { *xp = kp.x; *yp = kp.y; }
     const float2 *gptr = grad + (((long)si * oh + yi) * (long)ow + xi);
     const double st0 = (double)nmfp::sinf_spec(angle0), ct0 = (double)nmfp::cosf_spec(angle0);
-    const double dSBP = (double)SBP;
+    const double dSBP = (double)SBP, rSBP = 1.0 / dSBP;
     const int tx = lane & 15, tyg = lane >> 4;
 
     {   // zero the wave's partial histograms with 16-byte stores
@@ -156,9 +156,9 @@ __device__ __forceinline__ void describe_wave(const float4 kp, const float angle
             const float mod = inwin ? gq.x : 0.f, ang = gq.y;
             const float theta = nmfp::mod_2pi_f(ang - angle0);
             const float dx = (float)(xi + cx) - x, dy = (float)(yi + cy) - y;
-            const float nx = (float)(fma64(ct0, (double)dx, st0 * (double)dy) / dSBP);
-            const float ny = (float)(fma64(-st0, (double)dx, ct0 * (double)dy) / dSBP);
-            const float nt = (float)((double)(8.0f * theta) / nmfp::TWO_PI_D);
+            const float nx = nmfp::div_to_f32(fma64(ct0, (double)dx, st0 * (double)dy), dSBP, rSBP);
+            const float ny = nmfp::div_to_f32(fma64(-st0, (double)dx, ct0 * (double)dy), dSBP, rSBP);
+            const float nt = nmfp::div_to_f32((double)(8.0f * theta), nmfp::TWO_PI_D, nmfp::INV_TWO_PI_D);
             const float win = (float)nmfp::exp_spec((double)fma32(nx, nx, ny * ny) / 8.0);
             const int binx = (int)__builtin_floor((double)nx - 0.5);
             const int biny = (int)__builtin_floor((double)ny - 0.5);

@@ -21,6 +21,21 @@ __device__ __forceinline__ float pow2i_f(int n) { return __uint_as_float((uint32
 __device__ __forceinline__ double pow2i_d(int n) { return __longlong_as_double((long long)((uint64_t)(n + 1023) << 52)); }
 
 constexpr double TWO_PI_D = 6.283185307179586476925286766559;
+constexpr double INV_TWO_PI_D = 1.0 / 6.283185307179586476925286766559;    // RN64(1 / TWO_PI_D)
+
+// (float)(a / b) without the fp64 divide, bit-identical to the plain expression. r must be RN64(1/b).
+// y = a*r lies within 2.5 double ulps of RN64(a/b); the two narrow to the same float unless a float rounding boundary
+// (low 29 mantissa bits = 0x10000000) sits within a few double ulps of y -- then (p ~ 2^-24), and for results too small
+// to be normal floats, the exact quotient is computed.
+__device__ __forceinline__ float div_to_f32(double a, double b, double r)
+{
+    const double y = a * r;
+    const unsigned long long u = (unsigned long long)__double_as_longlong(y);
+    const uint32_t lo = (uint32_t)u & 0x1FFFFFFFu;
+    const uint32_t ex = (uint32_t)(u >> 52) & 0x7FFu;
+    if (__builtin_expect(((lo - 0x0FFFFFF0u) <= 0x20u) || (ex < 1023u - 120u && y != 0.0), 0)) return (float)(a / b);
+    return (float)y;
+}
 constexpr float TWO_PI_F = (float)(2 * 3.14159265358979323846);
 
 // atan(ay/ax), ax > 0, ay >= 0

@@ -23,7 +23,8 @@ def _run_arena(nm, cuda, frame, capacity):
     return out
 
 
-@pytest.mark.parametrize("wh,cap", [((128, 96), 2048), ((640, 480), 16384), ((1920, 1080), 16384)])
+@pytest.mark.parametrize("wh,cap", [((128, 96), 2048), ((250, 187), 4096), ((37, 41), 256), ((640, 480), 16384),
+                                    ((1920, 1080), 16384)])
 def test_frame_driver_matches_oracle(nm, oracle, cuda, wh, cap):
     w, h = wh
     frame = H.blurred_frame(0, w, h)

@@ -21,7 +21,7 @@ def _eq(got, ref, what):
         what, (~same).sum(), same.size, np.nanmax(np.abs(got.astype(np.float64) - ref.astype(np.float64))))
 
 
-@pytest.mark.parametrize("wh", [(200, 150), (640, 480), (60, 33)])
+@pytest.mark.parametrize("wh", [(200, 150), (640, 480), (60, 33), (135, 67), (61, 45), (3, 2)])
 def test_convolve_all_sift_kernels(nm, oracle, cuda, wh):
     w, h = wh
     img = H.synth.noise_frame(7, w, h)
