@@ -38,14 +38,14 @@ __device__ __forceinline__ float div_to_f32(double a, double b, double r)
 }
 constexpr float TWO_PI_F = (float)(2 * 3.14159265358979323846);
 
-// atan(ay/ax), ax > 0, ay >= 0
+// atan(ay/ax), ax > 0, ay >= 0: one IEEE division (range chosen by products, see oracle/nmo_math.h)
 __device__ __forceinline__ float atanf_q1(float ay, float ax)
 {
-    const float t = ay / ax;
-    float hi, lo, z;
-    if (t > 2.414213562373095f)       { hi = 1.57079637050628662109375f;  lo = -4.37113900018624283e-8f; z = -(ax / ay); }
-    else if (t > 0.4142135623730950f) { hi = 0.785398185253143310546875f; lo = -2.18556950009312142e-8f; z = (ay - ax) / (ay + ax); }
-    else                              { hi = 0.0f; lo = 0.0f; z = t; }
+    float hi, lo, num, den;
+    if (ay > 2.414213562373095f * ax)       { hi = 1.57079637050628662109375f;  lo = -4.37113900018624283e-8f; num = -ax; den = ay; }
+    else if (ay > 0.4142135623730950f * ax) { hi = 0.785398185253143310546875f; lo = -2.18556950009312142e-8f; num = ay - ax; den = ay + ax; }
+    else                                    { hi = 0.0f; lo = 0.0f; num = ay; den = ax; }
+    const float z = num / den;
     const float zz = z * z;
     float p = fma32(-0.06459416449069977f, zz, 0.10746313631534576f);
     p = fma32(p, zz, -0.14264234900474548f);

@@ -151,7 +151,7 @@ float *nm_sift_arena_level(nm_sift_arena *a, int l) { return (a && l >= 0 && l <
 float *nm_sift_arena_dog(nm_sift_arena *a, int d) { return (a && d >= 0 && d < 5) ? a->dog[d] : nullptr; }
 float *nm_sift_arena_grad(nm_sift_arena *a) { return a ? a->grad[0] : nullptr; }
 
-static int octave_pyramid(nm_sift_arena *a, int o, int ow, int oh, hipStream_t st)
+static int octave_pyramid(nm_sift_arena *a, int o, int ow, int oh, bool store_top, hipStream_t st)
 {
     if (o == 0) nm_prof_begin(NM_PROF_PYRAMID_O0, st);
     const size_t plane = (size_t)ow * oh;
@@ -160,7 +160,8 @@ static int octave_pyramid(nm_sift_arena *a, int o, int ow, int oh, hipStream_t s
         // the launch that blurs level i-1 into level i also emits DoG i-1 and, for i-1 in 1..3, the gradient plane
         // i-2 of level i-1 (compute_gradients: level l from octave[l+1], sift/siftfunctions.cu:53-63)
         float *grad = (i >= 2 && i <= 4) ? a->grad[o] + 2 * (size_t)(i - 2) * plane : nullptr;
-        rc = nm_launch_convolve(a->level[i], a->level[i - 1], nullptr, a->dog[i - 1], grad, ow, oh, a->taps[i - 1],
+        // level 5 is only ever read through DoG 4: its plane is not stored
+        rc = nm_launch_convolve((i < 5 || store_top) ? a->level[i] : nullptr, a->level[i - 1], nullptr, a->dog[i - 1], grad, ow, oh, a->taps[i - 1],
                                 a->radii[i - 1], st);
     }
     if (o == 0) nm_prof_end(NM_PROF_PYRAMID_O0, st);
@@ -170,7 +171,7 @@ static int octave_pyramid(nm_sift_arena *a, int o, int ow, int oh, hipStream_t s
 int nm_sift_octave_pyramid(nm_sift_arena *a, int ow, int oh, void *stream)
 {
     if (!a || ow <= 0 || oh <= 0 || (size_t)ow * oh > a->npix) return (int)hipErrorInvalidValue;
-    return octave_pyramid(a, 0, ow, oh, nm_stream(stream));
+    return octave_pyramid(a, 0, ow, oh, true, nm_stream(stream));
 }
 
 int nm_sift_detect_describe(nm_sift_arena *a, const float *gray, float *desc, float *x, float *y, float *kpts,
@@ -195,7 +196,7 @@ int nm_sift_detect_describe(nm_sift_arena *a, const float *gray, float *desc, fl
             rc = nm_downsample2_f32(a->level[0], ow, oh, a->level[3], a->width >> (o - 1), a->height >> (o - 1), st);
             if (rc) return rc;
         }
-        rc = octave_pyramid(a, o, ow, oh, st);
+        rc = octave_pyramid(a, o, ow, oh, false, st);
         if (rc) return rc;
 
         const int nseg = nm_divup(ow, 256);

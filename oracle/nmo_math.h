@@ -35,15 +35,16 @@ static inline double nmo_pow2i_d(int n)           /* exact 2^n, n in [-1022,1023
     double d; std::memcpy(&d, &bits, 8); return d;
 }
 
-/* atan(ay/ax) for ax > 0, ay >= 0 (Cephes atanf range reduction; the reduced argument is formed from ax, ay directly and
- * the pi/2, pi/4 offsets are added as hi+lo pairs to stay inside 2 ulp). */
+/* atan(ay/ax) for ax > 0, ay >= 0: Cephes atanf range reduction with ONE division. The range is chosen by products
+ * (ay > tan(3pi/8) ax, ay > tan(pi/8) ax), the reduced argument z = num/den is formed from ax, ay directly, and the
+ * pi/2, pi/4 offsets are added as hi+lo pairs to stay near 2 ulp. */
 static inline float nmo_atanf_q1(float ay, float ax)
 {
-    const float t = ay / ax;
-    float hi, lo, z;
-    if (t > 2.414213562373095f)      { hi = 1.57079637050628662109375f; lo = -4.37113900018624283e-8f; z = -(ax / ay); }
-    else if (t > 0.4142135623730950f){ hi = 0.785398185253143310546875f; lo = -2.18556950009312142e-8f; z = (ay - ax) / (ay + ax); }
-    else                             { hi = 0.0f; lo = 0.0f; z = t; }
+    float hi, lo, num, den;
+    if (ay > 2.414213562373095f * ax)      { hi = 1.57079637050628662109375f; lo = -4.37113900018624283e-8f; num = -ax; den = ay; }
+    else if (ay > 0.4142135623730950f * ax){ hi = 0.785398185253143310546875f; lo = -2.18556950009312142e-8f; num = ay - ax; den = ay + ax; }
+    else                                   { hi = 0.0f; lo = 0.0f; num = ay; den = ax; }
+    const float z = num / den;
     const float zz = z * z;
     float p = std::fmaf(-0.06459416449069977f, zz, 0.10746313631534576f);      /* degree-4 minimax in z^2 on */
     p = std::fmaf(p, zz, -0.14264234900474548f);                              /* [0, tan^2(pi/8)], fitted for */
