@@ -125,6 +125,7 @@ __device__ __forceinline__ void describe_wave(const float4 kp, const float angle
     const float2 *gptr = grad + (((long)si * oh + yi) * (long)ow + xi);
     const double st0 = (double)nmfp::sinf_spec(angle0), ct0 = (double)nmfp::cosf_spec(angle0);
     const double dSBP = (double)SBP, rSBP = 1.0 / dSBP;
+    const float fct = (float)ct0, fst = (float)st0, frs = 1.0f / SBP;
     const int tx = lane & 15, tyg = lane >> 4;
 
     {   // zero the wave's partial histograms with 16-byte stores
@@ -152,6 +153,13 @@ __device__ __forceinline__ void describe_wave(const float4 kp, const float angle
         for (int q = 0; q < 4; ++q) {
             const int cx = tx + xmin + 16 * c, cy = 4 * q + tyg + ymin + 16 * c;
             const bool inwin = (cx <= xmax && cy <= ymax);
+            {   // a sample votes only if |nx| < 2.5 and |ny| < 2.5 (bins -2..1 in x and y). Skip the whole 4 x 16 pass
+                // when no lane can: the skipped votes would all have been exact +0 no-ops. fp32 estimate, 0.01 margin.
+                const float fdx = (float)(xi + cx) - x, fdy = (float)(yi + cy) - y;
+                const float enx = (fct * fdx + fst * fdy) * frs, eny = (fct * fdy - fst * fdx) * frs;
+                const bool maybe = inwin && __builtin_fabsf(enx) < 2.51f && __builtin_fabsf(eny) < 2.51f;
+                if (!__any(maybe)) continue;
+            }
             const float2 gq = cur[q];
             const float mod = inwin ? gq.x : 0.f, ang = gq.y;
             const float theta = nmfp::mod_2pi_f(ang - angle0);
@@ -194,6 +202,10 @@ __device__ __forceinline__ void describe_wave(const float4 kp, const float angle
 #pragma unroll
                     for (int j = 0; j < 8; ++j) mine[loc[j]] = o[j] + wt[j];
                 }
+                // The four groups are mutually exclusive per THREAD, so the compiler may merge or reorder them; their
+                // order only matters across lanes (same word, different rows). A compiler-level memory fence between
+                // the groups pins the program order that the in-order LDS then executes.
+                asm volatile("" ::: "memory");
             }
         }
 #pragma unroll
