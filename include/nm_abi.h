@@ -134,6 +134,27 @@ NM_API int nm_sift_match_shard_f32(const float *A, int nA, const float *B_shard,
 NM_API int nm_sift_match_merge_f32(const float *min1, const int *idx1, const float *min2, int n_shards, int nA,
                                    int *result, float ambiguity, void *stream);
 
+/* ---- "next" rows of SURVEY.md 8(f): the element-wise stages either side of the path ---- */
+/* cuda_grayscale<float> (kernels/bgra_2_gray.h:14-18, bgra_2_gray.cu:9-31): 0.07 B + 0.72 G + 0.21 R. bgra = uchar4. */
+NM_API int nm_grayscale_f32(const unsigned char *bgra, float *output, int width, int height, void *stream);
+/* cuda_extract_channel<float> (bgra_2_gray.cu:36-62): channel 0..3 = B, G, R, A. */
+NM_API int nm_extract_channel_f32(const unsigned char *bgra, float *output, int width, int height, int channel,
+                                  void *stream);
+/* cuda_put_channel<float> (bgra_2_gray.cu:65-92): channel 3 writes 255, as the reference does. */
+NM_API int nm_put_channel_f32(unsigned char *bgra, const float *input, int width, int height, int channel, void *stream);
+/* cuda_set_alpha_to_const (bgra_2_gray.cu:95-112). */
+NM_API int nm_set_alpha_to_const(unsigned char *bgra, int width, int height, unsigned char val, void *stream);
+/* cuda_cast<float, unsigned char> (kernels/cast.h:17-22, cast.cu:8-39): saturates at max_val when max_val != 0. */
+NM_API int nm_cast_f32_u8(const float *src, size_t cols, size_t rows, unsigned char *dst, unsigned char max_val,
+                          void *stream);
+/* downsample_by_2<uchar4> (kernels/downsample.cu:32). */
+NM_API int nm_downsample2_u8x4(unsigned char *result, int result_width, int result_height, const unsigned char *source,
+                               int source_width, int source_height, void *stream);
+/* align_points (kernels/ransac.h:8-10, ransac.cu:29-59): gathers the matched coordinates; unmatched rows get -1. */
+NM_API int nm_align_points(const float *src_x, const float *src_y, const float *dst_x, const float *dst_y,
+                           float *c_src_x, float *c_src_y, float *c_dst_x, float *c_dst_y, const int *matches,
+                           int num_pts, void *stream);
+
 /* ---- per-frame driver ---- */
 /* The per-octave client loop the reference leaves to its caller, run entirely on `stream` with no
  * host synchronisation and no allocation: Gaussian pyramid + DoG + gradients + extrema + ordered compaction +

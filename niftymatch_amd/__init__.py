@@ -41,6 +41,13 @@ _SIGNATURES = {
     "nm_sift_match_f32": (_I, [_P, _I, _P, _I, _P, _P, _F, _P, _P]),
     "nm_sift_match_shard_f32": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
     "nm_sift_match_merge_f32": (_I, [_P, _P, _P, _I, _I, _P, _F, _P]),
+    "nm_grayscale_f32": (_I, [_P, _P, _I, _I, _P]),
+    "nm_extract_channel_f32": (_I, [_P, _P, _I, _I, _I, _P]),
+    "nm_put_channel_f32": (_I, [_P, _P, _I, _I, _I, _P]),
+    "nm_set_alpha_to_const": (_I, [_P, _I, _I, C.c_ubyte, _P]),
+    "nm_cast_f32_u8": (_I, [_P, _SZ, _SZ, _P, C.c_ubyte, _P]),
+    "nm_downsample2_u8x4": (_I, [_P, _I, _I, _P, _I, _I, _P]),
+    "nm_align_points": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "nm_sift_arena_create": (_I, [_I, _I, _I, _P]),
     "nm_sift_arena_destroy": (None, [_P]),
     "nm_sift_arena_bytes": (_SZ, [_P]),
@@ -276,6 +283,67 @@ def sift_match_merge(m1_all, ix_all, m2_all, ambiguity=0.8, prior=None):
                                          _dev(m2_all, torch.float32), n_shards, nA, _dev(res), ambiguity, _stream()),
            "nm_sift_match_merge_f32")
     return res
+
+
+# ---- element-wise stages either side of the path --------------------------------------------
+def grayscale(bgra):
+    """uint8 (H, W, 4) BGRA -> float32 (H, W): 0.07 B + 0.72 G + 0.21 R."""
+    torch = _torch()
+    h, w, _ = bgra.shape
+    out = torch.empty((h, w), dtype=torch.float32, device=bgra.device)
+    _check(lib().nm_grayscale_f32(_dev(bgra, torch.uint8), _dev(out), w, h, _stream()), "nm_grayscale_f32")
+    return out
+
+
+def extract_channel(bgra, channel):
+    torch = _torch()
+    h, w, _ = bgra.shape
+    out = torch.full((h, w), -7.0, dtype=torch.float32, device=bgra.device)
+    _check(lib().nm_extract_channel_f32(_dev(bgra, torch.uint8), _dev(out), w, h, channel, _stream()),
+           "nm_extract_channel_f32")
+    return out
+
+
+def put_channel(bgra, plane, channel):
+    torch = _torch()
+    out = bgra.clone()
+    h, w, _ = out.shape
+    _check(lib().nm_put_channel_f32(_dev(out, torch.uint8), _dev(plane, torch.float32), w, h, channel, _stream()),
+           "nm_put_channel_f32")
+    return out
+
+
+def set_alpha(bgra, val=255):
+    torch = _torch()
+    out = bgra.clone()
+    h, w, _ = out.shape
+    _check(lib().nm_set_alpha_to_const(_dev(out, torch.uint8), w, h, val, _stream()), "nm_set_alpha_to_const")
+    return out
+
+
+def cast_f32_u8(src, max_val=0):
+    torch = _torch()
+    h, w = src.shape
+    out = torch.empty((h, w), dtype=torch.uint8, device=src.device)
+    _check(lib().nm_cast_f32_u8(_dev(src, torch.float32), w, h, _dev(out), max_val, _stream()), "nm_cast_f32_u8")
+    return out
+
+
+def downsample2_u8x4(src, rw, rh):
+    torch = _torch()
+    sh, sw, _ = src.shape
+    out = torch.empty((rh, rw, 4), dtype=torch.uint8, device=src.device)
+    _check(lib().nm_downsample2_u8x4(_dev(out), rw, rh, _dev(src, torch.uint8), sw, sh, _stream()), "nm_downsample2_u8x4")
+    return out
+
+
+def align_points(sx, sy, dx, dy, matches):
+    torch = _torch()
+    n = matches.shape[0]
+    outs = [torch.empty(n, dtype=torch.float32, device=matches.device) for _ in range(4)]
+    _check(lib().nm_align_points(_dev(sx), _dev(sy), _dev(dx), _dev(dy), *[_dev(o) for o in outs],
+                                 _dev(matches, torch.int32), n, _stream()), "nm_align_points")
+    return outs
 
 
 class SiftArena:

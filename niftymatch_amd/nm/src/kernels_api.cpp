@@ -2,6 +2,8 @@
 // Error convention: a failing launch prints file:line + the HIP error and exit()s, as helper_cuda.h's
 // getLastCudaError does in the reference (e.g. kernels/convolution.cu:152,158, kernels/match.cu:134).
 #include "../../../include/nm_abi.h"
+#include "../bgra_2_gray.h"
+#include "../cast.h"
 #include "../convolution.h"
 #include "../cudamath.h"
 #include "../descriptor.h"
@@ -10,6 +12,7 @@
 #include "../keypoint.h"
 #include "../match.h"
 #include "../orientation.h"
+#include "../ransac.h"
 #include "../transpose.h"
 
 template <typename TYPE>
@@ -110,3 +113,60 @@ void get_sift_matches(const TYPE *distance, const int rows, const int cols, cons
              "Set matches launch failed");
 }
 template void get_sift_matches<float>(const float *, const int, const int, const int, int *, float, hipStream_t);
+
+template <>
+void downsample_by_2<uchar4>(uchar4 *result, const int result_width, const int result_height, const uchar4 *source,
+                             const int source_width, const int source_height, hipStream_t stream)
+{
+    nm_check(nm_downsample2_u8x4(reinterpret_cast<unsigned char *>(result), result_width, result_height,
+                                 reinterpret_cast<const unsigned char *>(source), source_width, source_height, stream),
+             "Downsampling kernel failed");
+}
+
+template <typename OutputType>
+void cuda_grayscale(const uchar4 *bgra, OutputType *output, const int width, const int height, hipStream_t stream)
+{
+    nm_check(nm_grayscale_f32(reinterpret_cast<const unsigned char *>(bgra), output, width, height, stream),
+             "CUDA grayscale launch failed");
+}
+template void cuda_grayscale<float>(const uchar4 *, float *, const int, const int, hipStream_t);
+
+template <typename OutputType>
+void cuda_extract_channel(const uchar4 *bgra, OutputType *output, const int width, const int height, const int channel,
+                          hipStream_t stream)
+{
+    nm_check(nm_extract_channel_f32(reinterpret_cast<const unsigned char *>(bgra), output, width, height, channel, stream),
+             "CUDA extract channel launch failed");
+}
+template void cuda_extract_channel<float>(const uchar4 *, float *, const int, const int, const int, hipStream_t);
+
+template <typename InputType>
+void cuda_put_channel(uchar4 *bgra, const InputType *input, const int width, const int height, const int channel,
+                      hipStream_t stream)
+{
+    nm_check(nm_put_channel_f32(reinterpret_cast<unsigned char *>(bgra), input, width, height, channel, stream),
+             "CUDA put channel launch failed");
+}
+template void cuda_put_channel<float>(uchar4 *, const float *, const int, const int, const int, hipStream_t);
+
+void cuda_set_alpha_to_const(uchar4 *bgra, const int width, const int height, const unsigned char val, hipStream_t stream)
+{
+    nm_check(nm_set_alpha_to_const(reinterpret_cast<unsigned char *>(bgra), width, height, val, stream),
+             "CUDA set alpha launch failed");
+}
+
+template <typename FROM, typename TO>
+void cuda_cast(const FROM *src, const size_t cols, const size_t rows, TO *dst, TO max_val, hipStream_t stream)
+{
+    nm_check(nm_cast_f32_u8(src, cols, rows, dst, max_val, stream), "Cast kernel launch failed");
+}
+template void cuda_cast<float, unsigned char>(const float *, const size_t, const size_t, unsigned char *, unsigned char,
+                                              hipStream_t);
+
+void align_points(const float *src_x, const float *src_y, const float *dst_x, const float *dst_y, float *c_src_x,
+                  float *c_src_y, float *c_dst_x, float *c_dst_y, const int *matches, const int num_pts,
+                  hipStream_t stream)
+{
+    nm_check(nm_align_points(src_x, src_y, dst_x, dst_y, c_src_x, c_src_y, c_dst_x, c_dst_y, matches, num_pts, stream),
+             "Align points launch failed");
+}

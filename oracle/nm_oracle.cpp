@@ -596,6 +596,60 @@ NMO_API void nmo_octave_pyramid(const float *level0, int ow, int oh, int width, 
 }
 
 /* ---------------------------------------------------------------------------------------------------------- */
+/* "next" rows: element-wise stages either side of the path                                   */
+/* grayscale -- kernels/bgra_2_gray.cu:9-18: 0.07*B + 0.72*G + 0.21*R in double, narrowed; contraction explicit. */
+NMO_API void nmo_grayscale(const unsigned char *bgra, float *out, int width, int height)
+{
+    const size_t n = (size_t)width * height;
+    for (size_t i = 0; i < n; ++i) {
+        const double b = bgra[4 * i], g = bgra[4 * i + 1], r = bgra[4 * i + 2];
+        out[i] = (float)std::fma(0.21, r, std::fma(0.07, b, 0.72 * g));
+    }
+}
+/* extract_channel / put_channel / set_alpha_to_const -- bgra_2_gray.cu:36-113 */
+NMO_API void nmo_extract_channel(const unsigned char *bgra, float *out, int width, int height, int channel)
+{
+    if (channel < 0 || channel > 3) return;
+    const size_t n = (size_t)width * height;
+    for (size_t i = 0; i < n; ++i) out[i] = (float)bgra[4 * i + channel];
+}
+NMO_API void nmo_put_channel(unsigned char *bgra, const float *in, int width, int height, int channel)
+{
+    if (channel < 0 || channel > 3) return;
+    const size_t n = (size_t)width * height;
+    for (size_t i = 0; i < n; ++i) bgra[4 * i + channel] = (channel == 3) ? 255 : (unsigned char)in[i];
+}
+NMO_API void nmo_set_alpha(unsigned char *bgra, int width, int height, unsigned char val)
+{
+    const size_t n = (size_t)width * height;
+    for (size_t i = 0; i < n; ++i) bgra[4 * i + 3] = val;
+}
+/* cast<float, unsigned char> -- kernels/cast.cu:8-21 (inputs in [0, 256)) */
+NMO_API void nmo_cast_f32_u8(const float *src, size_t cols, size_t rows, unsigned char *dst, unsigned char max_val)
+{
+    for (size_t i = 0; i < cols * rows; ++i)
+        dst[i] = (max_val != 0 && src[i] >= (float)max_val) ? max_val : (unsigned char)src[i];
+}
+/* downsample_by_2<uchar4> -- kernels/downsample.cu:6-17,32 */
+NMO_API void nmo_downsample2_u8x4(unsigned char *result, int rw, int rh, const unsigned char *source, int sw, int sh)
+{
+    (void)sh;
+    for (int y = 0; y < rh; ++y)
+        for (int x = 0; x < rw; ++x)
+            std::memcpy(result + 4 * ((size_t)y * rw + x), source + 4 * ((size_t)(y * 2) * sw + (x * 2)), 4);
+}
+/* align_points -- kernels/ransac.cu:29-48 */
+NMO_API void nmo_align_points(const float *sx, const float *sy, const float *dx, const float *dy, float *csx, float *csy,
+                              float *cdx, float *cdy, const int *matches, int n)
+{
+    for (int i = 0; i < n; ++i) {
+        const int m = matches[i];
+        if (m != -1) { csx[i] = sx[i]; csy[i] = sy[i]; cdx[i] = dx[m]; cdy[i] = dy[m]; }
+        else { csx[i] = -1; csy[i] = -1; cdx[i] = -1; cdy[i] = -1; }
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------------------- */
 /* vectorised math entry points for tests/test_oracle_math.py                                                */
 NMO_API void nmo_vec_atan2f(const float *y, const float *x, float *o, int n) { for (int i = 0; i < n; ++i) o[i] = nmo_atan2f(y[i], x[i]); }
 NMO_API void nmo_vec_expf(const float *x, float *o, int n) { for (int i = 0; i < n; ++i) o[i] = nmo_expf(x[i]); }

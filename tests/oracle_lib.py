@@ -209,3 +209,63 @@ def vec(fn, *arrs, dtype=np.float32):
     out = np.empty_like(arrs[0])
     getattr(lib(), "nmo_vec_" + fn)(*[_fp(a) for a in arrs], _fp(out), C.c_int(arrs[0].size))
     return out
+
+
+# ---- "next" rows: element-wise image stages ----------------------------------------------------------------------
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def grayscale(bgra):
+    bgra = _u8(bgra)
+    h, w, _ = bgra.shape
+    out = np.empty((h, w), np.float32)
+    lib().nmo_grayscale(_fp(bgra), _fp(out), C.c_int(w), C.c_int(h))
+    return out
+
+
+def extract_channel(bgra, channel):
+    bgra = _u8(bgra)
+    h, w, _ = bgra.shape
+    out = np.full((h, w), -7.0, np.float32)
+    lib().nmo_extract_channel(_fp(bgra), _fp(out), C.c_int(w), C.c_int(h), C.c_int(channel))
+    return out
+
+
+def put_channel(bgra, plane, channel):
+    out = _u8(bgra).copy()
+    h, w, _ = out.shape
+    lib().nmo_put_channel(_fp(out), _fp(_f32(plane)), C.c_int(w), C.c_int(h), C.c_int(channel))
+    return out
+
+
+def set_alpha(bgra, val):
+    out = _u8(bgra).copy()
+    h, w, _ = out.shape
+    lib().nmo_set_alpha(_fp(out), C.c_int(w), C.c_int(h), C.c_ubyte(val))
+    return out
+
+
+def cast_f32_u8(src, max_val=0):
+    src = _f32(src)
+    h, w = src.shape
+    out = np.empty((h, w), np.uint8)
+    lib().nmo_cast_f32_u8(_fp(src), C.c_size_t(w), C.c_size_t(h), _fp(out), C.c_ubyte(max_val))
+    return out
+
+
+def downsample2_u8x4(src, rw, rh):
+    src = _u8(src)
+    sh, sw, _ = src.shape
+    out = np.empty((rh, rw, 4), np.uint8)
+    lib().nmo_downsample2_u8x4(_fp(out), C.c_int(rw), C.c_int(rh), _fp(src), C.c_int(sw), C.c_int(sh))
+    return out
+
+
+def align_points(sx, sy, dx, dy, matches):
+    sx, sy, dx, dy = _f32(sx), _f32(sy), _f32(dx), _f32(dy)
+    matches = np.ascontiguousarray(matches, np.int32)
+    n = len(matches)
+    outs = [np.empty(n, np.float32) for _ in range(4)]
+    lib().nmo_align_points(_fp(sx), _fp(sy), _fp(dx), _fp(dy), *[_fp(o) for o in outs], _fp(matches), C.c_int(n))
+    return outs
