@@ -64,8 +64,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=16, help="frame pairs per GPU per step")
-    ap.add_argument("--streams", type=int, default=8)
+    ap.add_argument("--pairs", type=int, default=32, help="frame pairs per GPU per step")
+    ap.add_argument("--streams", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -83,73 +83,65 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     nm.lib()
 
-    P, S = args.pairs, max(1, min(args.streams, args.pairs))
+    P, S = args.pairs, max(1, min(args.streams, 2 * args.pairs))
     # distinct seeds per rank and pair: (2i, 2i+1) is a pair
     seeds = [2 * (rank * P + i) + k for i in range(P) for k in (0, 1)]
     frames = make_frames(nm, torch, dev, seeds)
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
-    arenas = [(nm.SiftArena(W, H, CAP, device=dev), nm.SiftArena(W, H, CAP, device=dev)) for _ in range(S)]
-    wss = [nm.MatchWorkspace(CAP, CAP, dev) for _ in range(S)]
-    results = [torch.full((CAP,), -1, dtype=torch.int32, device=dev) for _ in range(S)]
+    mstream = torch.cuda.Stream(device=dev)
+    # one arena per frame of the batch (0.4 GB each): nothing on the hot path is reused before it has been consumed
+    arenas = [nm.SiftArena(W, H, CAP, device=dev) for _ in range(2 * P)]
+    ws = nm.MatchWorkspace(CAP, CAP, dev)
+    results = [torch.full((CAP,), -1, dtype=torch.int32, device=dev) for _ in range(P)]
 
     # keypoint counts are data-dependent but deterministic: one untimed pass gives the host-side sizes of each pair
     counts = []
     for i in range(P):
-        a0, a1 = arenas[0]
-        a0.detect_describe(frames[2 * i]); a1.detect_describe(frames[2 * i + 1])
+        arenas[2 * i].detect_describe(frames[2 * i]); arenas[2 * i + 1].detect_describe(frames[2 * i + 1])
         torch.cuda.synchronize()
-        counts.append((int(a0.num_items.item()), int(a1.num_items.item())))
+        counts.append((int(arenas[2 * i].num_items.item()), int(arenas[2 * i + 1].num_items.item())))
 
-    ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(2)] for k in ("match", "pyr")}
-    for k in ev:
-        for e in ev[k]:
-            e.record()
+    def mk_events(n):
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for a, b in evs:
+            a.record(); b.record()
+        return evs
+    ev_match = mk_events(P)
+    ev_pyr = mk_events(1)
     torch.cuda.synchronize()
     match_ms, pyr_ms = [], []
-
-    # The probed pair (pair 0) has its own stream, arenas and workspace so that its two probed launches can be kept
-    # free of other streams' kernels: its first frame runs ahead of everything else (octave-0 pyramid probe) and its
-    # match runs after every other stream has drained (MFMA probe). Everything is inside the timed region.
-    pstream = torch.cuda.Stream(device=dev)
-    parena = (nm.SiftArena(W, H, CAP, device=dev), nm.SiftArena(W, H, CAP, device=dev))
-    pws = nm.MatchWorkspace(CAP, CAP, dev)
-    pres = torch.full((CAP,), -1, dtype=torch.int32, device=dev)
     done = [torch.cuda.Event() for _ in range(S)]
-    lead = torch.cuda.Event()
 
     def step(timed):
-        with torch.cuda.stream(pstream):
-            if timed:
-                nm.profile_events(nm.PROF_PYRAMID_O0, ev["pyr"][0], ev["pyr"][1])
-            parena[0].detect_describe(frames[0])
-            if timed:
-                nm.profile_events(nm.PROF_PYRAMID_O0, None, None)
-            lead.record(pstream)
-            parena[1].detect_describe(frames[1])
-        for s in range(S):
-            streams[s].wait_event(lead)
-        for i in range(1, P):
-            s = i % S
-            with torch.cuda.stream(streams[s]):
-                b0, b1 = arenas[s]
-                b0.detect_describe(frames[2 * i])
-                b1.detect_describe(frames[2 * i + 1])
-                nA, nB = counts[i]
-                nm.sift_match(b0.desc, b1.desc, 0.8, prior=results[s], workspace=wss[s], nA=nA, nB=nB)
+        """One batch. Detect+describe of the 2P frames is spread over S streams; the P fused matches then run back
+        to back on one stream (a match launch fills the chip by itself). The last frame runs after the others have
+        drained so that the octave-0 pyramid probe times that sequence alone; every match launch is event-timed."""
+        for f in range(0, 2 * P - 1):
+            with torch.cuda.stream(streams[f % S]):
+                arenas[f].detect_describe(frames[f])
         for s in range(S):
             done[s].record(streams[s])
-            pstream.wait_event(done[s])
-        with torch.cuda.stream(pstream):
-            nA, nB = counts[0]
+            mstream.wait_event(done[s])
+        with torch.cuda.stream(mstream):        # the last frame runs alone: its octave-0 pyramid sequence is the probe
             if timed:
-                nm.profile_events(nm.PROF_MATCH_TOP2, ev["match"][0], ev["match"][1])
-            nm.sift_match(parena[0].desc, parena[1].desc, 0.8, prior=pres, workspace=pws, nA=nA, nB=nB)
+                nm.profile_events(nm.PROF_PYRAMID_O0, ev_pyr[0][0], ev_pyr[0][1])
+            arenas[2 * P - 1].detect_describe(frames[2 * P - 1])
+            if timed:
+                nm.profile_events(nm.PROF_PYRAMID_O0, None, None)
+        with torch.cuda.stream(mstream):
+            for i in range(P):
+                nA, nB = counts[i]
+                if timed:
+                    nm.profile_events(nm.PROF_MATCH_TOP2, ev_match[i][0], ev_match[i][1])
+                nm.sift_match(arenas[2 * i].desc, arenas[2 * i + 1].desc, 0.8, prior=results[i], workspace=ws, nA=nA, nB=nB)
             if timed:
                 nm.profile_events(nm.PROF_MATCH_TOP2, None, None)
+        for s in range(S):                      # the next step's detects overwrite the arenas: wait for the matches
+            streams[s].wait_stream(mstream)
         if timed:
-            pstream.synchronize()
-            match_ms.append(ev["match"][0].elapsed_time(ev["match"][1]))
-            pyr_ms.append(ev["pyr"][0].elapsed_time(ev["pyr"][1]))
+            mstream.synchronize()
+            match_ms.extend(a.elapsed_time(b) for a, b in ev_match)
+            pyr_ms.append(ev_pyr[0][0].elapsed_time(ev_pyr[0][1]))
 
     def barrier():
         torch.cuda.synchronize()
@@ -180,9 +172,9 @@ def main():
     if rank == 0:
         pairs_total = P * world * args.steps
         nA, nB = counts[0]
-        m_ms = sum(match_ms) / len(match_ms)
+        m_ms = sum(match_ms) / len(match_ms)            # every match launch of the timed region
         p_ms = sum(pyr_ms) / len(pyr_ms)
-        flops = 256.0 * nA * nB                         # 2*N*M*128
+        flops = 256.0 * sum(a * b for a, b in counts) / len(counts)      # 2*N*M*128 per launch
         pyr_bytes = 136.0 * W * H                       # octave 0, levels 1..5: 40 (Gaussian) + 60 (DoG) + 36 (gradients) B/px
         traffic = {}
         try:
@@ -196,7 +188,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[2]: SIFT detect+describe x2 + fused BF L2 match per 1920x1080 pair",
-                       "pairs_per_gpu_per_step": P, "streams": S + 1, "keypoints_pair0": [nA, nB], "capacity": CAP,
+                       "pairs_per_gpu_per_step": P, "detect_streams": S, "keypoints_pair0": [nA, nB], "capacity": CAP,
                        "parallelism": "frame-pair sharding, %d rank(s), no data-path collective" % world},
             "keypoints_per_s": round(kp_all * args.steps / dt, 1),
             "descriptor_comparisons_per_s": round(cmp_all * args.steps / dt, 1),
@@ -204,7 +196,7 @@ def main():
                          "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(flops / (m_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": t_match,
                          "traffic_note": "HBM bytes per launch from the rocprofv3 PMC passes in profiles/ (not live)",
-                         "avg_ms": round(m_ms, 4), "launch_shape": [nA, nB, 128]},
+                         "avg_ms": round(m_ms, 4), "launches_timed": len(match_ms), "launch_shape": [nA, nB, 128]},
             "roofline_pyramid": {"kernel": "octave-0 pyramid sequence (5x conv_sep_kernel: Gaussian+DoG+gradient fused)", "bound": "hbm",
                                  "achieved": round(pyr_bytes / (p_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": round(pyr_bytes / (p_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
