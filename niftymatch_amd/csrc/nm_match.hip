@@ -11,8 +11,6 @@
 //                          the scan semantics of match.cu:91-116 (lowest index wins ties, min2 initial 2139095040.0f,
 //                          result untouched when min2 <= 0).
 // API building blocks (transpose / bf_distance / get_sift_matches) keep the reference's layouts and are exact.
-#include <cstdlib>
-
 #include "nm_common.hpp"
 #include "../../include/nm_abi.h"
 
@@ -41,10 +39,14 @@ static MatchPlan make_plan(int nA, int nB)
     return p;
 }
 
-__global__ __launch_bounds__(256) void norms_kernel(const float *__restrict__ X, int n, float *__restrict__ out)
+// ||x||^2 of every row of A (nA rows) and B (nB rows) in one launch.
+__global__ __launch_bounds__(256) void norms_kernel(const float *__restrict__ A, int nA, float *__restrict__ na,
+                                                   const float *__restrict__ B, int nB, float *__restrict__ nb)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    int i = blockIdx.x * 256 + threadIdx.x;
+    const float *X = A;
+    float *out = na;
+    if (i >= nA) { i -= nA; X = B; out = nb; if (i >= nB) return; }
     const float4 *row = reinterpret_cast<const float4 *>(X + (size_t)i * DIM);
     float acc = 0.f;
 #pragma unroll 8
@@ -72,7 +74,6 @@ __device__ __forceinline__ void top2_insert(Top2 &t, float d, int j)
 // through a double-buffered LDS image (row pitch KP). Dynamic LDS: 2 * TILE_C * KP floats.
 // MFMA orientation: rows (accumulator registers) = candidates, columns (lanes) = queries, so every lane scans its own
 // query's candidates in increasing index order and the running best/second-best never crosses lanes in the loop.
-template <int DBG>
 __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restrict__ A, int nA,
                                                            const float *__restrict__ B, int nB,
                                                            const float *__restrict__ na, const float *__restrict__ nb,
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
 
     for (int n = 0; n < ntiles; ++n) {
         float *buf = lds + (n & 1) * (TILE_C * KP);
-        if (DBG != 2) { if (n + 1 < ntiles) stage_load(n + 1); }
+        if (n + 1 < ntiles) stage_load(n + 1);
         const int jb = c0 + n * TILE_C;
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
@@ -168,7 +169,6 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
                 }
             }
             // running best / second best. Within a lane the candidate index increases with (half, g, e).
-            if (DBG == 1) { best.m1 = __builtin_fminf(best.m1, acc[0][0] + acc[1][5]); continue; }
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 float mn = __builtin_fminf(acc[g][0], acc[g][1]);
@@ -183,8 +183,8 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
                 }
             }
         }
-        if (DBG != 2) { if (n + 1 < ntiles) stage_write(lds + ((n + 1) & 1) * (TILE_C * KP)); }
-        if (DBG != 3) __syncthreads();
+        if (n + 1 < ntiles) stage_write(lds + ((n + 1) & 1) * (TILE_C * KP));
+        __syncthreads();
     }
 
     // merge the two lane halves (same query, disjoint candidates) and publish
@@ -202,21 +202,25 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
 
 __device__ __forceinline__ float exact_dist(const float4 *__restrict__ a, const float4 *__restrict__ b)
 {
+    float4 x[DIM / 4], y[DIM / 4];
+#pragma unroll
+    for (int k = 0; k < DIM / 4; ++k) { x[k] = a[k]; y[k] = b[k]; }     // all 64 loads in flight together
     float acc = 0.0f;
-#pragma unroll 8
+#pragma unroll
     for (int k = 0; k < DIM / 4; ++k) {
-        const float4 x = a[k], y = b[k];
         float t;
-        t = x.x - y.x; acc = __builtin_fmaf(t, t, acc);
-        t = x.y - y.y; acc = __builtin_fmaf(t, t, acc);
-        t = x.z - y.z; acc = __builtin_fmaf(t, t, acc);
-        t = x.w - y.w; acc = __builtin_fmaf(t, t, acc);
+        t = x[k].x - y[k].x; acc = __builtin_fmaf(t, t, acc);
+        t = x[k].y - y[k].y; acc = __builtin_fmaf(t, t, acc);
+        t = x[k].z - y[k].z; acc = __builtin_fmaf(t, t, acc);
+        t = x[k].w - y[k].w; acc = __builtin_fmaf(t, t, acc);
     }
     return acc;
 }
 
-// One thread per query: approximate top-4 of the 2*S partial candidates -> exact distances -> (min1, idx, min2).
-// mode 0: apply the ratio test and write result[i]; mode 1: emit the shard triple (min1, idx + index_offset, min2).
+// Four lanes per query. Each lane scans a quarter of the query's 2*S partial candidates, the quad merges them into the
+// 4 best by (approximate distance, index), every lane recomputes ONE of them EXACTLY (sum_k fma(t,t,acc), k ascending:
+// 32 float4 loads in flight per lane), and lane 0 of the quad applies the scan semantics of match.cu:91-116.
+// mode 0: ratio test -> result[i]; mode 1: emit the shard triple (min1, idx + index_offset, min2).
 __global__ __launch_bounds__(256) void match_finalize_kernel(const float *__restrict__ A, int nA,
                                                             const float *__restrict__ B, int nB, int S,
                                                             const float4 *__restrict__ partial, int mode,
@@ -224,35 +228,51 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(const float *__rest
                                                             float *__restrict__ min1_out, int *__restrict__ idx_out,
                                                             float *__restrict__ min2_out)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nA) return;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int i = t >> 2, sub = t & 3;
+    const bool live = i < nA;
+    const int iq = live ? i : nA - 1;
     float cd[4]; int ci[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { cd[k] = __builtin_inff(); ci[k] = -1; }
-    for (int s = 0; s < S; ++s) {
-        const float4 p = partial[(size_t)i * S + s];
-        const float dd[2] = {p.x, p.z};
-        const int jj[2] = {__float_as_int(p.y), __float_as_int(p.w)};
+    auto insert = [&](float d, int j) {
+        if (j < 0) return;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            float d = dd[c]; int j = jj[c];
-            if (j < 0) continue;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {            // sorted insertion by (approx distance, index)
-                const bool lt = (d < cd[k]) || (d == cd[k] && j < ci[k]);
-                if (lt) { const float td = cd[k]; const int tj = ci[k]; cd[k] = d; ci[k] = j; d = td; j = tj; }
-            }
+        for (int k = 0; k < 4; ++k) {                // sorted insertion by (approx distance, index)
+            const bool lt = (d < cd[k]) || (d == cd[k] && j < ci[k]);
+            if (lt) { const float td = cd[k]; const int tj = ci[k]; cd[k] = d; ci[k] = j; d = td; j = tj; }
         }
+    };
+    for (int s = sub; s < S; s += 4) {
+        const float4 p = partial[(size_t)iq * S + s];
+        insert(p.x, __float_as_int(p.y));
+        insert(p.z, __float_as_int(p.w));
     }
-    const float4 *a = reinterpret_cast<const float4 *>(A + (size_t)i * DIM);
+#pragma unroll
+    for (int m = 1; m <= 2; m <<= 1) {               // quad butterfly: afterwards all 4 lanes hold the same sorted top-4
+        float od[4]; int oi[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { od[k] = __shfl_xor(cd[k], m); oi[k] = __shfl_xor(ci[k], m); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) insert(od[k], oi[k]);
+    }
+    const int mine = (sub == 0) ? ci[0] : (sub == 1) ? ci[1] : (sub == 2) ? ci[2] : ci[3];
+    float d = 0.f;
+    if (mine >= 0)
+        d = exact_dist(reinterpret_cast<const float4 *>(A + (size_t)iq * DIM),
+                       reinterpret_cast<const float4 *>(B + (size_t)mine * DIM));
+    // gather the quad's exact distances into lane 0 of the quad, in candidate order
+    float ed[4]; int ei[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ed[k] = __shfl(d, ((threadIdx.x & 63) & ~3) + k); ei[k] = ci[k]; }
+    if (!live || sub != 0) return;
     float m1 = 0.f, m2 = MIN2_INIT; int idx = 0; bool have = false;
-#pragma unroll 1
+#pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (ci[k] < 0) continue;
-        const float d = exact_dist(a, reinterpret_cast<const float4 *>(B + (size_t)ci[k] * DIM));
-        if (!have) { m1 = d; idx = ci[k]; have = true; }
-        else if (d < m1 || (d == m1 && ci[k] < idx)) { m2 = m1; m1 = d; idx = ci[k]; }
-        else if (d < m2) m2 = d;
+        if (ei[k] < 0) continue;
+        if (!have) { m1 = ed[k]; idx = ei[k]; have = true; }
+        else if (ed[k] < m1 || (ed[k] == m1 && ei[k] < idx)) { m2 = m1; m1 = ed[k]; idx = ei[k]; }
+        else if (ed[k] < m2) m2 = ed[k];
     }
     if (!have) return;
     if (mode == 1) {
@@ -411,39 +431,21 @@ static int run_fused(const float *A, int nA, const float *B, int nB, int mode, i
     if (nA <= 0 || nB <= 0) return 0;
     const MatchPlan p = make_plan(nA, nB);
     MatchWs w = carve(workspace, nA, nB, p);
-    hipLaunchKernelGGL(norms_kernel, dim3(nm_divup(nA, 256)), dim3(256), 0, st, A, nA, w.na);
-    NM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(norms_kernel, dim3(nm_divup(nB, 256)), dim3(256), 0, st, B, nB, w.nb);
+    hipLaunchKernelGGL(norms_kernel, dim3(nm_divup(nA + nB, 256)), dim3(256), 0, st, A, nA, w.na, B, nB, w.nb);
     NM_LAUNCH_CHECK();
     const size_t lds_bytes = (size_t)2 * TILE_C * KP * sizeof(float);
     static bool attr_set = false;
-    static int dbg = 0;
     if (!attr_set) {
-        const char *e = getenv("NM_MATCH_DEBUG");
-        dbg = e ? atoi(e) : 0;
-        NM_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_kernel<0>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        NM_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_kernel<1>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        NM_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_kernel<2>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        NM_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_kernel<3>),
+        NM_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_set = true;
     }
     nm_prof_begin(NM_PROF_MATCH_TOP2, st);
-    if (dbg == 1)
-        hipLaunchKernelGGL(match_top2_kernel<1>, dim3(p.qblocks, p.S), dim3(512), lds_bytes, st, A, nA, B, nB, w.na, w.nb, p.chunk, p.S, w.partial);
-    else if (dbg == 2)
-        hipLaunchKernelGGL(match_top2_kernel<2>, dim3(p.qblocks, p.S), dim3(512), lds_bytes, st, A, nA, B, nB, w.na, w.nb, p.chunk, p.S, w.partial);
-    else if (dbg == 3)
-        hipLaunchKernelGGL(match_top2_kernel<3>, dim3(p.qblocks, p.S), dim3(512), lds_bytes, st, A, nA, B, nB, w.na, w.nb, p.chunk, p.S, w.partial);
-    else
-    hipLaunchKernelGGL(match_top2_kernel<0>, dim3(p.qblocks, p.S), dim3(512), lds_bytes, st, A, nA, B, nB, w.na, w.nb,
+    hipLaunchKernelGGL(match_top2_kernel, dim3(p.qblocks, p.S), dim3(512), lds_bytes, st, A, nA, B, nB, w.na, w.nb,
                        p.chunk, p.S, w.partial);
     nm_prof_end(NM_PROF_MATCH_TOP2, st);
     NM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(match_finalize_kernel, dim3(nm_divup(nA, 256)), dim3(256), 0, st, A, nA, B, nB, p.S, w.partial,
+    hipLaunchKernelGGL(match_finalize_kernel, dim3(nm_divup(4 * nA, 256)), dim3(256), 0, st, A, nA, B, nB, p.S, w.partial,
                        mode, index_offset, ambiguity, result, min1, idx1, min2);
     NM_LAUNCH_CHECK();
     return 0;

@@ -128,3 +128,30 @@ def test_full_size_properties_12k(nm, cuda):
     assert torch.equal(res, res2)
     m1, ix, m2 = nm.sift_match_shard(A, B, 0)
     assert float(m1.abs().max()) == 0.0 and torch.equal(ix.long(), inv) and bool((m2 > 0).all())
+
+
+def test_config5_shard_scale_100k_by_12k5(nm, cuda):
+    """BASELINE config 5, one rank's share: 100 000 queries against a 12 500-row shard (3.2e11 flop). Properties:
+    every shard row planted into A is found at distance 0 with the right GLOBAL index; run-to-run identical."""
+    import torch
+    nA, nB, off = 100_000, 12_500, 37_500                   # rank 3 of 8
+    g = torch.Generator(device=cuda).manual_seed(1)
+    A = torch.rand((nA, 128), device=cuda, generator=g)
+    B = torch.rand((nB, 128), device=cuda, generator=g)
+    rows = torch.randperm(nA, device=cuda, generator=g)[:nB]
+    A[rows] = B                                             # query rows[j] is an exact copy of shard row j
+    ws = nm.MatchWorkspace(nA, nB, cuda)
+    m1, ix, m2 = nm.sift_match_shard(A, B, off, workspace=ws)
+    torch.cuda.synchronize()
+    assert float(m1[rows].abs().max()) == 0.0
+    assert torch.equal(ix[rows].long(), torch.arange(nB, device=cuda) + off)
+    assert bool((m2 > 0).all()) and bool((m1 <= m2).all()) and int(ix.min()) >= off and int(ix.max()) < off + nB
+    m1b, ixb, m2b = nm.sift_match_shard(A, B, off, workspace=ws)
+    assert torch.equal(m1, m1b) and torch.equal(ix, ixb) and torch.equal(m2, m2b)
+    # spot-check 64 random queries against a direct fp64 evaluation
+    q = torch.randint(0, nA, (64,), device=cuda, generator=g)
+    d = ((A[q].double()[:, None, :] - B.double()[None]) ** 2).sum(-1)
+    top = d.topk(2, dim=1, largest=False)
+    assert torch.equal(ix[q].long() - off, top.indices[:, 0])
+    assert torch.allclose(m1[q].double(), top.values[:, 0], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(m2[q].double(), top.values[:, 1], rtol=1e-5)
