@@ -26,15 +26,28 @@ constexpr float MIN2_INIT = 2139095040.0f;   // (float)0x7f800000, match.cu:91
 
 struct MatchPlan { int qblocks, S, chunk; };
 
+// Grid = qblocks x S workgroups, one resident per CU (LDS). S is chosen to maximise
+//   (fill of the last round of workgroups over the 256 CUs) x (tiles / (tiles + 0.6)),
+// the second factor being the per-workgroup prologue (staging 256 queries) expressed in 128-candidate tiles.
 static MatchPlan make_plan(int nA, int nB)
 {
     MatchPlan p;
+    const int n_cu = 256;
     p.qblocks = nm_divup(nA > 0 ? nA : 1, QB);
     const int tiles = nm_divup(nB > 0 ? nB : 1, TILE_C);
-    int S = nm_divup(768, p.qblocks);
-    if (S > tiles) S = tiles;
-    if (S < 1) S = 1;
-    p.chunk = nm_divup(nm_divup(nB > 0 ? nB : 1, S), TILE_C) * TILE_C;
+    double best = -1.0;
+    int bestS = 1;
+    for (int S = 1; S <= tiles && S <= 64; ++S) {
+        const int tpc = nm_divup(tiles, S);                    // tiles per chunk
+        const int Seff = nm_divup(tiles, tpc);
+        if (Seff != S) continue;
+        const long blocks = (long)p.qblocks * S;
+        const long rounds = (blocks + n_cu - 1) / n_cu;
+        const double fill = (double)blocks / (double)(rounds * n_cu);
+        const double score = fill * ((double)tpc / ((double)tpc + 0.6));
+        if (score > best + 1e-9) { best = score; bestS = S; }
+    }
+    p.chunk = nm_divup(tiles, bestS) * TILE_C;
     p.S = nm_divup(nB > 0 ? nB : 1, p.chunk);
     return p;
 }
