@@ -121,10 +121,13 @@ NM_API int nm_get_sift_matches_f32(const float *distance, int rows, int cols, in
  * A: nA x 128, B: nB x 128 row-major. Fused MFMA path; `distance` (nA x nB) is optional (NULL = do not
  * materialise; extension). result[i] in {-1, 0..nB-1}, left untouched when the second-best distance is <= 0
  * (match.cu:107-116). Match decisions are made on distances recomputed exactly in the reference's summation
- * order. workspace: nm_sift_match_workspace_bytes(nA, nB) bytes of device scratch.                            */
+ * order; rows whose best two cannot be proven from the MFMA pass are re-scanned exactly. workspace: nm_sift_match_workspace_bytes(nA, nB) bytes of device scratch.                            */
 NM_API size_t nm_sift_match_workspace_bytes(int nA, int nB);
 NM_API int nm_sift_match_f32(const float *A, int nA, const float *B, int nB, float *distance, int *result,
                              float ambiguity, void *workspace, void *stream);
+/* Diagnostics: number of query rows of the LAST nm_sift_match_f32 / _shard_f32 call on `workspace` (same nA, nB) that took
+ * the exact full-scan fallback because the MFMA candidate pass could not prove its top-2. Synchronises the stream. */
+NM_API int nm_sift_match_fallback_count(const void *workspace, int nA, int nB, int *host_count, void *stream);
 /* Multi-GPU building blocks (no reference counterpart: the reference is single-GPU). A shard call scans the local
  * rows [0,nB_shard) of B and emits, per query row, the exact (min1, index1 + index_offset, min2) of that shard
  * with the scan semantics of match.cu:91-105. The merge combines n_shards such triples per row, given shard-major

@@ -39,6 +39,7 @@ _SIGNATURES = {
     "nm_get_sift_matches_f32": (_I, [_P, _I, _I, _I, _P, _F, _P]),
     "nm_sift_match_workspace_bytes": (_SZ, [_I, _I]),
     "nm_sift_match_f32": (_I, [_P, _I, _P, _I, _P, _P, _F, _P, _P]),
+    "nm_sift_match_fallback_count": (_I, [_P, _I, _I, _P, _P]),
     "nm_sift_match_shard_f32": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
     "nm_sift_match_merge_f32": (_I, [_P, _P, _P, _I, _I, _P, _F, _P]),
     "nm_grayscale_f32": (_I, [_P, _P, _I, _I, _P]),
@@ -258,6 +259,14 @@ def sift_match(A, B, ambiguity=0.8, want_distance=False, prior=None, workspace=N
                                    _dev(D) if D is not None else None, _dev(res, torch.int32), ambiguity,
                                    _dev(ws.buf), _stream()), "nm_sift_match_f32")
     return res, D
+
+
+def match_fallback_count(workspace, nA, nB):
+    """Rows of the last match call on `workspace` (same sizes) that needed the exact full-scan fallback."""
+    n = C.c_int(0)
+    _check(lib().nm_sift_match_fallback_count(_dev(workspace.buf), nA, nB, C.byref(n), _stream()),
+           "nm_sift_match_fallback_count")
+    return n.value
 
 
 def sift_match_shard(A, B_shard, index_offset, workspace=None):

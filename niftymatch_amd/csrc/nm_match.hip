@@ -9,7 +9,9 @@
 //   3. match_finalize_kernel  per query: pick the 4 best partial candidates, recompute their distances EXACTLY in the
 //                          reference's order (sum_k fma(t,t,acc), t = a_k - b_k, k ascending: match.cu:36-42), then apply
 //                          the scan semantics of match.cu:91-116 (lowest index wins ties, min2 initial 2139095040.0f,
-//                          result untouched when min2 <= 0).
+//                          result untouched when min2 <= 0). Each chunk also reports the VALUE of its third best; when
+//                          anything not recomputed comes within the MFMA error margin of the exact min2, the query goes to
+//   4. match_fallback_kernel  which scans all candidates exactly (a fraction of a percent of the queries).
 // API building blocks (transpose / bf_distance / get_sift_matches) keep the reference's layouts and are exact.
 #include "nm_common.hpp"
 #include "../../include/nm_abi.h"
@@ -23,6 +25,7 @@ constexpr int KP = 132;            // LDS row pitch (floats): 128 data + norm sl
 constexpr int TILE_C = 128;        // candidates per LDS tile
 constexpr int QB = 256;            // queries per workgroup (32 per wave, fragments resident in VGPRs)
 constexpr float MIN2_INIT = 2139095040.0f;   // (float)0x7f800000, match.cu:91
+constexpr int MAX_CHUNKS = 64;     // upper bound of the candidate-chunk count S of any grid plan
 
 struct MatchPlan { int qblocks, S, chunk; };
 
@@ -37,7 +40,7 @@ static MatchPlan make_plan(int nA, int nB)
     const int tiles = nm_divup(nB > 0 ? nB : 1, TILE_C);
     double best = -1.0;
     int bestS = 1;
-    for (int S = 1; S <= tiles && S <= 64; ++S) {
+    for (int S = 1; S <= tiles && S <= MAX_CHUNKS; ++S) {
         const int tpc = nm_divup(tiles, S);                    // tiles per chunk
         const int Seff = nm_divup(tiles, tpc);
         if (Seff != S) continue;
@@ -71,10 +74,13 @@ __global__ __launch_bounds__(256) void norms_kernel(const float *__restrict__ A,
     out[i] = acc;
 }
 
-struct Top2 { float m1, m2; int i1, i2; };
+// running best / second best with indices + the VALUE of the third best (m3): the finalize pass uses m3 to prove that
+// no candidate dropped here could have beaten the exact second best (otherwise the query takes the exact fallback).
+struct Top2 { float m1, m2, m3; int i1, i2; };
 
 __device__ __forceinline__ void top2_insert(Top2 &t, float d, int j)
 {
+    t.m3 = __builtin_amdgcn_fmed3f(t.m2, t.m3, d);      // third smallest of {m1, m2, m3, d} (m2 <= m3)
     const bool lt1 = d < t.m1, lt2 = d < t.m2;
     t.m2 = lt1 ? t.m1 : (lt2 ? d : t.m2);
     t.i2 = lt1 ? t.i1 : (lt2 ? j : t.i2);
@@ -90,7 +96,8 @@ __device__ __forceinline__ void top2_insert(Top2 &t, float d, int j)
 __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restrict__ A, int nA,
                                                            const float *__restrict__ B, int nB,
                                                            const float *__restrict__ na, const float *__restrict__ nb,
-                                                           int chunk, int S, float4 *__restrict__ partial)
+                                                           int chunk, int S, float4 *__restrict__ partial,
+                                                           float *__restrict__ partial3)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
     __syncthreads();
 
     Top2 best;
-    best.m1 = best.m2 = __builtin_inff(); best.i1 = best.i2 = -1;
+    best.m1 = best.m2 = best.m3 = __builtin_inff(); best.i1 = best.i2 = -1;
 
     float4 st[8];
     float stn = 0.f;
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
                 float mn = __builtin_fminf(acc[g][0], acc[g][1]);
 #pragma unroll
                 for (int e = 2; e < 16; e += 2) mn = __builtin_fminf(mn, __builtin_fminf(acc[g][e], acc[g][e + 1]));
-                if (__any(mn < best.m2)) {
+                if (__any(mn < best.m3)) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int j = jb + half * 64 + 32 * g + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -203,13 +210,16 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
     // merge the two lane halves (same query, disjoint candidates) and publish
     {
         Top2 o;
-        o.m1 = __shfl_xor(best.m1, 32); o.m2 = __shfl_xor(best.m2, 32);
+        o.m1 = __shfl_xor(best.m1, 32); o.m2 = __shfl_xor(best.m2, 32); o.m3 = __shfl_xor(best.m3, 32);
         o.i1 = __shfl_xor(best.i1, 32); o.i2 = __shfl_xor(best.i2, 32);
         Top2 m = best;
         if (o.i1 >= 0) top2_insert(m, o.m1, o.i1);
         if (o.i2 >= 0) top2_insert(m, o.m2, o.i2);
-        if (h == 0 && qi < nA)
+        m.m3 = __builtin_fminf(m.m3, o.m3);             // o.m3 >= o.m2 >= the merged m2: only the third value can change
+        if (h == 0 && qi < nA) {
             partial[(size_t)qi * S + s] = make_float4(m.m1, __int_as_float(m.i1), m.m2, __int_as_float(m.i2));
+            partial3[(size_t)qi * S + s] = m.m3;
+        }
     }
 }
 
@@ -230,22 +240,41 @@ __device__ __forceinline__ float exact_dist(const float4 *__restrict__ a, const 
     return acc;
 }
 
+// Scan semantics of match.cu:91-116 on an exact (min1, idx, min2) triple. mode 0: ratio test -> result[i] (untouched when
+// min2 <= 0); mode 1: emit the shard triple with the global index.
+__device__ __forceinline__ void emit_match(int i, float m1, int idx, float m2, int mode, int index_offset, float ambiguity,
+                                           int *__restrict__ result, float *__restrict__ min1_out,
+                                           int *__restrict__ idx_out, float *__restrict__ min2_out)
+{
+    if (mode == 1) { min1_out[i] = m1; idx_out[i] = idx + index_offset; min2_out[i] = m2; return; }
+    if (m2 > 0) {
+        const float q = m1 / m2;
+        result[i] = (q < ambiguity) ? idx : -1;
+    }
+}
+
 // Four lanes per query. Each lane scans a quarter of the query's 2*S partial candidates, the quad merges them into the
 // 4 best by (approximate distance, index), every lane recomputes ONE of them EXACTLY (sum_k fma(t,t,acc), k ascending:
-// 32 float4 loads in flight per lane), and lane 0 of the quad applies the scan semantics of match.cu:91-116.
-// mode 0: ratio test -> result[i]; mode 1: emit the shard triple (min1, idx + index_offset, min2).
+// all loads in flight together), and lane 0 of the quad forms the exact (min1, idx, min2).
+// Proof obligation: every candidate NOT recomputed has an approximate distance >= rest (the minimum over the chunks'
+// third-best values and everything that dropped out of a top-4 list). If rest is not safely above the exact min2
+// (margin = bound on the MFMA formulation's error), the query is appended to the fallback list instead of being emitted.
 __global__ __launch_bounds__(256) void match_finalize_kernel(const float *__restrict__ A, int nA,
                                                             const float *__restrict__ B, int nB, int S,
-                                                            const float4 *__restrict__ partial, int mode,
-                                                            int index_offset, float ambiguity, int *__restrict__ result,
+                                                            const float4 *__restrict__ partial,
+                                                            const float *__restrict__ partial3,
+                                                            const float *__restrict__ na, int mode, int index_offset,
+                                                            float ambiguity, int *__restrict__ result,
                                                             float *__restrict__ min1_out, int *__restrict__ idx_out,
-                                                            float *__restrict__ min2_out)
+                                                            float *__restrict__ min2_out, int *__restrict__ fb_count,
+                                                            int *__restrict__ fb_list)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int i = t >> 2, sub = t & 3;
     const bool live = i < nA;
     const int iq = live ? i : nA - 1;
     float cd[4]; int ci[4];
+    float rest = __builtin_inff();
 #pragma unroll
     for (int k = 0; k < 4; ++k) { cd[k] = __builtin_inff(); ci[k] = -1; }
     auto insert = [&](float d, int j) {
@@ -255,9 +284,11 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(const float *__rest
             const bool lt = (d < cd[k]) || (d == cd[k] && j < ci[k]);
             if (lt) { const float td = cd[k]; const int tj = ci[k]; cd[k] = d; ci[k] = j; d = td; j = tj; }
         }
+        if (j >= 0) rest = __builtin_fminf(rest, d);  // fell off the end of the list: not going to be recomputed
     };
     for (int s = sub; s < S; s += 4) {
         const float4 p = partial[(size_t)iq * S + s];
+        rest = __builtin_fminf(rest, partial3[(size_t)iq * S + s]);
         insert(p.x, __float_as_int(p.y));
         insert(p.z, __float_as_int(p.w));
     }
@@ -266,15 +297,17 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(const float *__rest
         float od[4]; int oi[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { od[k] = __shfl_xor(cd[k], m); oi[k] = __shfl_xor(ci[k], m); }
+        rest = __builtin_fminf(rest, __shfl_xor(rest, m));
 #pragma unroll
         for (int k = 0; k < 4; ++k) insert(od[k], oi[k]);
     }
+    rest = __builtin_fminf(rest, __builtin_fminf(__shfl_xor(rest, 1), __shfl_xor(rest, 2)));
+    rest = __builtin_fminf(rest, __builtin_fminf(__shfl_xor(rest, 1), __shfl_xor(rest, 2)));
     const int mine = (sub == 0) ? ci[0] : (sub == 1) ? ci[1] : (sub == 2) ? ci[2] : ci[3];
     float d = 0.f;
     if (mine >= 0)
         d = exact_dist(reinterpret_cast<const float4 *>(A + (size_t)iq * DIM),
                        reinterpret_cast<const float4 *>(B + (size_t)mine * DIM));
-    // gather the quad's exact distances into lane 0 of the quad, in candidate order
     float ed[4]; int ei[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { ed[k] = __shfl(d, ((threadIdx.x & 63) & ~3) + k); ei[k] = ci[k]; }
@@ -288,13 +321,79 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(const float *__rest
         else if (ed[k] < m2) m2 = ed[k];
     }
     if (!have) return;
-    if (mode == 1) {
-        min1_out[i] = m1; idx_out[i] = idx + index_offset; min2_out[i] = m2;
+    // Error of the MFMA formulation: 129 roundings of partial sums of magnitude <= na + nb, i.e. a random walk with
+    // sigma ~ sqrt(129/12) * 2^-23 * 0.7 (na + nb) = 2.7e-7 (na + nb); nb <= (sqrt(na) + sqrt(d))^2 <= 2 na + 2 d for any
+    // candidate at distance d. margin = 2.4e-6 (3 na + 2 d) is ~9 sigma (the all-aligned worst case is 3x larger still
+    // and has probability < 2^-129). A candidate within the margin of min2 (or a tie of min1 hiding among them) sends
+    // the query to the exact fallback.
+    const float nai = na[i];
+    const float margin = 2.4e-6f * (3.0f * nai + 2.0f * __builtin_fminf(m2, 4.0f * nai + 4.0f * m1));
+    if (rest <= m2 + margin && rest < __builtin_inff()) {
+        const int pos = atomicAdd(fb_count, 1);
+        fb_list[pos] = i;
         return;
     }
-    if (m2 > 0) {
-        const float q = m1 / m2;
-        result[i] = (q < ambiguity) ? idx : -1;
+    emit_match(i, m1, idx, m2, mode, index_offset, ambiguity, result, min1_out, idx_out, min2_out);
+}
+
+// Exact fallback for the queries the finalize pass could not prove: one workgroup per listed query scans ALL candidates
+// exactly (the reference's own arithmetic) and merges (min1, lowest index, multiset second minimum) across threads.
+__global__ __launch_bounds__(256) void match_fallback_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                            int nB, const int *__restrict__ fb_count,
+                                                            const int *__restrict__ fb_list, int mode, int index_offset,
+                                                            float ambiguity, int *__restrict__ result,
+                                                            float *__restrict__ min1_out, int *__restrict__ idx_out,
+                                                            float *__restrict__ min2_out)
+{
+    __shared__ float s_m1[4], s_m2[4];
+    __shared__ int s_i1[4];
+    const int count = *fb_count;
+    for (int e = blockIdx.x; e < count; e += gridDim.x) {
+        const int i = fb_list[e];
+        __syncthreads();
+        float4 x[DIM / 4];                                 // the query row lives in registers
+#pragma unroll
+        for (int k = 0; k < DIM / 4; ++k) x[k] = reinterpret_cast<const float4 *>(A + (size_t)i * DIM)[k];
+        float m1 = __builtin_inff(), m2 = __builtin_inff(); int i1 = 0x7fffffff;
+        for (int j = threadIdx.x; j < nB; j += 256) {
+            const float4 *b = reinterpret_cast<const float4 *>(B + (size_t)j * DIM);
+            float4 y[DIM / 4];
+#pragma unroll
+            for (int k = 0; k < DIM / 4; ++k) y[k] = b[k];
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < DIM / 4; ++k) {
+                float tt;
+                tt = x[k].x - y[k].x; acc = __builtin_fmaf(tt, tt, acc);
+                tt = x[k].y - y[k].y; acc = __builtin_fmaf(tt, tt, acc);
+                tt = x[k].z - y[k].z; acc = __builtin_fmaf(tt, tt, acc);
+                tt = x[k].w - y[k].w; acc = __builtin_fmaf(tt, tt, acc);
+            }
+            if (acc < m1) { m2 = m1; m1 = acc; i1 = j; }
+            else if (acc < m2) m2 = acc;
+        }
+        auto merge = [&](float o1, int oi, float o2) {
+            const bool take = (o1 < m1) || (o1 == m1 && oi < i1);
+            const float lo = take ? o1 : m1, hi = take ? m1 : o1;
+            const float s2 = take ? o2 : m2;
+            i1 = take ? oi : i1;
+            m1 = lo;
+            m2 = (hi < s2) ? hi : s2;
+        };
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const float o1 = __shfl_xor(m1, sft), o2 = __shfl_xor(m2, sft);
+            const int oi = __shfl_xor(i1, sft);
+            merge(o1, oi, o2);
+        }
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { s_m1[wave] = m1; s_m2[wave] = m2; s_i1[wave] = i1; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w) merge(s_m1[w], s_i1[w], s_m2[w]);
+            if (MIN2_INIT < m2) m2 = MIN2_INIT;
+            emit_match(i, m1, i1, m2, mode, index_offset, ambiguity, result, min1_out, idx_out, min2_out);
+        }
     }
 }
 
@@ -423,7 +522,7 @@ __global__ __launch_bounds__(256) void set_matches_kernel(int *__restrict__ resu
     }
 }
 
-struct MatchWs { float *na, *nb; float4 *partial; };
+struct MatchWs { float *na, *nb; float4 *partial; float *partial3; int *fb_count, *fb_list; };
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -433,8 +532,10 @@ static MatchWs carve(void *workspace, int nA, int nB, const MatchPlan &p)
     char *base = static_cast<char *>(workspace);
     w.na = reinterpret_cast<float *>(base); base += align256((size_t)nA * 4);
     w.nb = reinterpret_cast<float *>(base); base += align256((size_t)nB * 4);
-    w.partial = reinterpret_cast<float4 *>(base);
-    (void)p;
+    w.partial = reinterpret_cast<float4 *>(base); base += align256((size_t)nA * p.S * sizeof(float4));
+    w.partial3 = reinterpret_cast<float *>(base); base += align256((size_t)nA * p.S * sizeof(float));
+    w.fb_count = reinterpret_cast<int *>(base); base += 256;
+    w.fb_list = reinterpret_cast<int *>(base);
     return w;
 }
 
@@ -455,11 +556,15 @@ static int run_fused(const float *A, int nA, const float *B, int nB, int mode, i
     }
     nm_prof_begin(NM_PROF_MATCH_TOP2, st);
     hipLaunchKernelGGL(match_top2_kernel, dim3(p.qblocks, p.S), dim3(512), lds_bytes, st, A, nA, B, nB, w.na, w.nb,
-                       p.chunk, p.S, w.partial);
+                       p.chunk, p.S, w.partial, w.partial3);
     nm_prof_end(NM_PROF_MATCH_TOP2, st);
     NM_LAUNCH_CHECK();
+    NM_RETURN_IF(hipMemsetAsync(w.fb_count, 0, sizeof(int), st));
     hipLaunchKernelGGL(match_finalize_kernel, dim3(nm_divup(4 * nA, 256)), dim3(256), 0, st, A, nA, B, nB, p.S, w.partial,
-                       mode, index_offset, ambiguity, result, min1, idx1, min2);
+                       w.partial3, w.na, mode, index_offset, ambiguity, result, min1, idx1, min2, w.fb_count, w.fb_list);
+    NM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(match_fallback_kernel, dim3(256), dim3(256), 0, st, A, B, nB, w.fb_count, w.fb_list, mode,
+                       index_offset, ambiguity, result, min1, idx1, min2);
     NM_LAUNCH_CHECK();
     return 0;
 }
@@ -500,12 +605,23 @@ int nm_get_sift_matches_f32(const float *distance, int rows, int cols, int buffe
     return 0;
 }
 
+// Upper bound for every call with nA' <= nA and nB' <= nB on the same workspace (the grid plan, hence the number of
+// candidate chunks S <= MAX_CHUNKS, depends on the actual sizes).
 size_t nm_sift_match_workspace_bytes(int nA, int nB)
 {
     if (nA < 0) nA = 0;
     if (nB < 0) nB = 0;
+    return align256((size_t)nA * 4) + align256((size_t)nB * 4) + align256((size_t)nA * MAX_CHUNKS * sizeof(float4)) +
+           align256((size_t)nA * MAX_CHUNKS * sizeof(float)) + 256 + align256((size_t)nA * 4) + 256;
+}
+
+int nm_sift_match_fallback_count(const void *workspace, int nA, int nB, int *host_count, void *stream)
+{
+    if (!workspace || !host_count || nA <= 0 || nB <= 0) return (int)hipErrorInvalidValue;
     const MatchPlan p = make_plan(nA, nB);
-    return align256((size_t)nA * 4) + align256((size_t)nB * 4) + align256((size_t)nA * p.S * sizeof(float4)) + 256;
+    MatchWs w = carve(const_cast<void *>(workspace), nA, nB, p);
+    NM_RETURN_IF(hipMemcpyAsync(host_count, w.fb_count, sizeof(int), hipMemcpyDeviceToHost, nm_stream(stream)));
+    return (int)hipStreamSynchronize(nm_stream(stream));
 }
 
 int nm_sift_match_f32(const float *A, int nA, const float *B, int nB, float *distance, int *result, float ambiguity,

@@ -81,3 +81,52 @@ def test_cpp_api_client_loop(nm, oracle, cuda):
     _eq(desc[:n], ref["desc"], "C++ API descriptors")
     _eq(x[:n], ref["x"], "C++ API x")
     _eq(y[:n], ref["y"], "C++ API y")
+
+
+def test_flat_and_tiny_frames_have_no_keypoints(nm, oracle, cuda):
+    import torch
+    for shape in ((64, 64), (5, 4)):
+        flat = np.full(shape, 37.0, np.float32)
+        ref = oracle.sift_detect_describe(flat, 64)
+        got = _run_arena(nm, cuda, flat, 64)
+        assert got["n"] == ref["n"]
+        if ref["n"]:
+            _eq(got["desc"], ref["desc"], "descriptors of the zero-padding border extrema")
+    z = np.zeros((48, 40), np.float32)
+    assert _run_arena(nm, cuda, z, 16)["n"] == 0 == oracle.sift_detect_describe(z, 16)["n"]
+
+
+def test_empty_level_ends_the_octave_q9(nm, oracle, cuda):
+    """SURVEY Q9 (sift/siftfunctions.cu:145,160): keypoints of the levels after the first empty level of an octave are
+    dropped. A single blob whose scale puts it in level 1 or 2 of octave 0 (level 0 empty) must vanish."""
+    yy, xx = np.mgrid[0:128, 0:128].astype(np.float64)
+    hits = 0
+    for sb in (3.1, 3.3, 3.5, 3.7):
+        img = (200.0 * np.exp(-((xx - 64.3) ** 2 + (yy - 63.6) ** 2) / (2 * sb * sb))).astype(np.float32)
+        ref = oracle.sift_detect_describe(img, 64)
+        got = _run_arena(nm, cuda, img, 64)
+        assert got["n"] == ref["n"]
+        _eq(got["kpts"], ref["kpts"], "keypoints sb=%g" % sb)
+        p = oracle.sift_params(128, 128)
+        levels, dogs, _ = oracle.octave_pyramid(oracle.convolve(img, *oracle.create_kernel_for_sigma(p.base_smooth))[0], 128, 128)
+        per_level = [len(oracle.compact_keypoints(oracle.find_keypoints(dogs[l + 1], dogs[l], dogs[l + 2], 0.0, 10.0, 1.0,
+                                                                      p.sigma_0, 3, l))) for l in range(3)]
+        if per_level[0] == 0 and sum(per_level) > 0:
+            hits += 1
+            assert ref["counts"][0].tolist() == [0, 0, 0]      # found by the stage, dropped by the orchestration
+    assert hits >= 1, "no blob exercised the empty-level rule; adjust the scales"
+
+
+def test_cpp_api_match_with_and_without_distance(nm, oracle, cuda):
+    """compute_sift_matches through the C++ SiftData API (nm_client_match), incl. the materialised distance matrix."""
+    A = H.synth.descriptors(11, 700)
+    B = H.synth.descriptors(12, 450)
+    ref, Dref, _ = oracle.sift_matches(A, B, 0.8)
+    res = np.full(700, -1, np.int32)
+    D = np.zeros((700, 450), np.float32)
+    assert nm.lib().nm_client_match(A.ctypes.data, 700, B.ctypes.data, 450, D.ctypes.data, res.ctypes.data, 0.8) == 0
+    assert np.array_equal(res, ref)
+    _eq(D, Dref, "distance matrix via the C++ API")
+    res2 = np.full(700, -1, np.int32)
+    assert nm.lib().nm_client_match(A.ctypes.data, 700, B.ctypes.data, 450, None, res2.ctypes.data, 0.8) == 0
+    assert np.array_equal(res2, ref)

@@ -155,3 +155,73 @@ def test_config5_shard_scale_100k_by_12k5(nm, cuda):
     assert torch.equal(ix[q].long() - off, top.indices[:, 0])
     assert torch.allclose(m1[q].double(), top.values[:, 0], rtol=1e-5, atol=1e-6)
     assert torch.allclose(m2[q].double(), top.values[:, 1], rtol=1e-5)
+
+
+def test_match_random_shapes_sweep(nm, oracle, cuda):
+    """Ragged sizes around every tiling boundary of the fused kernel (256 queries / 128 candidates / chunking)."""
+    rng = np.random.default_rng(2026)
+    shapes = [(1, 1), (1, 2), (2, 1), (255, 127), (256, 128), (257, 129), (511, 385), (33, 1025)]
+    shapes += [(int(rng.integers(1, 900)), int(rng.integers(1, 900))) for _ in range(6)]
+    for na, nb in shapes:
+        A = H.synth.descriptors(100 + na, na)
+        B = H.synth.descriptors(200 + nb, nb)
+        ref, _, (m1, ix, m2) = oracle.sift_matches(A, B, 0.8, want_distance=False)
+        got, _ = _match(nm, cuda, A, B)
+        assert np.array_equal(got, ref), (na, nb)
+        t = nm.sift_match_shard(_t(A, cuda), _t(B, cuda), 5)
+        assert np.array_equal(t[1].cpu().numpy(), ix + 5), (na, nb)
+        assert np.array_equal(t[0].cpu().numpy(), m1) and np.array_equal(t[2].cpu().numpy(), m2), (na, nb)
+
+
+def test_match_empty_sets_are_noops(nm, cuda):
+    import torch
+    A = _t(H.synth.descriptors(1, 8), cuda)
+    prior = torch.full((8,), 5, dtype=torch.int32, device=cuda)
+    ws = nm.MatchWorkspace(8, 8, cuda)
+    res, _ = nm.sift_match(A, A, 0.8, prior=prior, workspace=ws, nA=0, nB=8)
+    res, _ = nm.sift_match(A, A, 0.8, prior=prior, workspace=ws, nA=8, nB=0)
+    torch.cuda.synchronize()
+    assert bool((res == 5).all())
+
+
+def test_fallback_rate_and_forced_fallback(nm, oracle, cuda):
+    """The exact fallback must be rare on ordinary data and must fire (and give the exact answer) on near-ties that
+    the MFMA formulation cannot resolve."""
+    import torch
+    A = H.synth.descriptors(1, 4000) * 100
+    B = H.synth.descriptors(2, 3000) * 100
+    ws = nm.MatchWorkspace(4000, 3000, cuda)
+    res, _ = nm.sift_match(_t(A, cuda), _t(B, cuda), 0.8, workspace=ws)
+    assert nm.match_fallback_count(ws, 4000, 3000) < 0.05 * 4000
+    ref, _, _ = oracle.sift_matches(A, B, 0.8, want_distance=False)
+    assert np.array_equal(res.cpu().numpy(), ref)
+    # near-ties: every query has three candidates whose distances differ by ~1 ulp of the accumulated sum
+    rng = np.random.default_rng(0)
+    A = rng.uniform(0, 255, (300, 128)).astype(np.float32)
+    B = rng.uniform(0, 255, (900, 128)).astype(np.float32)
+    for i in range(300):
+        for c in range(3):
+            v = A[i].copy()
+            v[(7 * i + c) % 128] += np.float32(60.0)              # three candidates at (almost) the same distance 3600
+            v[(11 * i + 5 * c) % 128] += np.float32(1e-3 * c)
+            B[3 * i + c] = v
+    ws = nm.MatchWorkspace(300, 900, cuda)
+    m1, ix, m2 = nm.sift_match_shard(_t(A, cuda), _t(B, cuda), 0, workspace=ws)
+    assert nm.match_fallback_count(ws, 300, 900) > 100
+    _, _, (m1r, ixr, m2r) = oracle.sift_matches(A, B, 0.8, want_distance=False)
+    assert np.array_equal(ix.cpu().numpy(), ixr)
+    assert np.array_equal(m1.cpu().numpy(), m1r) and np.array_equal(m2.cpu().numpy(), m2r)
+
+
+def test_oversized_workspace_is_valid_for_smaller_calls(nm, oracle, cuda):
+    """A workspace sized for (16384, 16384) must serve any smaller call (bench.py does exactly that): the chunk count of
+    the grid plan depends on the actual sizes, so the workspace bound has to cover the worst plan."""
+    import torch
+    ws = nm.MatchWorkspace(16384, 16384, cuda)
+    for na, nb in [(300, 2500), (5000, 140), (16384, 130), (2591, 2600), (1, 16384)]:
+        A = H.synth.descriptors(na + 1, na)
+        B = H.synth.descriptors(nb + 2, nb)
+        ref, _, _ = oracle.sift_matches(A, B, 0.8, want_distance=False)
+        res, _ = nm.sift_match(_t(A, cuda), _t(B, cuda), 0.8, workspace=ws)
+        torch.cuda.synchronize()
+        assert np.array_equal(res.cpu().numpy(), ref), (na, nb)
