@@ -30,7 +30,7 @@ constexpr int MAX_CHUNKS = 64;     // upper bound of the candidate-chunk count S
 struct MatchPlan { int qblocks, S, chunk; };
 
 // Grid = qblocks x S workgroups, one resident per CU (LDS). S is chosen to maximise
-//   (fill of the last round of workgroups over the 256 CUs) x (tiles / (tiles + 0.6)),
+//   (fill of the last round of workgroups over the 256 CUs) x (tiles / (tiles + 0.4)),
 // the second factor being the per-workgroup prologue (staging 256 queries) expressed in 128-candidate tiles.
 static MatchPlan make_plan(int nA, int nB)
 {
@@ -47,7 +47,7 @@ static MatchPlan make_plan(int nA, int nB)
         const long blocks = (long)p.qblocks * S;
         const long rounds = (blocks + n_cu - 1) / n_cu;
         const double fill = (double)blocks / (double)(rounds * n_cu);
-        const double score = fill * ((double)tpc / ((double)tpc + 0.6));
+        const double score = fill * ((double)tpc / ((double)tpc + 0.4));
         if (score > best + 1e-9) { best = score; bestS = S; }
     }
     p.chunk = nm_divup(tiles, bestS) * TILE_C;
