@@ -23,7 +23,7 @@ using nmfp::fma32;
 // Tiles are dealt so that workgroups sharing an XCD (blockIdx % 8) walk one contiguous band of the image: halo rows
 // re-read by vertical neighbours hit that XCD's L2. R is a template parameter: tap loops unroll, windows live in VGPRs.
 template <int R, int TH, bool WRITE_BUF, bool WRITE_DOG, bool WRITE_GRAD, bool VEC>
-__global__ __launch_bounds__(256) void conv_sep_kernel(float *__restrict__ result, const float *__restrict__ image,
+__global__ __launch_bounds__(TH * 8) void conv_sep_kernel(float *__restrict__ result, const float *__restrict__ image,
                                                       float *__restrict__ buffer, float *__restrict__ dog,
                                                       float2 *__restrict__ grad, int width, int height,
                                                       const float *__restrict__ taps, int tiles_x, int ntiles)
@@ -37,7 +37,8 @@ __global__ __launch_bounds__(256) void conv_sep_kernel(float *__restrict__ resul
     constexpr int NT = 2 * R + 1;
     constexpr int V_PER_ROW = IN_W / 4;
     constexpr int NE = VEC ? ROWS * V_PER_ROW : ROWS * IN_W;     // staged elements (float4 or float)
-    constexpr int PER = (NE + 255) / 256;
+    constexpr int NTH = TH * 8;                   // 256 threads for 64 x 32 tiles, 512 for 64 x 64
+    constexpr int PER = (NE + NTH - 1) / NTH;
     __shared__ __attribute__((aligned(16))) float s_in[ROWS * IN_P];
     __shared__ __attribute__((aligned(16))) float s_mid[ROWS * TW];
 
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void conv_sep_kernel(float *__restrict__ resul
         const int x0 = tx * TW, y0 = ty * TH;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            const int idx = tid + 256 * i;
+            const int idx = tid + NTH * i;
             if (VEC) {
                 const int row = idx / V_PER_ROW, c4 = idx - row * V_PER_ROW;
                 const int gy = y0 - R + row, gx = x0 - RA + 4 * c4;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void conv_sep_kernel(float *__restrict__ resul
         // phase 1: registers -> LDS
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            const int idx = tid + 256 * i;
+            const int idx = tid + NTH * i;
             if (VEC) {
                 const int row = idx / V_PER_ROW, c4 = idx - row * V_PER_ROW;
                 if (idx < NE) *reinterpret_cast<float4 *>(&s_in[row * IN_P + 4 * c4]) = pf4[i];
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void conv_sep_kernel(float *__restrict__ resul
         // phase 2: rows
         {
             const int xc = tid & 7;
-            for (int row = tid >> 3; row < ROWS; row += 32) {
+            for (int row = tid >> 3; row < ROWS; row += NTH / 8) {
                 float v[8 + 2 * RA];                  // 16-byte aligned window; the taps use v[OFF .. OFF + 8 + 2R)
                 const float *p = &s_in[row * IN_P + xc * 8];
 #pragma unroll
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void conv_sep_kernel(float *__restrict__ resul
 
         // phase 3: columns
         {
-            constexpr int NY = TH / 4;
+            constexpr int NY = TH / (NTH / 64);       // 8 vertical outputs per thread
             const int x = tid & 63, yg = tid >> 6;
             float v[NY + 2 * R];
             const float *p = &s_mid[(yg * NY) * TW + x];
@@ -219,7 +220,7 @@ static int launch_conv_rvt(float *result, const float *image, float *buffer, flo
     dim3 grid(blocks);
     float2 *g2 = reinterpret_cast<float2 *>(grad);
 #define NM_CONV_LAUNCH(BUF, DOG, GRAD)                                                                              \
-    hipLaunchKernelGGL((conv_sep_kernel<R, TH, BUF, DOG, GRAD, VEC>), grid, dim3(256), 0, stream, result, image,    \
+    hipLaunchKernelGGL((conv_sep_kernel<R, TH, BUF, DOG, GRAD, VEC>), grid, dim3(TH * 8), 0, stream, result, image, \
                        buffer, dog, g2, width, height, taps, tiles_x, ntiles)
     if (buffer) {
         if (dog || grad || TH != 32) return (int)hipErrorInvalidValue;   // the API path never asks for the fused outputs
@@ -242,7 +243,12 @@ template <int R, bool VEC>
 static int launch_conv_rv(float *result, const float *image, float *buffer, float *dog, float *grad, int width,
                           int height, const float *taps, hipStream_t stream)
 {
-    // 64 x 32 tiles. (Measured on MI355X, 1080p: 64 x 64 tiles are 5-12 % slower for r <= 10 and 4 % faster for r = 13.)
+    // 64 x 32 tiles with 256 threads, or 64 x 64 tiles with 512 threads (less halo re-reading and row-pass redundancy)
+    // once the image has enough tiles to fill the chip that way.
+    static int th = 0;
+    if (th == 0) { const char *e = getenv("NM_CONV_TH"); th = e ? atoi(e) : 64; }
+    if (VEC && !buffer && th == 64 && (long)width * height >= 256L * 64 * 64)
+        return launch_conv_rvt<R, VEC, VEC ? 64 : 32>(result, image, buffer, dog, grad, width, height, taps, stream);
     return launch_conv_rvt<R, VEC, 32>(result, image, buffer, dog, grad, width, height, taps, stream);
 }
 
