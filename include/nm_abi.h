@@ -158,6 +158,20 @@ NM_API int nm_align_points(const float *src_x, const float *src_y, const float *
                            float *c_src_x, float *c_src_y, float *c_dst_x, float *c_dst_y, const int *matches,
                            int num_pts, void *stream);
 
+/* RANSAC hypothesis evaluation (kernels/ransac.cu:430-521 kernels + the max_element/copy of :523-694).
+ * model: 0 translation (1 sample per hypothesis), 1 similarity (2), 2 homography (4). rand_list: DEVICE array of
+ * iterations * samples point indices (the reference draws them on the host, ransac.cu:543-551; see the C++ wrappers).
+ * Outputs (device): homographies iterations x 9 (zeros for a hypothesis with a repeated index), inliers iterations,
+ * H_best 9 floats = the hypothesis at the FIRST maximum of inliers, *d_position its index (may be NULL).
+ * Points with src_x < 0 (unmatched rows of align_points) are ignored. The null vector of the design matrix is found by
+ * an independent one-sided Jacobi, not the reference's GSL port: see csrc/nm_ransac_math.hpp.                     */
+NM_API int nm_ransac_f32(int model, const float *src_x, const float *src_y, const float *dst_x, const float *dst_y,
+                         int num_pts, const int *rand_list, int iterations, float inlier_threshold,
+                         float *homographies, int *inliers, float *H_best, int *d_position, void *stream);
+
+/* Seed of the host-side sampler used by the C++ ransac_* wrappers (0 = std::random_device, the reference's behaviour). */
+NM_API void nm_ransac_seed(unsigned int seed);
+
 /* ---- per-frame driver ---- */
 /* The per-octave client loop the reference leaves to its caller, run entirely on `stream` with no
  * host synchronisation and no allocation: Gaussian pyramid + DoG + gradients + extrema + ordered compaction +

@@ -16,6 +16,12 @@ __attribute__((visibility("default"))) int nm_client_detect_describe(const float
 /* A: nA*128, B: nB*128 (host). distance: nA*nB (host) or NULL. result: nA ints, pre-filled by the caller. */
 __attribute__((visibility("default"))) int nm_client_match(const float *A, int nA, const float *B, int nB,
                                                           float *distance, int *result, float ambiguity);
+/* model 0/1/2 = ransac_translation / ransac_similarity / ransac_homography of the C++ API with the given sampler seed.
+ * Host arrays in, H (9 floats, host) out. Returns 1 when the fit ran, 0 when there were too few points, -1 on error. */
+__attribute__((visibility("default"))) int nm_client_ransac(int model, const float *src_x, const float *src_y,
+                                                           const float *dst_x, const float *dst_y, int n,
+                                                           float inlier_threshold, int iterations, unsigned int seed,
+                                                           float *H);
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,8 @@ _SIGNATURES = {
     "nm_cast_f32_u8": (_I, [_P, _SZ, _SZ, _P, C.c_ubyte, _P]),
     "nm_downsample2_u8x4": (_I, [_P, _I, _I, _P, _I, _I, _P]),
     "nm_align_points": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "nm_ransac_f32": (_I, [_I, _P, _P, _P, _P, _I, _P, _I, _F, _P, _P, _P, _P, _P]),
+    "nm_ransac_seed": (None, [C.c_uint]),
     "nm_sift_arena_create": (_I, [_I, _I, _I, _P]),
     "nm_sift_arena_destroy": (None, [_P]),
     "nm_sift_arena_bytes": (_SZ, [_P]),
@@ -57,6 +59,7 @@ _SIGNATURES = {
     "nm_sift_octave_pyramid": (_I, [_P, _I, _I, _P]),
     "nm_client_detect_describe": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "nm_client_match": (_I, [_P, _I, _P, _I, _P, _P, _F]),
+    "nm_client_ransac": (_I, [_I, _P, _P, _P, _P, _I, _F, _I, C.c_uint, _P]),
 }
 
 ABI_SYMBOLS = tuple(k for k in _SIGNATURES if not k.startswith("nm_client_"))
@@ -353,6 +356,21 @@ def align_points(sx, sy, dx, dy, matches):
     _check(lib().nm_align_points(_dev(sx), _dev(sy), _dev(dx), _dev(dy), *[_dev(o) for o in outs],
                                  _dev(matches, torch.int32), n, _stream()), "nm_align_points")
     return outs
+
+
+def ransac(model, sx, sy, dx, dy, rand_list, thr):
+    """Evaluate RANSAC hypotheses on the device. model 0/1/2 = translation/similarity/homography; rand_list int32
+    (iterations, samples). Returns (position, H_best[9], homographies[iterations, 9], inliers[iterations])."""
+    torch = _torch()
+    it = rand_list.shape[0]
+    H_all = torch.zeros((it, 9), dtype=torch.float32, device=sx.device)
+    inl = torch.zeros(it, dtype=torch.int32, device=sx.device)
+    Hb = torch.zeros(9, dtype=torch.float32, device=sx.device)
+    pos = torch.zeros(1, dtype=torch.int32, device=sx.device)
+    _check(lib().nm_ransac_f32(model, _dev(sx, torch.float32), _dev(sy), _dev(dx), _dev(dy), sx.shape[0],
+                               _dev(rand_list, torch.int32), it, thr, _dev(H_all), _dev(inl), _dev(Hb), _dev(pos),
+                               _stream()), "nm_ransac_f32")
+    return pos, Hb, H_all, inl
 
 
 class SiftArena:

@@ -10,6 +10,7 @@
 
 #include "../convolution.h"
 #include "../downsample.h"
+#include "../ransac.h"
 #include "../siftfunctions.h"
 
 extern "C" int nm_client_detect_describe(const float *gray, int width, int height, int capacity, float *desc, float *x,
@@ -70,6 +71,28 @@ extern "C" int nm_client_match(const float *A, int nA, const float *B, int nB, f
             std::memcpy(distance, h.data(), h.size() * sizeof(float));
         }
         return 0;
+    } catch (const std::exception &e) {
+        std::cerr << e.what() << std::endl;
+        return -1;
+    }
+}
+
+extern "C" int nm_client_ransac(int model, const float *src_x, const float *src_y, const float *dst_x, const float *dst_y,
+                                int n, float inlier_threshold, int iterations, unsigned int seed, float *H)
+{
+    try {
+        nm::device_vector<float> sx(std::vector<float>(src_x, src_x + n)), sy(std::vector<float>(src_y, src_y + n));
+        nm::device_vector<float> dx(std::vector<float>(dst_x, dst_x + n)), dy(std::vector<float>(dst_y, dst_y + n));
+        nm::device_vector<float> h(9, 0.f);
+        nm_ransac_seed(seed);
+        bool ok = false;
+        if (model == 0) ok = ransac_translation(sx.data(), sy.data(), dx.data(), dy.data(), n, n, inlier_threshold, iterations, h.data());
+        else if (model == 1) ok = ransac_similarity(sx.data(), sy.data(), dx.data(), dy.data(), n, n, inlier_threshold, iterations, h.data());
+        else ok = ransac_homography(sx.data(), sy.data(), dx.data(), dy.data(), n, n, inlier_threshold, iterations, h.data());
+        nm_ransac_seed(0);
+        std::vector<float> hh = h.to_host();
+        std::memcpy(H, hh.data(), 9 * sizeof(float));
+        return ok ? 1 : 0;
     } catch (const std::exception &e) {
         std::cerr << e.what() << std::endl;
         return -1;

@@ -20,6 +20,7 @@
  *   - atomics with undefined order get ONE fixed order, stated at each site.
  */
 #include "nmo_math.h"
+#include "nmo_ransac.h"
 
 #include <algorithm>
 #include <cmath>
@@ -647,6 +648,43 @@ NMO_API void nmo_align_points(const float *sx, const float *sy, const float *dx,
         if (m != -1) { csx[i] = sx[i]; csy[i] = sy[i]; cdx[i] = dx[m]; cdy[i] = dy[m]; }
         else { csx[i] = -1; csy[i] = -1; cdx[i] = -1; cdy[i] = -1; }
     }
+}
+
+/* ---------------------------------------------------------------------------------------------------------- */
+/* RANSAC hypotheses -- kernels/ransac.cu:430-521 (one hypothesis per thread), :523-694 (host: best = first maximum).
+ * model 0 translation (1 sample), 1 similarity (2), 2 homography (4). rand_list holds iterations * samples point
+ * indices, drawn by the caller (the reference draws them on the host from std::mt19937, :543-551). Hypotheses with
+ * a repeated index are skipped: their H stays 0 and their inlier count 0, as in the reference's zero-initialised
+ * device vectors. Returns the position of the first maximum of the inlier counts; H_best = that hypothesis.       */
+NMO_API int nmo_ransac(int model, const float *sx, const float *sy, const float *dx, const float *dy, int n,
+                       const int *rand_list, int iterations, float thr, float *H_all, int *inliers, float *H_best)
+{
+    const int ns = (model == 0) ? 1 : (model == 1) ? 2 : 4;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int it = 0; it < iterations; ++it) {
+        float *H = H_all + 9 * (size_t)it;
+        for (int k = 0; k < 9; ++k) H[k] = 0.f;
+        inliers[it] = 0;
+        const int *ri = rand_list + (size_t)it * ns;
+        bool dup = false;
+        for (int a = 0; a < ns; ++a)
+            for (int b = a + 1; b < ns; ++b) dup = dup || (ri[a] == ri[b]);
+        if (dup) continue;
+        float px[4], py[4], qx[4], qy[4];
+        for (int a = 0; a < ns; ++a) { px[a] = sx[ri[a]]; py[a] = sy[ri[a]]; qx[a] = dx[ri[a]]; qy[a] = dy[ri[a]]; }
+        if (model == 0) nmo_fit_translation(px, py, qx, qy, H);
+        else if (model == 1) nmo_fit_similarity(px, py, qx, qy, H);
+        else nmo_fit_homography(px, py, qx, qy, H);
+        int cnt = 0;
+        for (int i = 0; i < n; ++i)
+            if (sx[i] >= 0 && nmo_is_inlier(H, sx[i], sy[i], dx[i], dy[i], thr)) ++cnt;
+        inliers[it] = cnt;
+    }
+    int pos = 0;
+    for (int it = 1; it < iterations; ++it)
+        if (inliers[it] > inliers[pos]) pos = it;                  /* thrust::max_element: first maximum */
+    for (int k = 0; k < 9; ++k) H_best[k] = H_all[9 * (size_t)pos + k];
+    return pos;
 }
 
 /* ---------------------------------------------------------------------------------------------------------- */

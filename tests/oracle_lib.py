@@ -19,7 +19,7 @@ class Params(C.Structure):
 
 
 def build():
-    src = [os.path.join(_ORACLE_DIR, f) for f in ("nm_oracle.cpp", "nmo_math.h", "Makefile")]
+    src = [os.path.join(_ORACLE_DIR, f) for f in ("nm_oracle.cpp", "nmo_math.h", "nmo_ransac.h", "Makefile")]
     if (not os.path.exists(_LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src):
         subprocess.check_call(["make", "-C", _ORACLE_DIR], stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -269,3 +269,16 @@ def align_points(sx, sy, dx, dy, matches):
     outs = [np.empty(n, np.float32) for _ in range(4)]
     lib().nmo_align_points(_fp(sx), _fp(sy), _fp(dx), _fp(dy), *[_fp(o) for o in outs], _fp(matches), C.c_int(n))
     return outs
+
+
+def ransac(model, sx, sy, dx, dy, rand_list, thr):
+    """model: 0 translation, 1 similarity, 2 homography. rand_list: (iterations, samples) int32."""
+    sx, sy, dx, dy = _f32(sx), _f32(sy), _f32(dx), _f32(dy)
+    rl = np.ascontiguousarray(rand_list, np.int32)
+    it = rl.shape[0]
+    H_all = np.zeros((it, 9), np.float32)
+    inl = np.zeros(it, np.int32)
+    Hb = np.zeros(9, np.float32)
+    pos = lib().nmo_ransac(C.c_int(model), _fp(sx), _fp(sy), _fp(dx), _fp(dy), C.c_int(len(sx)), _fp(rl), C.c_int(it),
+                           C.c_float(thr), _fp(H_all), _fp(inl), _fp(Hb))
+    return pos, Hb, H_all, inl

@@ -46,7 +46,7 @@ def test_cpp_headers_mirror_reference_names():
     """Every header a client of the hot path includes by name exists, flat, like ${prefix}/include/nm."""
     need = ["macros.h", "exception.h", "siftparams.h", "pyramidata.h", "siftdata.h", "siftfunctions.h", "convolution.h",
             "downsample.h", "cudamath.h", "keypoint.h", "orientation.h", "descriptor.h", "match.h", "transpose.h",
-            "cudatimer.h", "cudautils.h"]
+            "cudatimer.h", "cudautils.h", "bgra_2_gray.h", "cast.h", "ransac.h"]
     have = os.listdir(os.path.join(ROOT, "niftymatch_amd", "nm"))
     assert not [h for h in need if h not in have]
     cfg = open(os.path.join(ROOT, "niftymatch_amd", "cmake", "NiftyMatchConfig.cmake")).read()
