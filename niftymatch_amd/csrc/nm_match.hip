@@ -548,12 +548,9 @@ static int run_fused(const float *A, int nA, const float *B, int nB, int mode, i
     hipLaunchKernelGGL(norms_kernel, dim3(nm_divup(nA + nB, 256)), dim3(256), 0, st, A, nA, w.na, B, nB, w.nb);
     NM_LAUNCH_CHECK();
     const size_t lds_bytes = (size_t)2 * TILE_C * KP * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        NM_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_set = true;
-    }
+    // per call: the attribute is per device, and a process may drive several (cheap host-side call, not a stream op)
+    NM_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     nm_prof_begin(NM_PROF_MATCH_TOP2, st);
     hipLaunchKernelGGL(match_top2_kernel, dim3(p.qblocks, p.S), dim3(512), lds_bytes, st, A, nA, B, nB, w.na, w.nb,
                        p.chunk, p.S, w.partial, w.partial3);

@@ -2,8 +2,6 @@
 // gradient. Replaces kernels/convolution.cu:16-159, kernels/downsample.cu:6-29, kernels/cudamath.cu:26-80 of the
 // reference. All kernels are HBM/L2 streaming stencils; arithmetic order is fixed by the fp spec:
 //   conv: taps k = -r..r, sum = fma(x[k], w[r-k], sum) starting from +0, rows first, then columns, zero padding.
-#include <cstdlib>
-
 #include "nm_common.hpp"
 #include "nm_fpspec.hpp"
 #include "../../include/nm_abi.h"
@@ -213,10 +211,7 @@ static int launch_conv_rvt(float *result, const float *image, float *buffer, flo
     const int ntiles = tiles_x * tiles_y;
     // one tile per workgroup up to the chip's residency; grid is a multiple of 8 (XCDs). (Measured on MI355X: more
     // tiles per workgroup with register prefetch is slower than more resident workgroups.)
-    static int tpb = 0;
-    if (tpb == 0) { const char *e = getenv("NM_CONV_TPB"); tpb = e ? atoi(e) : 1; if (tpb < 1) tpb = 1; }
-    int blocks = (ntiles >= 256 * tpb) ? (ntiles + tpb - 1) / tpb : ntiles;
-    blocks = ((blocks + 7) / 8) * 8;
+    const int blocks = ((ntiles + 7) / 8) * 8;
     dim3 grid(blocks);
     float2 *g2 = reinterpret_cast<float2 *>(grad);
 #define NM_CONV_LAUNCH(BUF, DOG, GRAD)                                                                              \
@@ -245,9 +240,7 @@ static int launch_conv_rv(float *result, const float *image, float *buffer, floa
 {
     // 64 x 32 tiles with 256 threads, or 64 x 64 tiles with 512 threads (less halo re-reading and row-pass redundancy)
     // once the image has enough tiles to fill the chip that way.
-    static int th = 0;
-    if (th == 0) { const char *e = getenv("NM_CONV_TH"); th = e ? atoi(e) : 64; }
-    if (VEC && !buffer && th == 64 && (long)width * height >= 256L * 64 * 64)
+    if (VEC && !buffer && (long)width * height >= 256L * 64 * 64)
         return launch_conv_rvt<R, VEC, VEC ? 64 : 32>(result, image, buffer, dog, grad, width, height, taps, stream);
     return launch_conv_rvt<R, VEC, 32>(result, image, buffer, dog, grad, width, height, taps, stream);
 }
