@@ -32,8 +32,10 @@ struct nm_sift_arena {
     std::vector<void *> allocs;
     float *taps_base; int base_radius;
     float *taps[8]; int radii[8];
-    float *level[6];
-    float *dog[5];
+    float *level[6];           // Gaussian levels, reused by every octave (the pyramid chain is sequential)
+    float *dog[20][5];         // DoG planes PER OCTAVE: detection of octave o overlaps the pyramid of octave o+1
+    hipStream_t side;          // detection / compaction stream forked off the caller's stream
+    hipEvent_t ev_pyr[20], ev_join;
     float *grad[20];           // per octave: 3 float2 planes
     float *staging; size_t stage_stride;
     int *counts, *offsets; int max_blocks;
@@ -104,6 +106,8 @@ int nm_sift_arena_create(int width, int height, int capacity, nm_sift_arena **ou
     nm_sift_arena *a = new (std::nothrow) nm_sift_arena();
     if (!a) return (int)hipErrorOutOfMemory;
     a->width = width; a->height = height; a->capacity = capacity;
+    a->side = nullptr; a->ev_join = nullptr;
+    for (int o = 0; o < 20; ++o) a->ev_pyr[o] = nullptr;
     a->params = SiftParams(width, height);
     a->npix = (size_t)width * height;
     a->bytes = 0;
@@ -121,9 +125,14 @@ int nm_sift_arena_create(int width, int height, int capacity, nm_sift_arena **ou
     rc = upload(P._base_smooth, &a->taps_base, &a->base_radius);
     for (size_t i = 0; !rc && i < P._sigmas.size(); ++i) rc = upload(P._sigmas[i], &a->taps[i], &a->radii[i]);
     for (int i = 0; !rc && i < 6; ++i) rc = a->alloc(&a->level[i], a->npix);
-    for (int i = 0; !rc && i < 5; ++i) rc = a->alloc(&a->dog[i], a->npix);
-    for (int o = 0; !rc && o < P._num_octaves; ++o)
-        rc = a->alloc(&a->grad[o], (size_t)6 * (width >> o) * (height >> o));
+    for (int o = 0; !rc && o < P._num_octaves; ++o) {
+        const size_t plane = (size_t)(width >> o) * (height >> o);
+        for (int i = 0; !rc && i < 5; ++i) rc = a->alloc(&a->dog[o][i], plane);
+        if (!rc) rc = a->alloc(&a->grad[o], 6 * plane);
+        if (!rc) rc = (int)hipEventCreateWithFlags(&a->ev_pyr[o], hipEventDisableTiming);
+    }
+    if (!rc) rc = (int)hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming);
+    if (!rc) rc = (int)hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking);
     a->max_blocks = height * nm_divup(width, 256);
     a->stage_stride = (size_t)a->max_blocks * 256;
     if (!rc) rc = a->alloc(&a->staging, 3 * a->stage_stride * 4);
@@ -142,13 +151,17 @@ int nm_sift_arena_create(int width, int height, int capacity, nm_sift_arena **ou
 void nm_sift_arena_destroy(nm_sift_arena *a)
 {
     if (!a) return;
+    if (a->side) { (void)hipStreamSynchronize(a->side); (void)hipStreamDestroy(a->side); }
+    for (int o = 0; o < 20; ++o)
+        if (a->ev_pyr[o]) (void)hipEventDestroy(a->ev_pyr[o]);
+    if (a->ev_join) (void)hipEventDestroy(a->ev_join);
     for (void *p : a->allocs) (void)hipFree(p);
     delete a;
 }
 
 size_t nm_sift_arena_bytes(const nm_sift_arena *a) { return a ? a->bytes : 0; }
 float *nm_sift_arena_level(nm_sift_arena *a, int l) { return (a && l >= 0 && l < 6) ? a->level[l] : nullptr; }
-float *nm_sift_arena_dog(nm_sift_arena *a, int d) { return (a && d >= 0 && d < 5) ? a->dog[d] : nullptr; }
+float *nm_sift_arena_dog(nm_sift_arena *a, int d) { return (a && d >= 0 && d < 5) ? a->dog[0][d] : nullptr; }
 float *nm_sift_arena_grad(nm_sift_arena *a) { return a ? a->grad[0] : nullptr; }
 
 static int octave_pyramid(nm_sift_arena *a, int o, int ow, int oh, bool store_top, hipStream_t st)
@@ -161,7 +174,7 @@ static int octave_pyramid(nm_sift_arena *a, int o, int ow, int oh, bool store_to
         // i-2 of level i-1 (compute_gradients: level l from octave[l+1], sift/siftfunctions.cu:53-63)
         float *grad = (i >= 2 && i <= 4) ? a->grad[o] + 2 * (size_t)(i - 2) * plane : nullptr;
         // level 5 is only ever read through DoG 4: its plane is not stored
-        rc = nm_launch_convolve((i < 5 || store_top) ? a->level[i] : nullptr, a->level[i - 1], nullptr, a->dog[i - 1], grad, ow, oh, a->taps[i - 1],
+        rc = nm_launch_convolve((i < 5 || store_top) ? a->level[i] : nullptr, a->level[i - 1], nullptr, a->dog[o][i - 1], grad, ow, oh, a->taps[i - 1],
                                 a->radii[i - 1], st);
     }
     if (o == 0) nm_prof_end(NM_PROF_PYRAMID_O0, st);
@@ -189,6 +202,9 @@ int nm_sift_detect_describe(nm_sift_arena *a, const float *gray, float *desc, fl
     da.num_octaves = P._num_octaves; da.num_dogs = P._num_dog_levels; da.book = a->book;
     da.kpts = kp; da.orients = ori; da.desc = desc; da.x = x; da.y = y;
 
+    // Fork/join inside the frame: the pyramid chain of all octaves runs on the caller's stream; extrema + ordered
+    // compaction of octave o run on the arena's side stream as soon as that octave's DoG planes exist, i.e. concurrently
+    // with the pyramid of octave o+1. Orientation + descriptors follow the join. Capture-safe (events only).
     for (int o = 0; o < P._num_octaves; ++o) {
         const int ow = a->width >> o, oh = a->height >> o;
         const float xper = (float)std::pow(2.0, o);
@@ -198,11 +214,13 @@ int nm_sift_detect_describe(nm_sift_arena *a, const float *gray, float *desc, fl
         }
         rc = octave_pyramid(a, o, ow, oh, false, st);
         if (rc) return rc;
+        NM_RETURN_IF(hipEventRecord(a->ev_pyr[o], st));
+        NM_RETURN_IF(hipStreamWaitEvent(a->side, a->ev_pyr[o], 0));
 
         const int nseg = nm_divup(ow, 256);
         const int n_blocks = oh * nseg;
         NmDetectArgs d{};
-        for (int i = 0; i < 5; ++i) d.dog[i] = a->dog[i];
+        for (int i = 0; i < 5; ++i) d.dog[i] = a->dog[o][i];
         d.ow = ow; d.oh = oh; d.peak = P._peak_threshold; d.edge = P._edge_threshold; d.xper = xper;
         d.sigma0 = P._sigma_0; d.num_dogs = P._num_dog_levels; d.staging = a->staging; d.stage_stride = a->stage_stride;
         d.counts = a->counts; d.n_blocks = n_blocks; d.nseg = nseg;
@@ -212,11 +230,13 @@ int nm_sift_detect_describe(nm_sift_arena *a, const float *gray, float *desc, fl
         NmGatherArgs g{};
         g.staging = a->staging; g.stage_stride = a->stage_stride; g.counts = a->counts; g.offsets = a->offsets;
         g.n_blocks = n_blocks; g.octave = o; g.book = a->book; g.kpts = kp;
-        rc = nm_launch_detect_octave(d, s, g, st);
+        rc = nm_launch_detect_octave(d, s, g, a->side);
         if (rc) return rc;
 
         da.geom[o].grad = a->grad[o]; da.geom[o].ow = ow; da.geom[o].oh = oh; da.geom[o].xper = xper;
     }
+    NM_RETURN_IF(hipEventRecord(a->ev_join, a->side));
+    NM_RETURN_IF(hipStreamWaitEvent(st, a->ev_join, 0));
     return nm_launch_frame_describe(da, st);
 }
 
