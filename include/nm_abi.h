@@ -158,6 +158,32 @@ NM_API int nm_align_points(const float *src_x, const float *src_y, const float *
                            float *c_src_x, float *c_src_y, float *c_dst_x, float *c_dst_y, const int *matches,
                            int num_pts, void *stream);
 
+/* ---- N3/N4 warps. The reference samples cudaTextureObject_t's made by CudaTex2D (utils/cudatex2D.cu:13-19: border
+ * addressing, linear filter, unnormalised coordinates, normalised-float reads). Here a texture is a device plane
+ * (pointer, width, height, texel format); the filter is done in software with the texture unit's 1/256 weights.   */
+#define NM_TEX_U8N 0      /* unsigned char, read as c/255          (cudaReadModeNormalizedFloat) */
+#define NM_TEX_U8X4N 1    /* uchar4, each channel read as c/255 */
+#define NM_TEX_F32 2      /* float, read as is                      (cudaReadModeElementType) */
+/* cuda_undistort (kernels/undistort.h:30-35, undistort.cu:7-64): camera_matrix = fx, fy, cx, cy; distortion_coeffs =
+ * k1, k2, k3 (device pointers, as in the reference). */
+NM_API int nm_undistort_map_f32(const float *x, const float *y, size_t cols, size_t rows, const float *camera_matrix,
+                                const float *distortion_coeffs, float *u, float *v, void *stream);
+/* resample_undistort (kernels/resample.h:34-38, resample.cu:100-113,234-248): tex(x+.5, y+.5) * 255.9999f */
+NM_API int nm_resample_undistort_f32(const void *tex, int tex_width, int tex_height, int tex_format, const float *x,
+                                     const float *y, size_t cols, size_t rows, float *undistorted, void *stream);
+/* resample_mask (resample.h:12-14, resample.cu:69-82,207-216) */
+NM_API int nm_resample_mask_u8(unsigned char *result, const void *tex, int tex_width, int tex_height, int tex_format,
+                               int cols, int rows, const float *x_pos, const float *y_pos, float threshold, void *stream);
+/* resample_perspective_transform (resample.h:7-10, resample.cu:84-98,116-204): fills x_pos / y_pos with the (inverse)
+ * projective map of the pixel grid and samples the uchar4 texture there; one launch instead of two. */
+NM_API int nm_resample_perspective_u8x4(unsigned char *result, const unsigned char *tex, int tex_width, int tex_height,
+                                        int cols, int rows, float *x_pos, float *y_pos, const float *mat3x3, int inverse,
+                                        void *stream);
+/* transform_blend (resample.h:16-20, resample.cu:7-66,218-232): frame (uchar4), frame_mask and frame_wts are fw x fh. */
+NM_API int nm_transform_blend(unsigned char *canvas, int cw, int ch, const unsigned char *frame, int fw, int fh, int nw,
+                              int nh, const float *mat3x3, int tx, int ty, const void *frame_mask, int mask_format,
+                              float *canvas_wts, const void *frame_wts, int wts_format, void *stream);
+
 /* RANSAC hypothesis evaluation (kernels/ransac.cu:430-521 kernels + the max_element/copy of :523-694).
  * model: 0 translation (1 sample per hypothesis), 1 similarity (2), 2 homography (4). rand_list: DEVICE array of
  * iterations * samples point indices (the reference draws them on the host, ransac.cu:543-551; see the C++ wrappers).

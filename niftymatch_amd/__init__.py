@@ -49,6 +49,11 @@ _SIGNATURES = {
     "nm_cast_f32_u8": (_I, [_P, _SZ, _SZ, _P, C.c_ubyte, _P]),
     "nm_downsample2_u8x4": (_I, [_P, _I, _I, _P, _I, _I, _P]),
     "nm_align_points": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "nm_undistort_map_f32": (_I, [_P, _P, _SZ, _SZ, _P, _P, _P, _P, _P]),
+    "nm_resample_undistort_f32": (_I, [_P, _I, _I, _I, _P, _P, _SZ, _SZ, _P, _P]),
+    "nm_resample_mask_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P]),
+    "nm_resample_perspective_u8x4": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
+    "nm_transform_blend": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P, _P, _I, _P]),
     "nm_ransac_f32": (_I, [_I, _P, _P, _P, _P, _I, _P, _I, _F, _P, _P, _P, _P, _P]),
     "nm_ransac_seed": (None, [C.c_uint]),
     "nm_sift_arena_create": (_I, [_I, _I, _I, _P]),
@@ -356,6 +361,72 @@ def align_points(sx, sy, dx, dy, matches):
     _check(lib().nm_align_points(_dev(sx), _dev(sy), _dev(dx), _dev(dy), *[_dev(o) for o in outs],
                                  _dev(matches, torch.int32), n, _stream()), "nm_align_points")
     return outs
+
+
+TEX_U8N, TEX_U8X4N, TEX_F32 = 0, 1, 2
+
+
+def _tex_format(t):
+    torch = _torch()
+    if t.dtype == torch.float32 and t.dim() == 2:
+        return TEX_F32
+    if t.dtype == torch.uint8 and t.dim() == 2:
+        return TEX_U8N
+    raise NmError("a scalar texture must be a 2-D float32 or uint8 device tensor")
+
+
+def undistort_map(x, y, camera_matrix, distortion_coeffs):
+    """cuda_undistort: per-pixel source coordinates (u, v) of the radial model. camera_matrix = (fx, fy, cx, cy) and
+    distortion_coeffs = (k1, k2, k3) are device tensors, as in the reference."""
+    torch = _torch()
+    h, w = x.shape
+    u, v = torch.empty_like(x), torch.empty_like(y)
+    _check(lib().nm_undistort_map_f32(_dev(x, torch.float32), _dev(y, torch.float32), w, h,
+                                      _dev(camera_matrix, torch.float32), _dev(distortion_coeffs, torch.float32), _dev(u),
+                                      _dev(v), _stream()), "nm_undistort_map_f32")
+    return u, v
+
+
+def resample_undistort(tex, x, y):
+    torch = _torch()
+    h, w = x.shape
+    out = torch.empty((h, w), dtype=torch.float32, device=x.device)
+    _check(lib().nm_resample_undistort_f32(_dev(tex), tex.shape[1], tex.shape[0], _tex_format(tex), _dev(x, torch.float32),
+                                           _dev(y, torch.float32), w, h, _dev(out), _stream()), "nm_resample_undistort_f32")
+    return out
+
+
+def resample_mask(tex, x_pos, y_pos, threshold=0.5):
+    torch = _torch()
+    h, w = x_pos.shape
+    out = torch.empty((h, w), dtype=torch.uint8, device=x_pos.device)
+    _check(lib().nm_resample_mask_u8(_dev(out), _dev(tex), tex.shape[1], tex.shape[0], _tex_format(tex), w, h,
+                                     _dev(x_pos, torch.float32), _dev(y_pos, torch.float32), threshold, _stream()),
+           "nm_resample_mask_u8")
+    return out
+
+
+def resample_perspective(tex_bgra, cols, rows, mat3x3, inverse=True):
+    """resample_perspective_transform: returns (result (rows, cols, 4) uint8, x_pos, y_pos)."""
+    torch = _torch()
+    out = torch.empty((rows, cols, 4), dtype=torch.uint8, device=tex_bgra.device)
+    xp = torch.empty((rows, cols), dtype=torch.float32, device=tex_bgra.device)
+    yp = torch.empty_like(xp)
+    _check(lib().nm_resample_perspective_u8x4(_dev(out), _dev(tex_bgra, torch.uint8), tex_bgra.shape[1], tex_bgra.shape[0],
+                                              cols, rows, _dev(xp), _dev(yp), _dev(mat3x3, torch.float32),
+                                              1 if inverse else 0, _stream()), "nm_resample_perspective_u8x4")
+    return out, xp, yp
+
+
+def transform_blend(canvas, canvas_wts, frame, nw, nh, mat3x3, tx, ty, frame_mask, frame_wts):
+    """transform_blend: blends the warped frame into `canvas` / `canvas_wts` IN PLACE."""
+    torch = _torch()
+    ch, cw, _ = canvas.shape
+    fh, fw, _ = frame.shape
+    _check(lib().nm_transform_blend(_dev(canvas, torch.uint8), cw, ch, _dev(frame, torch.uint8), fw, fh, nw, nh,
+                                    _dev(mat3x3, torch.float32), tx, ty, _dev(frame_mask), _tex_format(frame_mask),
+                                    _dev(canvas_wts, torch.float32), _dev(frame_wts), _tex_format(frame_wts), _stream()),
+           "nm_transform_blend")
 
 
 def ransac(model, sx, sy, dx, dy, rand_list, thr):

@@ -13,7 +13,9 @@
 #include "../match.h"
 #include "../orientation.h"
 #include "../ransac.h"
+#include "../resample.h"
 #include "../transpose.h"
+#include "../undistort.h"
 
 template <typename TYPE>
 void convolve(TYPE *result, const TYPE *image, TYPE *buffer, const int width, const int height, const float *kernel,
@@ -169,4 +171,48 @@ void align_points(const float *src_x, const float *src_y, const float *dst_x, co
 {
     nm_check(nm_align_points(src_x, src_y, dst_x, dst_y, c_src_x, c_src_y, c_dst_x, c_dst_y, matches, num_pts, stream),
              "Align points launch failed");
+}
+
+// ---- N3/N4: undistort.h, resample.h ----
+void cuda_undistort(const float *x, const float *y, const size_t cols, const size_t rows, const float *camera_matrix,
+                    const float *distortion_coeffs, float *u, float *v, hipStream_t stream)
+{
+    nm_check(nm_undistort_map_f32(x, y, cols, rows, camera_matrix, distortion_coeffs, u, v, stream),
+             "Undistort kernel launch failed");
+}
+
+void resample_undistort(NmTexture tex, const float *x, const float *y, const size_t cols, const size_t rows,
+                        float *undistorted, hipStream_t stream)
+{
+    nm_check(nm_resample_undistort_f32(tex.data, tex.width, tex.height, tex.format, x, y, cols, rows, undistorted, stream),
+             "Resample 2D image kernel launch failed for undistort");
+}
+
+void resample_mask(unsigned char *result, NmTexture text, const int cols, const int rows, const float *x_pos,
+                   const float *y_pos, const float threshold, hipStream_t stream)
+{
+    nm_check(nm_resample_mask_u8(result, text.data, text.width, text.height, text.format, cols, rows, x_pos, y_pos,
+                                 threshold, stream),
+             "Resample 2D mask launch failed");
+}
+
+void resample_perspective_transform(uchar4 *result, NmTexture text, const int cols, const int rows, float *x_pos,
+                                    float *y_pos, const float *mat3x3, bool inverse, hipStream_t stream)
+{
+    nm_check(text.format == NM_TEXEL_U8X4_NORM ? 0 : (int)hipErrorInvalidValue, "Resample 2D image needs a uchar4 texture");
+    nm_check(nm_resample_perspective_u8x4(reinterpret_cast<unsigned char *>(result),
+                                          static_cast<const unsigned char *>(text.data), text.width, text.height, cols,
+                                          rows, x_pos, y_pos, mat3x3, inverse ? 1 : 0, stream),
+             "Resample 2D image launch failed");
+}
+
+void transform_blend(uchar4 *canvas, const int cw, const int ch, NmTexture frame, const int fw, const int fh, const int nw,
+                     const int nh, const float *mat3x3, const int tx, const int ty, NmTexture frame_mask,
+                     float *canvas_wts, NmTexture frame_wts, hipStream_t stream)
+{
+    nm_check(frame.format == NM_TEXEL_U8X4_NORM ? 0 : (int)hipErrorInvalidValue, "Blend needs a uchar4 frame texture");
+    nm_check(nm_transform_blend(reinterpret_cast<unsigned char *>(canvas), cw, ch,
+                                static_cast<const unsigned char *>(frame.data), fw, fh, nw, nh, mat3x3, tx, ty,
+                                frame_mask.data, frame_mask.format, canvas_wts, frame_wts.data, frame_wts.format, stream),
+             "Blend launch failed");
 }

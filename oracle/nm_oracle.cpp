@@ -21,6 +21,7 @@
  */
 #include "nmo_math.h"
 #include "nmo_ransac.h"
+#include "nmo_warp.h"
 
 #include <algorithm>
 #include <cmath>
@@ -648,6 +649,83 @@ NMO_API void nmo_align_points(const float *sx, const float *sy, const float *dx,
         if (m != -1) { csx[i] = sx[i]; csy[i] = sy[i]; cdx[i] = dx[m]; cdy[i] = dy[m]; }
         else { csx[i] = -1; csy[i] = -1; cdx[i] = -1; cdy[i] = -1; }
     }
+}
+
+/* ---------------------------------------------------------------------------------------------------------- */
+/* N3/N4 warps: undistortion map, texture resampling, perspective warp, mosaicking blend (see nmo_warp.h).      */
+/* cuda_undistort -- kernels/undistort.cu:7-46,48-64 */
+NMO_API void nmo_undistort_map(const float *x, const float *y, size_t cols, size_t rows, const float *camera_matrix,
+                               const float *distortion_coeffs, float *u, float *v)
+{
+    const float k1 = distortion_coeffs[0], k2 = distortion_coeffs[1], k3 = distortion_coeffs[2];
+    const float fx = camera_matrix[0], fy = camera_matrix[1], cx = camera_matrix[2], cy = camera_matrix[3];
+    for (size_t p = 0; p < cols * rows; ++p) nmo_undistort_point(x[p], y[p], fx, fy, cx, cy, k1, k2, k3, u[p], v[p]);
+}
+/* resample_undistort -- resample.cu:100-113,234-248: out = tex(x+0.5, y+0.5) * 255.9999f */
+NMO_API void nmo_resample_undistort(const void *tex, int tw, int th, int fmt, const float *x, const float *y,
+                                    size_t cols, size_t rows, float *out)
+{
+    const nmo_tex t{tex, tw, th, fmt};
+    for (size_t p = 0; p < cols * rows; ++p) out[p] = nmo_tex2d(t, x[p] + 0.5f, y[p] + 0.5f, 0) * 255.9999f;
+}
+/* resample_mask -- resample.cu:69-82,207-216 */
+NMO_API void nmo_resample_mask(unsigned char *result, const void *tex, int tw, int th, int fmt, int cols, int rows,
+                               const float *x, const float *y, float threshold)
+{
+    const nmo_tex t{tex, tw, th, fmt};
+    for (size_t p = 0; p < (size_t)cols * rows; ++p) {
+        const float r = nmo_tex2d(t, x[p] + 0.5f, y[p] + 0.5f, 0);
+        result[p] = (r <= threshold) ? 0 : (unsigned char)(r * 255.999f);
+    }
+}
+/* resample_perspective_transform -- resample.cu:84-98,116-204: fills x_pos / y_pos, then samples the uchar4 texture */
+NMO_API void nmo_resample_perspective(unsigned char *result, const unsigned char *tex, int tw, int th, int cols, int rows,
+                                      float *x_pos, float *y_pos, const float *mat3x3, int inverse)
+{
+    float m[9];
+    if (inverse) nmo_invert3x3(mat3x3, m);
+    else for (int k = 0; k < 9; ++k) m[k] = mat3x3[k];
+    const nmo_tex t{tex, tw, th, NMO_TEX_U8X4N};
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            const size_t p = (size_t)y * cols + x;
+            nmo_project(m, (float)x, (float)y, x_pos[p], y_pos[p]);
+            for (int c = 0; c < 4; ++c)
+                result[4 * p + c] = (unsigned char)(nmo_tex2d(t, x_pos[p] + 0.5f, y_pos[p] + 0.5f, c) * 255.9999f);
+        }
+}
+/* transform_blend -- resample.cu:7-66,218-232. frame (uchar4), frame_mask and frame_wts are fw x fh textures. */
+NMO_API void nmo_transform_blend(unsigned char *canvas, int cw, int ch, const unsigned char *frame, int fw, int fh, int nw,
+                                 int nh, const float *mat3x3, int tx, int ty, const void *mask, int mask_fmt,
+                                 float *canvas_wts, const void *wts, int wts_fmt)
+{
+    const nmo_tex tf{frame, fw, fh, NMO_TEX_U8X4N}, tm{mask, fw, fh, mask_fmt}, tw_{wts, fw, fh, wts_fmt};
+    for (int y = 0; y < nh; ++y)
+        for (int x = 0; x < nw; ++x) {
+            const int px = x + tx, py = y + ty;
+            if (px < 0 || px >= cw || py < 0 || py >= ch) continue;
+            float xp, yp;
+            nmo_project(mat3x3, (float)x, (float)y, xp, yp);
+            if (xp >= (float)fw || yp >= (float)fh) continue;
+            const float u = xp + 0.5f, v = yp + 0.5f;
+            if (nmo_tex2d(tm, u, v, 0) <= 0.5f) continue;
+            const float nwt = nmo_tex2d(tw_, u, v, 0);
+            const size_t idx = (size_t)py * cw + px;
+            float res[3];
+            for (int c = 0; c < 3; ++c) res[c] = nmo_tex2d(tf, u, v, c);
+            if (canvas_wts[idx] == 0) {
+                for (int c = 0; c < 3; ++c) canvas[4 * idx + c] = (unsigned char)(res[c] * 255.9999f);
+                canvas[4 * idx + 3] = 255;
+                canvas_wts[idx] = nwt;
+            } else {
+                const float cwt = canvas_wts[idx], sum = cwt + nwt;
+                for (int c = 0; c < 3; ++c)
+                    canvas[4 * idx + c] =
+                        (unsigned char)(std::fmaf(res[c] * nwt, 255.9999f, (float)canvas[4 * idx + c] * cwt) / sum);
+                canvas[4 * idx + 3] = 255;
+                canvas_wts[idx] = cwt + nwt;
+            }
+        }
 }
 
 /* ---------------------------------------------------------------------------------------------------------- */

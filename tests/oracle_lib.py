@@ -19,7 +19,7 @@ class Params(C.Structure):
 
 
 def build():
-    src = [os.path.join(_ORACLE_DIR, f) for f in ("nm_oracle.cpp", "nmo_math.h", "nmo_ransac.h", "Makefile")]
+    src = [os.path.join(_ORACLE_DIR, f) for f in ("nm_oracle.cpp", "nmo_math.h", "nmo_ransac.h", "nmo_warp.h", "Makefile")]
     if (not os.path.exists(_LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src):
         subprocess.check_call(["make", "-C", _ORACLE_DIR], stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -282,3 +282,73 @@ def ransac(model, sx, sy, dx, dy, rand_list, thr):
     pos = lib().nmo_ransac(C.c_int(model), _fp(sx), _fp(sy), _fp(dx), _fp(dy), C.c_int(len(sx)), _fp(rl), C.c_int(it),
                            C.c_float(thr), _fp(H_all), _fp(inl), _fp(Hb))
     return pos, Hb, H_all, inl
+
+
+# ---- N3/N4 warps (oracle/nmo_warp.h) ----
+TEX_U8N, TEX_U8X4N, TEX_F32 = 0, 1, 2
+
+
+def _tex(t):
+    t = np.ascontiguousarray(t)
+    if t.dtype == np.float32 and t.ndim == 2:
+        return t, TEX_F32
+    if t.dtype == np.uint8 and t.ndim == 2:
+        return t, TEX_U8N
+    if t.dtype == np.uint8 and t.ndim == 3 and t.shape[2] == 4:
+        return t, TEX_U8X4N
+    raise ValueError("unsupported texture")
+
+
+def undistort_map(x, y, cam, dist):
+    x, y = _f32(x), _f32(y)
+    h, w = x.shape
+    u, v = np.empty_like(x), np.empty_like(y)
+    lib().nmo_undistort_map(_fp(x), _fp(y), C.c_size_t(w), C.c_size_t(h), _fp(_f32(cam)), _fp(_f32(dist)), _fp(u), _fp(v))
+    return u, v
+
+
+def resample_undistort(tex, x, y):
+    tex, fmt = _tex(tex)
+    x, y = _f32(x), _f32(y)
+    h, w = x.shape
+    out = np.empty((h, w), np.float32)
+    lib().nmo_resample_undistort(_fp(tex), C.c_int(tex.shape[1]), C.c_int(tex.shape[0]), C.c_int(fmt), _fp(x), _fp(y),
+                                 C.c_size_t(w), C.c_size_t(h), _fp(out))
+    return out
+
+
+def resample_mask(tex, x, y, threshold=0.5):
+    tex, fmt = _tex(tex)
+    x, y = _f32(x), _f32(y)
+    h, w = x.shape
+    out = np.empty((h, w), np.uint8)
+    lib().nmo_resample_mask(_fp(out), _fp(tex), C.c_int(tex.shape[1]), C.c_int(tex.shape[0]), C.c_int(fmt), C.c_int(w),
+                            C.c_int(h), _fp(x), _fp(y), C.c_float(threshold))
+    return out
+
+
+def resample_perspective(tex, cols, rows, mat, inverse=True):
+    tex, fmt = _tex(tex)
+    assert fmt == TEX_U8X4N
+    out = np.empty((rows, cols, 4), np.uint8)
+    xp, yp = np.empty((rows, cols), np.float32), np.empty((rows, cols), np.float32)
+    lib().nmo_resample_perspective(_fp(out), _fp(tex), C.c_int(tex.shape[1]), C.c_int(tex.shape[0]), C.c_int(cols),
+                                   C.c_int(rows), _fp(xp), _fp(yp), _fp(_f32(mat).reshape(9)), C.c_int(1 if inverse else 0))
+    return out, xp, yp
+
+
+def transform_blend(canvas, canvas_wts, frame, nw, nh, mat, tx, ty, mask, wts):
+    """Returns updated COPIES of (canvas, canvas_wts)."""
+    canvas = np.ascontiguousarray(canvas, dtype=np.uint8).copy()
+    canvas_wts = _f32(canvas_wts).copy()
+    frame, ffmt = _tex(frame)
+    assert ffmt == TEX_U8X4N
+    mask, mfmt = _tex(mask)
+    wts, wfmt = _tex(wts)
+    ch, cw, _ = canvas.shape
+    fh, fw, _ = frame.shape
+    assert mask.shape == (fh, fw) and wts.shape == (fh, fw)
+    lib().nmo_transform_blend(_fp(canvas), C.c_int(cw), C.c_int(ch), _fp(frame), C.c_int(fw), C.c_int(fh), C.c_int(nw),
+                              C.c_int(nh), _fp(_f32(mat).reshape(9)), C.c_int(tx), C.c_int(ty), _fp(mask), C.c_int(mfmt),
+                              _fp(canvas_wts), _fp(wts), C.c_int(wfmt))
+    return canvas, canvas_wts

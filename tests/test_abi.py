@@ -46,7 +46,7 @@ def test_cpp_headers_mirror_reference_names():
     """Every header a client of the hot path includes by name exists, flat, like ${prefix}/include/nm."""
     need = ["macros.h", "exception.h", "siftparams.h", "pyramidata.h", "siftdata.h", "siftfunctions.h", "convolution.h",
             "downsample.h", "cudamath.h", "keypoint.h", "orientation.h", "descriptor.h", "match.h", "transpose.h",
-            "cudatimer.h", "cudautils.h", "bgra_2_gray.h", "cast.h", "ransac.h"]
+            "cudatimer.h", "cudautils.h", "bgra_2_gray.h", "cast.h", "ransac.h", "cudatex2D.h", "resample.h", "undistort.h"]
     have = os.listdir(os.path.join(ROOT, "niftymatch_amd", "nm"))
     assert not [h for h in need if h not in have]
     cfg = open(os.path.join(ROOT, "niftymatch_amd", "cmake", "NiftyMatchConfig.cmake")).read()
@@ -85,9 +85,11 @@ def test_cmake_find_package_dropin(tmp_path, nm):
         "ADD_DEFINITIONS(-D__HIP_PLATFORM_AMD__)\nADD_EXECUTABLE(app main.cpp)\n"
         "TARGET_LINK_LIBRARIES(app ${NiftyMatch_LIBS})\n")
     (src / "main.cpp").write_text(
-        '#include "siftfunctions.h"\n#include "convolution.h"\n#include "match.h"\n#include "cudamath.h"\n#include "macros.h"\n#include <cstdio>\n'
+        '#include "siftfunctions.h"\n#include "convolution.h"\n#include "match.h"\n#include "cudamath.h"\n#include "macros.h"\n#include "resample.h"\n#include "undistort.h"\n#include <cstdio>\n'
         "int main() { SiftParams p(1920, 1080); std::printf(\"%d %zu %d\\n\", p._num_octaves, p._sigmas.size(), DivUp(7, 2));\n"
-        "  if (p._num_octaves < 0) { PyramidData py(p); SiftData d(16); compute_dog(py, 8, 8); compute_sift_matches(&d, &d, nullptr); }\n"
+        "  if (p._num_octaves < 0) { PyramidData py(p); SiftData d(16); compute_dog(py, 8, 8); compute_sift_matches(&d, &d, nullptr);\n"
+        "    CudaTex2D t((const uchar4 *)nullptr, 4, 4); resample_perspective_transform(nullptr, t, 4, 4, nullptr, nullptr, nullptr);\n"
+        "    cuda_undistort(nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr); }\n"
         "  return 0; }\n")
     build = tmp_path / "build"
     build.mkdir()
