@@ -56,6 +56,11 @@ NM_API int nm_fill_u32(void *dst, size_t count, unsigned int pattern, void *stre
 #define NM_PROF_SITES 2
 NM_API int nm_profile_events(int site, void *start_event, void *stop_event);
 
+/* Self-test (no reference counterpart): the gradient's fast correctly-rounded square root is compared with the IEEE
+ * expansion for EVERY float of its domain [2^-96, 2^96) and 0; *d_mismatches (device) receives the number of differing
+ * inputs. Must be 0. */
+NM_API int nm_selftest_sqrt(unsigned long long *d_mismatches, void *stream);
+
 /* ---- host-side scale-space constants ---- */
 /* PyramidData::create_kernel_for_sigma (sift/pyramidata.cu:105-123). HOST function: writes 2*radius+1 normalised
  * taps to host memory `taps` (may be NULL to query) and returns radius = ceil(4*sigma).                          */

@@ -49,6 +49,7 @@ _SIGNATURES = {
     "nm_cast_f32_u8": (_I, [_P, _SZ, _SZ, _P, C.c_ubyte, _P]),
     "nm_downsample2_u8x4": (_I, [_P, _I, _I, _P, _I, _I, _P]),
     "nm_align_points": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "nm_selftest_sqrt": (_I, [_P, _P]),
     "nm_undistort_map_f32": (_I, [_P, _P, _SZ, _SZ, _P, _P, _P, _P, _P]),
     "nm_resample_undistort_f32": (_I, [_P, _I, _I, _I, _P, _P, _SZ, _SZ, _P, _P]),
     "nm_resample_mask_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P]),
@@ -361,6 +362,14 @@ def align_points(sx, sy, dx, dy, matches):
     _check(lib().nm_align_points(_dev(sx), _dev(sy), _dev(dx), _dev(dy), *[_dev(o) for o in outs],
                                  _dev(matches, torch.int32), n, _stream()), "nm_align_points")
     return outs
+
+
+def selftest_sqrt():
+    """Number of inputs for which the gradient's fast sqrt differs from IEEE sqrt over its whole domain (must be 0)."""
+    torch = _torch()
+    out = torch.zeros(1, dtype=torch.int64, device="cuda")
+    _check(lib().nm_selftest_sqrt(_dev(out), _stream()), "nm_selftest_sqrt")
+    return int(out.item())
 
 
 TEX_U8N, TEX_U8X4N, TEX_F32 = 0, 1, 2

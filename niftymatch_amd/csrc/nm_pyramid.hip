@@ -2,6 +2,7 @@
 // gradient. Replaces kernels/convolution.cu:16-159, kernels/downsample.cu:6-29, kernels/cudamath.cu:26-80 of the
 // reference. All kernels are HBM/L2 streaming stencils; arithmetic order is fixed by the fp spec:
 //   conv: taps k = -r..r, sum = fma(x[k], w[r-k], sum) starting from +0, rows first, then columns, zero padding.
+#include <cstdlib>
 #include "nm_common.hpp"
 #include "nm_fpspec.hpp"
 #include "../../include/nm_abi.h"
@@ -172,6 +173,322 @@ __global__ __launch_bounds__(TH * 8) void conv_sep_kernel(float *__restrict__ re
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Packed-math variant of the fused separable Gaussian (the frame driver's path: no row-pass output, width % 4 == 0).
+// The launches that also produce the gradient are VALU-bound (~190 VALU instructions per output pixel in the kernel
+// above), so this version is organised around v_pk_fma_f32 (two fp32 FMAs per lane per issue) without changing a single
+// rounding: every output is still  sum = fma(x[k], w[r-k], sum)  from +0 in k order.
+//   * the input tile is staged ROW-PAIR INTERLEAVED: LDS holds (row 2p, row 2p+1) of one column side by side, so a
+//     b128 read yields two aligned (rowA, rowB) register pairs and the row pass of TWO rows runs as packed FMAs at
+//     every tap shift (adjacent-column packing would need unaligned register pairs at odd shifts);
+//   * the column pass packs two adjacent columns: a b64 read of the row-pass result is the aligned pair;
+//   * lanes of a quarter wave read LDS at strides chosen bank-conflict-free (pitch = IN_W + 2 column pairs);
+//   * the gradient uses a correctly rounded sqrt built from v_rsq_f32 + two exact-residual corrections (validated
+//     against the IEEE expansion for every float of its domain by nm_selftest_sqrt), the single-subtraction form of
+//     mod_2pi, and 0.5f*x for (float)(0.5*(double)x) (exact scaling).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+namespace {
+
+__device__ __forceinline__ v2f pk_fma(v2f a, float w, v2f c)
+{
+    const v2f ww = {w, w};
+    return __builtin_elementwise_fma(a, ww, c);
+}
+
+// RN(sqrt(s)) for s = 0 or 2^-96 <= s < 2^96 without the denormal-safe expansion; other inputs take the IEEE path.
+__device__ __forceinline__ float sqrt_rn_fast_core(float s)
+{
+    const float e = __builtin_amdgcn_rsqf(__builtin_fmaxf(s, 0x1p-100f));
+    float y = s * e;
+    const float h = 0.5f * e;
+    y = fma32(fma32(-y, y, s), h, y);
+    y = fma32(fma32(-y, y, s), h, y);
+    return y;
+}
+__device__ __forceinline__ float sqrt_rn(float s)
+{
+    if (__builtin_expect((s >= 0x1p-96f || s == 0.0f) && s < 0x1p96f, 1)) return sqrt_rn_fast_core(s);
+    return __builtin_sqrtf(s);
+}
+
+// (magnitude, angle) of kernels/cudamath.cu:38-54 from the 4-neighbourhood; same value sequence as gradient_kernel
+__device__ __forceinline__ float2 grad_of(float xm, float xp, float ym, float yp)
+{
+    const float dx = xp - xm, dy = yp - ym;
+    const float g = 0.5f * sqrt_rn(fma32(dx, dx, dy * dy));
+    float r = 0.f;
+    if (g != 0.0f) {
+        r = (float)((double)nmfp::atan2f_spec(dy, dx) + nmfp::TWO_PI_D);      // in [pi, 3 pi]
+        if (r > nmfp::TWO_PI_F) r -= nmfp::TWO_PI_F;                          // mod_2pi_f: one subtraction suffices
+    }
+    return make_float2(g, r);
+}
+
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat(float c) { return (v2f){c, c}; }
+
+// num / den by the instruction sequence of the IEEE expansion (rcp, one refinement, two quotient corrections) without its
+// range scaling and special-case fix-up: identical result whenever neither is needed -- den in [2^-49, 2^49] and num = 0
+// or |num| >= 2^-100 (below that the exact residuals leave the normal range). Smaller numerators may give a different
+// quotient, which grad_pair tolerates (see there). Checked against `/` by nm_selftest_sqrt.
+__device__ __forceinline__ v2f div_pair(v2f num, v2f den)
+{
+    v2f rc = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    rc = fma2(fma2(-den, rc, splat(1.0f)), rc, rc);
+    v2f q = num * rc;
+    q = fma2(fma2(-den, q, num), rc, q);
+    q = fma2(fma2(-den, q, num), rc, q);
+    return q;
+}
+
+// Branch-free, packed evaluation of grad_of for two pixels. `ok` is false when an input leaves the domain on which the
+// shortcuts are proven equal to the generic sequence (dx^2+dy^2 = 0 or in [2^-96, 2^96)); the caller then redoes the
+// pixel with grad_of. Inside the domain den >= 2^-48.5, so a numerator below 2^-100 means a quotient below 2^-51; such a
+// quotient only ever arises where it is added to pi/2 (c1) or, in binary64, to 2 pi (third range), and is absorbed by
+// the rounding there whatever its low bits are (the cancelling numerator ay - ax of the middle range is 0 or >= 2^-72).
+__device__ __forceinline__ bool grad_pair(v2f xm, v2f xp, v2f ym, v2f yp, v2f &g, v2f &r)
+{
+    const v2f dx = xp - xm, dy = yp - ym;
+    const v2f s = fma2(dx, dx, dy * dy);
+    const bool ok = (s.x < 0x1p96f) && (s.x >= 0x1p-96f || s.x == 0.0f) && (s.y < 0x1p96f) && (s.y >= 0x1p-96f || s.y == 0.0f);
+    // magnitude: sqrt_rn_fast_core on both halves
+    const v2f e = {__builtin_amdgcn_rsqf(__builtin_fmaxf(s.x, 0x1p-100f)), __builtin_amdgcn_rsqf(__builtin_fmaxf(s.y, 0x1p-100f))};
+    const v2f h = e * splat(0.5f);
+    v2f y = s * e;
+    y = fma2(fma2(-y, y, s), h, y);
+    y = fma2(fma2(-y, y, s), h, y);
+    g = y * splat(0.5f);
+    // angle: nmfp::atan2f_spec with its three argument ranges selected per half
+    const v2f ax = {__builtin_fabsf(dx.x), __builtin_fabsf(dx.y)}, ay = {__builtin_fabsf(dy.x), __builtin_fabsf(dy.y)};
+    const v2f t1 = ax * splat(2.414213562373095f), t2 = ax * splat(0.4142135623730950f);
+    const v2f dif = ay - ax, sum = ay + ax;
+    v2f num, den, hi, lo;
+#define NM_SEL(F)                                                                                              \
+    {                                                                                                          \
+        const bool c1 = ay.F > t1.F, c2 = ay.F > t2.F;                                                         \
+        num.F = c1 ? -ax.F : (c2 ? dif.F : ay.F);                                                              \
+        den.F = c1 ? ay.F : (c2 ? sum.F : ax.F);                                                               \
+        hi.F = c1 ? 1.57079637050628662109375f : (c2 ? 0.785398185253143310546875f : 0.0f);                    \
+        lo.F = c1 ? -4.37113900018624283e-8f : (c2 ? -2.18556950009312142e-8f : 0.0f);                         \
+    }
+    NM_SEL(x)
+    NM_SEL(y)
+#undef NM_SEL
+    const v2f z = div_pair(num, den);
+    const v2f zz = z * z;
+    v2f p = fma2(splat(-0.06459416449069977f), zz, splat(0.10746313631534576f));
+    p = fma2(p, zz, splat(-0.14264234900474548f));
+    p = fma2(p, zz, splat(0.1999955028295517f));
+    p = fma2(p, zz, splat(-0.3333333134651184f));
+    p = p * zz;
+    p = fma2(p, z, z);
+    v2f a = hi + (p + lo);
+    const v2f alt = (splat(3.1415927410125732421875f) - a) + splat(-8.74227800037248566e-8f);
+    a.x = dx.x < 0.0f ? alt.x : a.x;
+    a.y = dx.y < 0.0f ? alt.y : a.y;
+    a.x = dy.x < 0.0f ? -a.x : a.x;
+    a.y = dy.y < 0.0f ? -a.y : a.y;
+    v2f t = {(float)((double)a.x + nmfp::TWO_PI_D), (float)((double)a.y + nmfp::TWO_PI_D)};
+    const v2f tw = t - splat(nmfp::TWO_PI_F);
+    t.x = t.x > nmfp::TWO_PI_F ? tw.x : t.x;
+    t.y = t.y > nmfp::TWO_PI_F ? tw.y : t.y;
+    r.x = g.x != 0.0f ? t.x : 0.0f;
+    r.y = g.y != 0.0f ? t.y : 0.0f;
+    return ok;
+}
+
+}  // namespace
+
+template <int R, bool WRITE_DOG, bool WRITE_GRAD, int EXP = 0>
+__global__ __launch_bounds__(256) void conv_pk_kernel(float *__restrict__ result, const float *__restrict__ image,
+                                                     float *__restrict__ dog, float2 *__restrict__ grad, int width,
+                                                     int height, const float *__restrict__ taps, int tiles_x, int ntiles)
+{
+    constexpr int TW = 64, TH = 32;
+    constexpr int RA = (R + 3) & ~3;
+    constexpr int IN_W = TW + 2 * RA;             // staged columns (image x = x0 - RA + c)
+    constexpr int IN_P2 = IN_W + 2;               // pitch in column PAIRS-of-rows; (2*IN_P2) % 32 == 4*odd: see above
+    constexpr int ROWS = TH + 2 * R;              // even
+    constexpr int RP = ROWS / 2;                  // row pairs; <= 32
+    constexpr int MID_P = TW + 4;                 // row-pass result pitch (16-byte aligned rows, skewed banks)
+    constexpr int OFF = RA - R;                   // first staged column the taps touch (for output column 0)
+    constexpr int W0 = OFF & ~1;                  // even start of the b128 window
+    constexpr int D = OFF - W0;
+    constexpr int NC = (8 + 2 * R + D + 1) & ~1;  // window columns per task (even)
+    constexpr int V = IN_W / 4;
+    constexpr int NLOAD = (RP * V + 255) / 256;
+    static_assert(RP <= 32 && (IN_P2 % 2) == 0, "tile geometry");
+    __shared__ __attribute__((aligned(16))) float s_in[RP * IN_P2 * 2];
+    __shared__ __attribute__((aligned(16))) float s_mid[ROWS * MID_P];
+
+    const int tid = threadIdx.x;
+    const int nxcd = 8;
+    const int xcd = blockIdx.x % nxcd, slot = blockIdx.x / nxcd;
+    const int band = (ntiles + nxcd - 1) / nxcd;
+    const int tile = xcd * band + slot;
+    if (slot >= band || tile >= ntiles) return;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int x0 = tx * TW, y0 = ty * TH;
+
+    float w[2 * R + 1];
+#pragma unroll
+    for (int i = 0; i <= 2 * R; ++i) w[i] = taps[i];
+
+    // phase 1: global -> LDS, two rows per thread, interleaved
+    {
+        float4 a[NLOAD], b[NLOAD];
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int t = tid + 256 * i;
+            const int p = t / V, c4 = t - p * V;
+            const int gy = y0 - R + 2 * p, gx = x0 - RA + 4 * c4;
+            a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            b[i] = a[i];
+            if (t < RP * V && gx >= 0 && gx < width) {
+                if (gy >= 0 && gy < height) a[i] = *reinterpret_cast<const float4 *>(image + (size_t)gy * width + gx);
+                if (gy + 1 >= 0 && gy + 1 < height) b[i] = *reinterpret_cast<const float4 *>(image + (size_t)(gy + 1) * width + gx);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int t = tid + 256 * i;
+            const int p = t / V, c4 = t - p * V;
+            if (t < RP * V) {
+                float4 *q = reinterpret_cast<float4 *>(&s_in[(p * IN_P2 + 4 * c4) * 2]);
+                q[0] = make_float4(a[i].x, b[i].x, a[i].y, b[i].y);
+                q[1] = make_float4(a[i].z, b[i].z, a[i].w, b[i].w);
+            }
+        }
+    }
+    __syncthreads();
+
+    // phase 2: rows. task = (row pair p, 8 output columns cg*8..): 16 outputs as 8 packed (rowA, rowB) accumulators
+    {
+        const int p = tid & 31, cg = tid >> 5;
+        if (p < RP) {
+            const v2f *src = reinterpret_cast<const v2f *>(&s_in[(p * IN_P2 + cg * 8 + W0) * 2]);
+            v2f win[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) win[j] = src[j];
+            v2f o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (v2f){0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t <= 2 * R; ++t) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = pk_fma(win[D + i + t], w[2 * R - t], o[i]);
+            }
+            float4 *qa = reinterpret_cast<float4 *>(&s_mid[(2 * p) * MID_P + cg * 8]);
+            float4 *qb = reinterpret_cast<float4 *>(&s_mid[(2 * p + 1) * MID_P + cg * 8]);
+            qa[0] = make_float4(o[0].x, o[1].x, o[2].x, o[3].x);
+            qa[1] = make_float4(o[4].x, o[5].x, o[6].x, o[7].x);
+            qb[0] = make_float4(o[0].y, o[1].y, o[2].y, o[3].y);
+            qb[1] = make_float4(o[4].y, o[5].y, o[6].y, o[7].y);
+        }
+    }
+    __syncthreads();
+
+    // phase 3: columns. task = (column pair xp, 4 output rows): 8 outputs as 4 packed (x, x+1) accumulators
+    {
+        constexpr int NY = 4;
+        const int xp = tid & 31, yg = tid >> 5;
+        v2f o[NY];
+        {
+            const float *src = &s_mid[(yg * NY) * MID_P + 2 * xp];
+            v2f win[NY + 2 * R];
+#pragma unroll
+            for (int j = 0; j < NY + 2 * R; ++j) win[j] = *reinterpret_cast<const v2f *>(src + j * MID_P);
+#pragma unroll
+            for (int i = 0; i < NY; ++i) o[i] = (v2f){0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t <= 2 * R; ++t) {
+#pragma unroll
+                for (int i = 0; i < NY; ++i) o[i] = pk_fma(win[i + t], w[2 * R - t], o[i]);
+            }
+        }
+        const int gx = x0 + 2 * xp;
+        if (gx < width) {
+            // input-level values around the 2 x 4 patch, from the interleaved tile: rows yy-1 .. yy+4, columns x-1 .. x+2
+            const int cc = RA + 2 * xp;
+            auto in_at = [&](int rr, int c) -> float { return s_in[((rr >> 1) * IN_P2 + c) * 2 + (rr & 1)]; };
+            v2f mid[NY + 2], lft[NY + 2], rgt[NY + 2];      // columns (x, x+1), (x-1, x), (x+1, x+2) of each row
+#pragma unroll
+            for (int j = 0; j < NY + 2; ++j) {
+                const int rr = yg * NY + R - 1 + j;
+                if (WRITE_GRAD || (j >= 1 && j <= NY)) mid[j] = (v2f){in_at(rr, cc), in_at(rr, cc + 1)};
+                if (WRITE_GRAD && j >= 1 && j <= NY) {
+                    lft[j] = (v2f){in_at(rr, cc - 1), in_at(rr, cc)};
+                    rgt[j] = (v2f){in_at(rr, cc + 1), in_at(rr, cc + 2)};
+                }
+            }
+            const unsigned row_bytes = (unsigned)width * 4u;
+            const bool in0 = gx >= 1, in1 = gx + 1 < width - 1;
+#pragma unroll
+            for (int i = 0; i < NY; ++i) {
+                const int gy = y0 + yg * NY + i;
+                if (gy < height) {
+                    const unsigned off = (unsigned)gy * row_bytes + (unsigned)gx * 4u;       // < 4 GiB: checked by the host
+                    if (result) *reinterpret_cast<float2 *>(reinterpret_cast<char *>(result) + off) = make_float2(o[i].x, o[i].y);
+                    if (WRITE_DOG) {
+                        const v2f d = o[i] - mid[i + 1];
+                        *reinterpret_cast<float2 *>(reinterpret_cast<char *>(dog) + off) = make_float2(d.x, d.y);
+                    }
+                    if (WRITE_GRAD) {
+                        v2f g, r;
+                        bool ok = true;
+                        if (EXP == 2) { g = rgt[i + 1] - lft[i + 1]; r = mid[i + 2] - mid[i]; }
+                        else ok = grad_pair(lft[i + 1], rgt[i + 1], mid[i], mid[i + 2], g, r);
+                        if (__builtin_expect(!ok, 0)) {      // out-of-domain input (denormal-range or huge differences)
+                            const float2 a = grad_of(lft[i + 1].x, rgt[i + 1].x, mid[i].x, mid[i + 2].x);
+                            const float2 b = grad_of(lft[i + 1].y, rgt[i + 1].y, mid[i].y, mid[i + 2].y);
+                            g = (v2f){a.x, b.x};
+                            r = (v2f){a.y, b.y};
+                        }
+                        const bool rowin = gy >= 1 && gy < height - 1;
+                        const bool k0 = rowin && in0, k1 = rowin && in1;
+                        if (EXP != 1 || g.x == 12345.678f)
+                        *reinterpret_cast<float4 *>(reinterpret_cast<char *>(grad) + 2 * (size_t)off) =
+                            make_float4(k0 ? g.x : 0.f, k0 ? r.x : 0.f, k1 ? g.y : 0.f, k1 ? r.y : 0.f);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Exhaustive self-test of sqrt_rn's fast path against the IEEE expansion (tests/test_gpu_stages.py).
+__global__ __launch_bounds__(256) void selftest_sqrt_kernel(unsigned long long *mismatches)
+{
+    const unsigned lo = 0x0F800000u /* 2^-96 */, hi = 0x6F800000u /* 2^96 */;
+    unsigned long long bad = 0;
+    for (unsigned long long u = lo + (unsigned long long)blockIdx.x * 256 + threadIdx.x; u < hi; u += (unsigned long long)gridDim.x * 256) {
+        const float s = __uint_as_float((unsigned)u);
+        if (__float_as_uint(sqrt_rn_fast_core(s)) != __float_as_uint(__builtin_sqrtf(s))) ++bad;
+    }
+    if (threadIdx.x == 0 && blockIdx.x == 0 && __float_as_uint(sqrt_rn_fast_core(0.0f)) != 0u) ++bad;
+    // div_pair against `/`: 2^31 pseudo-random (num, den) with den in [2^-49, 2^49), |num| >= 2^-100, |num/den| < 4
+    unsigned long long st = 0x9E3779B97F4A7C15ull * ((unsigned long long)blockIdx.x * 256 + threadIdx.x + 1);
+    for (int it = 0; it < 1024; ++it) {
+        float nd[4];
+        for (int k = 0; k < 2; ++k) {
+            st = st * 6364136223846793005ull + 1442695040888963407ull;
+            const unsigned a = (unsigned)(st >> 32), b = (unsigned)st;
+            const int ed = (int)((a >> 23) % 98u) - 49, eq = -(int)((b >> 23) % 102u) + 1;
+            const float den = __uint_as_float(((unsigned)(ed + 127) << 23) | (a & 0x7FFFFFu));
+            int en = ed + eq;
+            en = en < -100 ? -100 : en;
+            const float num = __uint_as_float(((unsigned)(en + 127) << 23) | (b & 0x7FFFFFu) | ((a >> 31) << 31));
+            nd[2 * k] = num; nd[2 * k + 1] = den;
+        }
+        const v2f q = div_pair((v2f){nd[0], nd[2]}, (v2f){nd[1], nd[3]});
+        const float q0 = nd[0] / nd[1], q1 = nd[2] / nd[3];
+        if (__float_as_uint(q.x) != __float_as_uint(q0)) ++bad;
+        if (__float_as_uint(q.y) != __float_as_uint(q1)) ++bad;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 // Any-radius fallback (two passes through global memory, one thread per pixel). Same arithmetic order.
 __global__ __launch_bounds__(256) void conv_rows_generic(float *__restrict__ out, const float *__restrict__ in,
                                                         int width, int height, const float *__restrict__ taps, int r)
@@ -234,10 +551,36 @@ static int launch_conv_rvt(float *result, const float *image, float *buffer, flo
     return 0;
 }
 
+template <int R>
+static int launch_conv_pk(float *result, const float *image, float *dog, float *grad, int width, int height,
+                          const float *taps, hipStream_t stream)
+{
+    const int tiles_x = nm_divup(width, 64), tiles_y = nm_divup(height, 32);
+    const int ntiles = tiles_x * tiles_y;
+    dim3 grid(((ntiles + 7) / 8) * 8);
+    float2 *g2 = reinterpret_cast<float2 *>(grad);
+#define NM_PK_LAUNCH(DOG, GRAD)                                                                                    \
+    hipLaunchKernelGGL((conv_pk_kernel<R, DOG, GRAD>), grid, dim3(256), 0, stream, result, image, dog, g2, width, \
+                       height, taps, tiles_x, ntiles)
+    static const int exp_mode = getenv("NM_EXP") ? atoi(getenv("NM_EXP")) : 0;
+    if (dog && grad && exp_mode == 1)
+        hipLaunchKernelGGL((conv_pk_kernel<R, true, true, 1>), grid, dim3(256), 0, stream, result, image, dog, g2, width, height, taps, tiles_x, ntiles);
+    else if (dog && grad && exp_mode == 2)
+        hipLaunchKernelGGL((conv_pk_kernel<R, true, true, 2>), grid, dim3(256), 0, stream, result, image, dog, g2, width, height, taps, tiles_x, ntiles);
+    else if (dog && grad) NM_PK_LAUNCH(true, true);
+    else if (dog) NM_PK_LAUNCH(true, false);
+    else NM_PK_LAUNCH(false, false);
+#undef NM_PK_LAUNCH
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int R, bool VEC>
 static int launch_conv_rv(float *result, const float *image, float *buffer, float *dog, float *grad, int width,
                           int height, const float *taps, hipStream_t stream)
 {
+    if (VEC && !buffer && !(grad && !dog) && (size_t)width * height * 4 < (1ull << 32))
+        return launch_conv_pk<R>(result, image, dog, grad, width, height, taps, stream);
     // 64 x 32 tiles with 256 threads, or 64 x 64 tiles with 512 threads (less halo re-reading and row-pass redundancy)
     // once the image has enough tiles to fill the chip that way.
     if (VEC && !buffer && (long)width * height >= 256L * 64 * 64)
@@ -336,6 +679,15 @@ int DivUp(int a, int b) { return ((a % b) != 0) ? (a / b + 1) : (a / b); }
 int DivDown(int a, int b) { return a / b; }
 int AlignUp(int a, int b) { return ((a % b) != 0) ? (a - a % b + b) : a; }
 int AlignDown(int a, int b) { return a - a % b; }
+
+int nm_selftest_sqrt(unsigned long long *d_mismatches, void *stream)
+{
+    if (!d_mismatches) return (int)hipErrorInvalidValue;
+    NM_RETURN_IF(hipMemsetAsync(d_mismatches, 0, sizeof(unsigned long long), nm_stream(stream)));
+    hipLaunchKernelGGL(selftest_sqrt_kernel, dim3(4096), dim3(256), 0, nm_stream(stream), d_mismatches);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
 
 int nm_convolve_f32(float *result, const float *image, float *buffer, int width, int height, const float *kernel,
                     int kernel_radius, void *stream)

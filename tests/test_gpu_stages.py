@@ -51,15 +51,42 @@ def test_downsample_subtract_gradient(nm, oracle, cuda):
     assert not nm.gradient(_t(flat, cuda)).cpu().numpy().any()
 
 
+def test_fast_sqrt_is_correctly_rounded_everywhere(nm):
+    """The packed Gaussian kernel's gradient uses rsq + two exact-residual corrections instead of the IEEE expansion:
+    exhaustive comparison over every float in [2^-96, 2^96) and 0."""
+    assert nm.selftest_sqrt() == 0
+
+
 def _octave(oracle, w, h, seed):
     lv0 = H.blurred_frame(seed, w, h, sigma=2.0)
     return oracle.octave_pyramid(lv0, 1920, 1080)
 
 
-def test_octave_pyramid_fused(nm, oracle, cuda):
+def _extreme_level0(w, h):
+    """Level-0 plane whose differences span the whole float range: decades of decay down to denormals (the gradient's
+    fast sqrt / division leave their proven domain there and must fall back), exact zeros, a huge plateau, a negative
+    zero, and isolated spikes next to flat areas (dx = 0 or dy = 0 exactly)."""
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = (200.0 * np.power(10.0, -(xx + 0.7 * yy) / 6.0)).astype(np.float32)        # reaches 0 via denormals
+    img[h // 2:, : w // 3] = 0.0
+    img[: h // 4, w // 2: w // 2 + 40] = np.float32(3e30)
+    img[h // 4: h // 4 + 3, w // 2: w // 2 + 40] = np.float32(1e-30)
+    img[5, 5] = -0.0
+    img[h - 20, w - 20] = 77.0
+    img[h - 40: h - 30, w - 60: w - 50] = np.float32(1e-20)
+    return np.ascontiguousarray(img)
+
+
+@pytest.mark.parametrize("kind", ["blurred", "extreme"])
+def test_octave_pyramid_fused(nm, oracle, cuda, kind):
     import torch
     w, h = 320, 200
-    levels, dogs, grad = _octave(oracle, w, h, 3)
+    if kind == "blurred":
+        levels, dogs, grad = _octave(oracle, w, h, 3)
+    else:
+        levels, dogs, grad = oracle.octave_pyramid(_extreme_level0(w, h), 1920, 1080)
+        g = np.asarray(grad)
+        assert ((g[..., 0] > 0) & (g[..., 0] < 1e-16)).any() and (g[..., 0] > 1e20).any()      # both fallback ends occur
     arena = nm.SiftArena(w, h, 1024)
     n = w * h
 
