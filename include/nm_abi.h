@@ -50,7 +50,7 @@ NM_API int nm_fill_u32(void *dst, size_t count, unsigned int pattern, void *stre
  * stop immediately after that kernel (sequence) on the stream it launches on. Pass NULLs to clear. Per host thread.
  *   NM_PROF_MATCH_TOP2 : the MFMA top-2 kernel inside nm_sift_match_f32 / nm_sift_match_shard_f32
  *   NM_PROF_PYRAMID_O0 : the octave-0 pyramid sequence (5 fused Gaussian + DoG + gradient launches) inside
- *                        nm_sift_detect_describe / nm_sift_octave_pyramid                                       */
+ *                        nm_sift_detect_describe[_batch] / nm_sift_octave_pyramid (all frames of a batch)       */
 #define NM_PROF_MATCH_TOP2 0
 #define NM_PROF_PYRAMID_O0 1
 #define NM_PROF_SITES 2
@@ -217,6 +217,16 @@ NM_API size_t nm_sift_arena_bytes(const nm_sift_arena *arena);
  * siftfunctions.cu:165-169). kpts (capacity float4) and orients (capacity float2) are optional (NULL).        */
 NM_API int nm_sift_detect_describe(nm_sift_arena *arena, const float *gray, float *desc, float *x, float *y,
                                    float *kpts, float *orients, int *d_num_items, void *stream);
+/* The same for n <= NM_SIFT_MAX_BATCH frames of equal size in ONE launch sequence (arrays of n pointers; arenas must be
+ * distinct; kpts, orients, d_num_items may be NULL or hold NULLs). The scale-space launches cover all frames at once --
+ * a single 1080p frame is only ~4 workgroups per CU at octave 0, a frame pair fills the chip -- while detection and
+ * description of the individual frames run concurrently on the arenas' internal side streams. Results are identical
+ * to n separate nm_sift_detect_describe calls. No reference counterpart (the reference processes one frame per call
+ * sequence, sift/siftfunctions.cu:42-181).                                                                        */
+#define NM_SIFT_MAX_BATCH 4
+NM_API int nm_sift_detect_describe_batch(nm_sift_arena *const *arenas, int n, const float *const *gray,
+                                         float *const *desc, float *const *x, float *const *y, float *const *kpts,
+                                         float *const *orients, int *const *d_num_items, void *stream);
 /* Pointers into the arena for stage-level inspection (tests, profiling): Gaussian level l (0..5) and DoG d (0..4)
  * planes of the LAST processed octave geometry are overwritten per octave, so these are meaningful only after
  * nm_sift_octave_pyramid().                                                                                      */

@@ -61,6 +61,7 @@ _SIGNATURES = {
     "nm_sift_arena_destroy": (None, [_P]),
     "nm_sift_arena_bytes": (_SZ, [_P]),
     "nm_sift_detect_describe": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "nm_sift_detect_describe_batch": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nm_sift_arena_level": (_P, [_P, _I]), "nm_sift_arena_dog": (_P, [_P, _I]), "nm_sift_arena_grad": (_P, [_P]),
     "nm_sift_octave_pyramid": (_I, [_P, _I, _I, _P]),
     "nm_client_detect_describe": (_I, [_P, _I, _I, _I, _P, _P, _P]),
@@ -451,6 +452,29 @@ def ransac(model, sx, sy, dx, dy, rand_list, thr):
                                _dev(rand_list, torch.int32), it, thr, _dev(H_all), _dev(inl), _dev(Hb), _dev(pos),
                                _stream()), "nm_ransac_f32")
     return pos, Hb, H_all, inl
+
+
+SIFT_MAX_BATCH = 4
+
+
+def detect_describe_batch(arenas, grays):
+    """Enqueue len(arenas) <= SIFT_MAX_BATCH equally sized frames as ONE launch sequence on the current stream
+    (nm_sift_detect_describe_batch); outputs land in each arena's own tensors, exactly as detect_describe would."""
+    torch = _torch()
+    n = len(arenas)
+    if n != len(grays) or not 0 < n <= SIFT_MAX_BATCH:
+        raise NmError("batch of %d arenas / %d frames (max %d)" % (n, len(grays), SIFT_MAX_BATCH))
+    for a, g in zip(arenas, grays):
+        if tuple(g.shape) != (a.height, a.width):
+            raise NmError("frame shape %s does not match the arena (%d,%d)" % (tuple(g.shape), a.height, a.width))
+
+    def arr(vals):
+        return (C.c_void_p * n)(*vals)
+    _check(lib().nm_sift_detect_describe_batch(
+        arr([a._h.value for a in arenas]), n, arr([_dev(g, torch.float32) for g in grays]),
+        arr([_dev(a.desc) for a in arenas]), arr([_dev(a.x) for a in arenas]), arr([_dev(a.y) for a in arenas]),
+        arr([_dev(a.kpts) for a in arenas]), arr([_dev(a.orients) for a in arenas]),
+        arr([_dev(a.num_items) for a in arenas]), _stream()), "nm_sift_detect_describe_batch")
 
 
 class SiftArena:

@@ -39,6 +39,26 @@ int nm_launch_gradient_batch(const NmGradBatch &b, int width, int height, hipStr
 int nm_launch_convolve(float *result, const float *image, float *buffer, float *dog, float *grad, int width,
                        int height, const float *taps_dev, int radius, hipStream_t stream);
 
+// The same Gaussian launch over up to NM_MAX_BATCH equally sized frames (one grid; the frame index is the slow part of
+// blockIdx.x): 1080p octave 0 is only ~4 workgroups per CU, a frame pair or quad fills the chip and amortises the
+// launch / drain phases that bound a single frame.
+#define NM_MAX_BATCH 4
+struct NmConvBatch {
+    float *result[NM_MAX_BATCH];
+    const float *image[NM_MAX_BATCH];
+    float *dog[NM_MAX_BATCH];
+    float *grad[NM_MAX_BATCH];
+    int n;
+};
+int nm_launch_convolve_batch(const NmConvBatch &b, int width, int height, const float *taps_dev, int radius,
+                             hipStream_t stream);
+struct NmPlaneBatch {
+    float *dst[NM_MAX_BATCH];
+    const float *src[NM_MAX_BATCH];
+    int n;
+};
+int nm_launch_downsample2_batch(const NmPlaneBatch &b, int rw, int rh, int sw, hipStream_t stream);
+
 // Device-side record the frame driver shares between its kernels.
 struct NmFrameBook {
     int num_items;        // descriptors written so far (<= capacity)

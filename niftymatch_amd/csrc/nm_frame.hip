@@ -164,7 +164,7 @@ float *nm_sift_arena_level(nm_sift_arena *a, int l) { return (a && l >= 0 && l <
 float *nm_sift_arena_dog(nm_sift_arena *a, int d) { return (a && d >= 0 && d < 5) ? a->dog[0][d] : nullptr; }
 float *nm_sift_arena_grad(nm_sift_arena *a) { return a ? a->grad[0] : nullptr; }
 
-static int octave_pyramid(nm_sift_arena *a, int o, int ow, int oh, bool store_top, hipStream_t st)
+static int octave_pyramid(nm_sift_arena *const *as, int n, int o, int ow, int oh, bool store_top, hipStream_t st)
 {
     if (o == 0) nm_prof_begin(NM_PROF_PYRAMID_O0, st);
     const size_t plane = (size_t)ow * oh;
@@ -172,10 +172,16 @@ static int octave_pyramid(nm_sift_arena *a, int o, int ow, int oh, bool store_to
     for (int i = 1; i < 6 && !rc; ++i) {
         // the launch that blurs level i-1 into level i also emits DoG i-1 and, for i-1 in 1..3, the gradient plane
         // i-2 of level i-1 (compute_gradients: level l from octave[l+1], sift/siftfunctions.cu:53-63)
-        float *grad = (i >= 2 && i <= 4) ? a->grad[o] + 2 * (size_t)(i - 2) * plane : nullptr;
-        // level 5 is only ever read through DoG 4: its plane is not stored
-        rc = nm_launch_convolve((i < 5 || store_top) ? a->level[i] : nullptr, a->level[i - 1], nullptr, a->dog[o][i - 1], grad, ow, oh, a->taps[i - 1],
-                                a->radii[i - 1], st);
+        NmConvBatch b{};
+        b.n = n;
+        for (int f = 0; f < n; ++f) {
+            nm_sift_arena *a = as[f];
+            b.result[f] = (i < 5 || store_top) ? a->level[i] : nullptr;     // level 5 is only read through DoG 4
+            b.image[f] = a->level[i - 1];
+            b.dog[f] = a->dog[o][i - 1];
+            b.grad[f] = (i >= 2 && i <= 4) ? a->grad[o] + 2 * (size_t)(i - 2) * plane : nullptr;
+        }
+        rc = nm_launch_convolve_batch(b, ow, oh, as[0]->taps[i - 1], as[0]->radii[i - 1], st);
     }
     if (o == 0) nm_prof_end(NM_PROF_PYRAMID_O0, st);
     return rc;
@@ -184,60 +190,93 @@ static int octave_pyramid(nm_sift_arena *a, int o, int ow, int oh, bool store_to
 int nm_sift_octave_pyramid(nm_sift_arena *a, int ow, int oh, void *stream)
 {
     if (!a || ow <= 0 || oh <= 0 || (size_t)ow * oh > a->npix) return (int)hipErrorInvalidValue;
-    return octave_pyramid(a, 0, ow, oh, true, nm_stream(stream));
+    return octave_pyramid(&a, 1, 0, ow, oh, true, nm_stream(stream));
+}
+
+// Frame driver for n <= NM_MAX_BATCH equally sized frames. The scale-space chain (base blur, decimations, 5 fused
+// Gaussian launches per octave) is ONE launch sequence on the caller's stream covering all frames; extrema + ordered
+// compaction of (frame f, octave o) run on arena f's side stream as soon as that octave's DoG planes exist, i.e.
+// concurrently with the pyramid of octave o+1 and with the other frames' detection; orientation + descriptors of frame
+// f follow on the same side stream; the caller's stream joins all side streams at the end. Capture-safe (events only).
+int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *const *gray, float *const *desc,
+                                  float *const *x, float *const *y, float *const *kpts, float *const *orients,
+                                  int *const *d_num_items, void *stream)
+{
+    if (!as || n <= 0 || n > NM_MAX_BATCH || !gray || !desc || !x || !y) return (int)hipErrorInvalidValue;
+    for (int f = 0; f < n; ++f) {
+        if (!as[f] || !gray[f] || !desc[f] || !x[f] || !y[f]) return (int)hipErrorInvalidValue;
+        if (as[f]->width != as[0]->width || as[f]->height != as[0]->height) return (int)hipErrorInvalidValue;
+        for (int g = 0; g < f; ++g)
+            if (as[g] == as[f]) return (int)hipErrorInvalidValue;
+    }
+    hipStream_t st = nm_stream(stream);
+    const SiftParams &P = as[0]->params;
+    const int W = as[0]->width, H = as[0]->height;
+    NmConvBatch base{};
+    base.n = n;
+    for (int f = 0; f < n; ++f) { base.result[f] = as[f]->level[0]; base.image[f] = gray[f]; }
+    int rc = nm_launch_convolve_batch(base, W, H, as[0]->taps_base, as[0]->base_radius, st);
+    if (rc) return rc;
+
+    NmDescribeArgs da[NM_MAX_BATCH];
+    float *kp[NM_MAX_BATCH];
+    for (int f = 0; f < n; ++f) {
+        nm_sift_arena *a = as[f];
+        da[f] = NmDescribeArgs{};
+        da[f].num_octaves = P._num_octaves; da[f].num_dogs = P._num_dog_levels; da[f].book = a->book;
+        kp[f] = (kpts && kpts[f]) ? kpts[f] : a->kpts;
+        da[f].kpts = kp[f];
+        da[f].orients = (orients && orients[f]) ? orients[f] : a->orients;
+        da[f].desc = desc[f]; da[f].x = x[f]; da[f].y = y[f];
+    }
+    for (int o = 0; o < P._num_octaves; ++o) {
+        const int ow = W >> o, oh = H >> o;
+        const float xper = (float)std::pow(2.0, o);
+        if (o > 0) {
+            NmPlaneBatch d{};
+            d.n = n;
+            for (int f = 0; f < n; ++f) { d.dst[f] = as[f]->level[0]; d.src[f] = as[f]->level[3]; }
+            rc = nm_launch_downsample2_batch(d, ow, oh, W >> (o - 1), st);
+            if (rc) return rc;
+        }
+        rc = octave_pyramid(as, n, o, ow, oh, false, st);
+        if (rc) return rc;
+        NM_RETURN_IF(hipEventRecord(as[0]->ev_pyr[o], st));
+
+        const int nseg = nm_divup(ow, 256);
+        const int n_blocks = oh * nseg;
+        for (int f = 0; f < n; ++f) {
+            nm_sift_arena *a = as[f];
+            NM_RETURN_IF(hipStreamWaitEvent(as[f]->side, as[0]->ev_pyr[o], 0));
+            NmDetectArgs d{};
+            for (int i = 0; i < 5; ++i) d.dog[i] = a->dog[o][i];
+            d.ow = ow; d.oh = oh; d.peak = P._peak_threshold; d.edge = P._edge_threshold; d.xper = xper;
+            d.sigma0 = P._sigma_0; d.num_dogs = P._num_dog_levels; d.staging = a->staging; d.stage_stride = a->stage_stride;
+            d.counts = a->counts; d.n_blocks = n_blocks; d.nseg = nseg;
+            NmScanArgs s{};
+            s.counts = a->counts; s.offsets = a->offsets; s.n_blocks = n_blocks; s.octave = o; s.capacity = a->capacity;
+            s.book = a->book; s.d_num_items = d_num_items ? d_num_items[f] : nullptr;
+            NmGatherArgs g{};
+            g.staging = a->staging; g.stage_stride = a->stage_stride; g.counts = a->counts; g.offsets = a->offsets;
+            g.n_blocks = n_blocks; g.octave = o; g.book = a->book; g.kpts = kp[f];
+            rc = nm_launch_detect_octave(d, s, g, as[f]->side);
+            if (rc) return rc;
+            da[f].geom[o].grad = a->grad[o]; da[f].geom[o].ow = ow; da[f].geom[o].oh = oh; da[f].geom[o].xper = xper;
+        }
+    }
+    for (int f = 0; f < n; ++f) {
+        rc = nm_launch_frame_describe(da[f], as[f]->side);
+        if (rc) return rc;
+        NM_RETURN_IF(hipEventRecord(as[f]->ev_join, as[f]->side));
+        NM_RETURN_IF(hipStreamWaitEvent(st, as[f]->ev_join, 0));
+    }
+    return 0;
 }
 
 int nm_sift_detect_describe(nm_sift_arena *a, const float *gray, float *desc, float *x, float *y, float *kpts,
                             float *orients, int *d_num_items, void *stream)
 {
-    if (!a || !gray || !desc || !x || !y) return (int)hipErrorInvalidValue;
-    hipStream_t st = nm_stream(stream);
-    const SiftParams &P = a->params;
-    float *kp = kpts ? kpts : a->kpts;
-    float *ori = orients ? orients : a->orients;
-    int rc = nm_launch_convolve(a->level[0], gray, nullptr, nullptr, nullptr, a->width, a->height, a->taps_base, a->base_radius, st);
-    if (rc) return rc;
-
-    NmDescribeArgs da{};
-    da.num_octaves = P._num_octaves; da.num_dogs = P._num_dog_levels; da.book = a->book;
-    da.kpts = kp; da.orients = ori; da.desc = desc; da.x = x; da.y = y;
-
-    // Fork/join inside the frame: the pyramid chain of all octaves runs on the caller's stream; extrema + ordered
-    // compaction of octave o run on the arena's side stream as soon as that octave's DoG planes exist, i.e. concurrently
-    // with the pyramid of octave o+1. Orientation + descriptors follow the join. Capture-safe (events only).
-    for (int o = 0; o < P._num_octaves; ++o) {
-        const int ow = a->width >> o, oh = a->height >> o;
-        const float xper = (float)std::pow(2.0, o);
-        if (o > 0) {
-            rc = nm_downsample2_f32(a->level[0], ow, oh, a->level[3], a->width >> (o - 1), a->height >> (o - 1), st);
-            if (rc) return rc;
-        }
-        rc = octave_pyramid(a, o, ow, oh, false, st);
-        if (rc) return rc;
-        NM_RETURN_IF(hipEventRecord(a->ev_pyr[o], st));
-        NM_RETURN_IF(hipStreamWaitEvent(a->side, a->ev_pyr[o], 0));
-
-        const int nseg = nm_divup(ow, 256);
-        const int n_blocks = oh * nseg;
-        NmDetectArgs d{};
-        for (int i = 0; i < 5; ++i) d.dog[i] = a->dog[o][i];
-        d.ow = ow; d.oh = oh; d.peak = P._peak_threshold; d.edge = P._edge_threshold; d.xper = xper;
-        d.sigma0 = P._sigma_0; d.num_dogs = P._num_dog_levels; d.staging = a->staging; d.stage_stride = a->stage_stride;
-        d.counts = a->counts; d.n_blocks = n_blocks; d.nseg = nseg;
-        NmScanArgs s{};
-        s.counts = a->counts; s.offsets = a->offsets; s.n_blocks = n_blocks; s.octave = o; s.capacity = a->capacity;
-        s.book = a->book; s.d_num_items = d_num_items;
-        NmGatherArgs g{};
-        g.staging = a->staging; g.stage_stride = a->stage_stride; g.counts = a->counts; g.offsets = a->offsets;
-        g.n_blocks = n_blocks; g.octave = o; g.book = a->book; g.kpts = kp;
-        rc = nm_launch_detect_octave(d, s, g, a->side);
-        if (rc) return rc;
-
-        da.geom[o].grad = a->grad[o]; da.geom[o].ow = ow; da.geom[o].oh = oh; da.geom[o].xper = xper;
-    }
-    NM_RETURN_IF(hipEventRecord(a->ev_join, a->side));
-    NM_RETURN_IF(hipStreamWaitEvent(st, a->ev_join, 0));
-    return nm_launch_frame_describe(da, st);
+    return nm_sift_detect_describe_batch(&a, 1, &gray, &desc, &x, &y, &kpts, &orients, &d_num_items, stream);
 }
 
 }  // extern "C"

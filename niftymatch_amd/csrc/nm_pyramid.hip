@@ -2,7 +2,6 @@
 // gradient. Replaces kernels/convolution.cu:16-159, kernels/downsample.cu:6-29, kernels/cudamath.cu:26-80 of the
 // reference. All kernels are HBM/L2 streaming stencils; arithmetic order is fixed by the fp spec:
 //   conv: taps k = -r..r, sum = fma(x[k], w[r-k], sum) starting from +0, rows first, then columns, zero padding.
-#include <cstdlib>
 #include "nm_common.hpp"
 #include "nm_fpspec.hpp"
 #include "../../include/nm_abi.h"
@@ -300,10 +299,10 @@ __device__ __forceinline__ bool grad_pair(v2f xm, v2f xp, v2f ym, v2f yp, v2f &g
 
 }  // namespace
 
-template <int R, bool WRITE_DOG, bool WRITE_GRAD, int EXP = 0>
-__global__ __launch_bounds__(256) void conv_pk_kernel(float *__restrict__ result, const float *__restrict__ image,
-                                                     float *__restrict__ dog, float2 *__restrict__ grad, int width,
-                                                     int height, const float *__restrict__ taps, int tiles_x, int ntiles)
+template <int R, bool WRITE_DOG, bool WRITE_GRAD>
+__global__ __launch_bounds__(256) void conv_pk_kernel(NmConvBatch batch, int width, int height,
+                                                     const float *__restrict__ taps, int tiles_x, int ntiles,
+                                                     int blocks_per_frame)
 {
     constexpr int TW = 64, TH = 32;
     constexpr int RA = (R + 3) & ~3;
@@ -324,12 +323,21 @@ __global__ __launch_bounds__(256) void conv_pk_kernel(float *__restrict__ result
 
     const int tid = threadIdx.x;
     const int nxcd = 8;
-    const int xcd = blockIdx.x % nxcd, slot = blockIdx.x / nxcd;
+    const int frame = blockIdx.x / blocks_per_frame;              // blocks_per_frame % 8 == 0: blockIdx % 8 is the XCD
+    const int blk = blockIdx.x - frame * blocks_per_frame;
+    const int xcd = blk % nxcd, slot = blk / nxcd;
     const int band = (ntiles + nxcd - 1) / nxcd;
     const int tile = xcd * band + slot;
     if (slot >= band || tile >= ntiles) return;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int x0 = tx * TW, y0 = ty * TH;
+    // uniform selects, not dynamic indexing: a by-value kernel argument indexed at run time would be copied to scratch
+#define NM_PICK(A) (frame == 0 ? batch.A[0] : frame == 1 ? batch.A[1] : frame == 2 ? batch.A[2] : batch.A[3])
+    float *__restrict__ result = NM_PICK(result);
+    const float *__restrict__ image = NM_PICK(image);
+    float *__restrict__ dog = NM_PICK(dog);
+    float2 *__restrict__ grad = reinterpret_cast<float2 *>(NM_PICK(grad));
+#undef NM_PICK
 
     float w[2 * R + 1];
 #pragma unroll
@@ -436,9 +444,7 @@ __global__ __launch_bounds__(256) void conv_pk_kernel(float *__restrict__ result
                     }
                     if (WRITE_GRAD) {
                         v2f g, r;
-                        bool ok = true;
-                        if (EXP == 2) { g = rgt[i + 1] - lft[i + 1]; r = mid[i + 2] - mid[i]; }
-                        else ok = grad_pair(lft[i + 1], rgt[i + 1], mid[i], mid[i + 2], g, r);
+                        const bool ok = grad_pair(lft[i + 1], rgt[i + 1], mid[i], mid[i + 2], g, r);
                         if (__builtin_expect(!ok, 0)) {      // out-of-domain input (denormal-range or huge differences)
                             const float2 a = grad_of(lft[i + 1].x, rgt[i + 1].x, mid[i].x, mid[i + 2].x);
                             const float2 b = grad_of(lft[i + 1].y, rgt[i + 1].y, mid[i].y, mid[i + 2].y);
@@ -447,7 +453,6 @@ __global__ __launch_bounds__(256) void conv_pk_kernel(float *__restrict__ result
                         }
                         const bool rowin = gy >= 1 && gy < height - 1;
                         const bool k0 = rowin && in0, k1 = rowin && in1;
-                        if (EXP != 1 || g.x == 12345.678f)
                         *reinterpret_cast<float4 *>(reinterpret_cast<char *>(grad) + 2 * (size_t)off) =
                             make_float4(k0 ? g.x : 0.f, k0 ? r.x : 0.f, k1 ? g.y : 0.f, k1 ? r.y : 0.f);
                     }
@@ -552,22 +557,17 @@ static int launch_conv_rvt(float *result, const float *image, float *buffer, flo
 }
 
 template <int R>
-static int launch_conv_pk(float *result, const float *image, float *dog, float *grad, int width, int height,
-                          const float *taps, hipStream_t stream)
+static int launch_conv_pk(const NmConvBatch &b, int width, int height, const float *taps, hipStream_t stream)
 {
     const int tiles_x = nm_divup(width, 64), tiles_y = nm_divup(height, 32);
     const int ntiles = tiles_x * tiles_y;
-    dim3 grid(((ntiles + 7) / 8) * 8);
-    float2 *g2 = reinterpret_cast<float2 *>(grad);
-#define NM_PK_LAUNCH(DOG, GRAD)                                                                                    \
-    hipLaunchKernelGGL((conv_pk_kernel<R, DOG, GRAD>), grid, dim3(256), 0, stream, result, image, dog, g2, width, \
-                       height, taps, tiles_x, ntiles)
-    static const int exp_mode = getenv("NM_EXP") ? atoi(getenv("NM_EXP")) : 0;
-    if (dog && grad && exp_mode == 1)
-        hipLaunchKernelGGL((conv_pk_kernel<R, true, true, 1>), grid, dim3(256), 0, stream, result, image, dog, g2, width, height, taps, tiles_x, ntiles);
-    else if (dog && grad && exp_mode == 2)
-        hipLaunchKernelGGL((conv_pk_kernel<R, true, true, 2>), grid, dim3(256), 0, stream, result, image, dog, g2, width, height, taps, tiles_x, ntiles);
-    else if (dog && grad) NM_PK_LAUNCH(true, true);
+    const int bpf = ((ntiles + 7) / 8) * 8;
+    dim3 grid(bpf * b.n);
+    const bool dog = b.dog[0] != nullptr, grad = b.grad[0] != nullptr;
+#define NM_PK_LAUNCH(DOG, GRAD)                                                                                     \
+    hipLaunchKernelGGL((conv_pk_kernel<R, DOG, GRAD>), grid, dim3(256), 0, stream, b, width, height, taps, tiles_x, \
+                       ntiles, bpf)
+    if (dog && grad) NM_PK_LAUNCH(true, true);
     else if (dog) NM_PK_LAUNCH(true, false);
     else NM_PK_LAUNCH(false, false);
 #undef NM_PK_LAUNCH
@@ -579,8 +579,11 @@ template <int R, bool VEC>
 static int launch_conv_rv(float *result, const float *image, float *buffer, float *dog, float *grad, int width,
                           int height, const float *taps, hipStream_t stream)
 {
-    if (VEC && !buffer && !(grad && !dog) && (size_t)width * height * 4 < (1ull << 32))
-        return launch_conv_pk<R>(result, image, dog, grad, width, height, taps, stream);
+    if (VEC && !buffer && !(grad && !dog) && (size_t)width * height * 4 < (1ull << 32)) {
+        NmConvBatch b{};
+        b.result[0] = result; b.image[0] = image; b.dog[0] = dog; b.grad[0] = grad; b.n = 1;
+        return launch_conv_pk<R>(b, width, height, taps, stream);
+    }
     // 64 x 32 tiles with 256 threads, or 64 x 64 tiles with 512 threads (less halo re-reading and row-pass redundancy)
     // once the image has enough tiles to fill the chip that way.
     if (VEC && !buffer && (long)width * height >= 256L * 64 * 64)
@@ -627,6 +630,37 @@ int nm_launch_convolve(float *result, const float *image, float *buffer, float *
     return 0;
 }
 
+// Batched form used by the frame driver: one launch for all frames when the packed kernel applies (same geometry, all
+// planes 16-byte aligned, same set of outputs), otherwise frame by frame.
+int nm_launch_convolve_batch(const NmConvBatch &b, int width, int height, const float *taps, int radius, hipStream_t stream)
+{
+    if (b.n <= 0 || width <= 0 || height <= 0) return 0;
+    if (b.n > NM_MAX_BATCH) return (int)hipErrorInvalidValue;
+    bool pk = (width % 4 == 0) && (size_t)width * height * 4 < (1ull << 32) && !(b.grad[0] && !b.dog[0]);
+    for (int f = 0; f < b.n; ++f) {
+        pk = pk && ((reinterpret_cast<uintptr_t>(b.image[f]) & 15) == 0);
+        pk = pk && ((b.result[f] != nullptr) == (b.result[0] != nullptr)) && ((b.dog[f] != nullptr) == (b.dog[0] != nullptr)) &&
+             ((b.grad[f] != nullptr) == (b.grad[0] != nullptr));
+    }
+    if (pk) {
+        switch (radius) {
+            case 5: return launch_conv_pk<5>(b, width, height, taps, stream);
+            case 7: return launch_conv_pk<7>(b, width, height, taps, stream);
+            case 8: return launch_conv_pk<8>(b, width, height, taps, stream);
+            case 10: return launch_conv_pk<10>(b, width, height, taps, stream);
+            case 12: return launch_conv_pk<12>(b, width, height, taps, stream);
+            case 13: return launch_conv_pk<13>(b, width, height, taps, stream);
+            case 16: return launch_conv_pk<16>(b, width, height, taps, stream);
+            default: break;
+        }
+    }
+    for (int f = 0; f < b.n; ++f) {
+        const int rc = nm_launch_convolve(b.result[f], b.image[f], nullptr, b.dog[f], b.grad[f], width, height, taps, radius, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void downsample2_kernel(float *__restrict__ result, int rw, int rh,
                                                          const float *__restrict__ source, int sw)
@@ -634,6 +668,26 @@ __global__ __launch_bounds__(256) void downsample2_kernel(float *__restrict__ re
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= rw || y >= rh) return;
     result[(size_t)y * rw + x] = source[(size_t)(y * 2) * sw + (x * 2)];
+}
+
+__global__ __launch_bounds__(256) void downsample2_batch_kernel(NmPlaneBatch b, int rw, int rh, int sw)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= rw || y >= rh) return;
+    const int f = blockIdx.z;
+    float *__restrict__ dst = f == 0 ? b.dst[0] : f == 1 ? b.dst[1] : f == 2 ? b.dst[2] : b.dst[3];
+    const float *__restrict__ src = f == 0 ? b.src[0] : f == 1 ? b.src[1] : f == 2 ? b.src[2] : b.src[3];
+    dst[(size_t)y * rw + x] = src[(size_t)(y * 2) * sw + (x * 2)];
+}
+
+int nm_launch_downsample2_batch(const NmPlaneBatch &b, int rw, int rh, int sw, hipStream_t stream)
+{
+    if (b.n <= 0 || rw <= 0 || rh <= 0) return 0;
+    if (b.n > NM_MAX_BATCH) return (int)hipErrorInvalidValue;
+    dim3 grid(nm_divup(rw, 64), nm_divup(rh, 4), b.n);
+    hipLaunchKernelGGL(downsample2_batch_kernel, grid, dim3(256), 0, stream, b, rw, rh, sw);
+    NM_LAUNCH_CHECK();
+    return 0;
 }
 
 __global__ __launch_bounds__(256) void subtract_kernel(const float *__restrict__ A, const float *__restrict__ B,

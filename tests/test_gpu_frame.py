@@ -67,6 +67,49 @@ def test_frame_driver_reuse_is_stateless(nm, oracle, cuda):
     _eq(outs[1][1], ref["desc"], "second frame after reuse")
 
 
+@pytest.mark.parametrize("wh,n", [((256, 192), 2), ((250, 187), 3), ((1920, 1080), 2), ((320, 240), 4)])
+def test_frame_batch_equals_single_frames(nm, oracle, cuda, wh, n):
+    """nm_sift_detect_describe_batch: one launch sequence for n frames; every frame's outputs equal the oracle's (and
+    therefore the single-frame driver's). Includes a width that is not a multiple of 4 (per-frame fallback kernels)."""
+    import torch
+    w, h = wh
+    frames = [H.blurred_frame(20 + i, w, h) for i in range(n)]
+    arenas = [nm.SiftArena(w, h, 16384) for _ in range(n)]
+    for rep in range(2):                                   # second pass: arenas and side streams are reused
+        order = list(range(n)) if rep == 0 else list(reversed(range(n)))
+        nm.detect_describe_batch(arenas, [_t(frames[i], cuda) for i in order])
+        torch.cuda.synchronize()
+        for a, i in zip(arenas, order):
+            ref = oracle.sift_detect_describe(frames[i], 16384) if (w * h <= 320 * 240 or i == 0) else None
+            cnt = int(a.num_items.item())
+            if ref is not None:
+                assert cnt == ref["n"]
+                _eq(a.kpts[:cnt], ref["kpts"], "batch keypoints frame %d" % i)
+                _eq(a.orients[:cnt], ref["orient"], "batch orientations frame %d" % i)
+                _eq(a.desc[:cnt], ref["desc"], "batch descriptors frame %d" % i)
+            else:                                           # 1080p: compare the other frames with the single-frame driver
+                single = _run_arena(nm, cuda, frames[i], 16384)
+                assert cnt == single["n"]
+                _eq(a.desc[:cnt], single["desc"], "batch vs single descriptors frame %d" % i)
+                _eq(a.x[:cnt], single["x"], "batch vs single x frame %d" % i)
+    for a in arenas:
+        a.close()
+
+
+def test_frame_batch_rejects_bad_arguments(nm, cuda):
+    import torch
+    a, b = nm.SiftArena(64, 48, 256), nm.SiftArena(128, 96, 256)
+    f64 = torch.zeros((48, 64), device=cuda)
+    f128 = torch.zeros((96, 128), device=cuda)
+    with pytest.raises(nm.NmError):
+        nm.detect_describe_batch([a, b], [f64, f128])          # different geometry
+    with pytest.raises(nm.NmError):
+        nm.detect_describe_batch([a, a], [f64, f64])           # the same arena twice
+    with pytest.raises(nm.NmError):
+        nm.detect_describe_batch([a] * 5, [f64] * 5)           # more than SIFT_MAX_BATCH
+    a.close(); b.close()
+
+
 def test_cpp_api_client_loop(nm, oracle, cuda):
     """The reference-style client (SiftParams/PyramidData/SiftData + compute_*) gives the same answer."""
     frame = H.blurred_frame(0, 640, 480)

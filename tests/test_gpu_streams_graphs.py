@@ -68,3 +68,56 @@ def test_frame_and_match_capture_into_hip_graph(nm, oracle, cuda):
     n2 = int(a0.num_items.item())
     assert n2 == r2["n"]
     _eq(a0.desc[:n2], r2["desc"], "second frame through the same graph")
+
+
+def test_batched_pair_call_captures_into_hip_graph(nm, oracle, cuda):
+    """nm_sift_detect_describe_batch forks onto the arenas' side streams with events only: capturable, replayable."""
+    import torch
+    w, h, cap = 320, 240, 4096
+    f = [H.blurred_frame(70 + i, w, h) for i in range(3)]
+    r = [oracle.sift_detect_describe(x, cap) for x in f]
+    a = [nm.SiftArena(w, h, cap) for _ in range(2)]
+    d = [_t(f[0], cuda), _t(f[1], cuda)]
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        nm.detect_describe_batch(a, d)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        nm.detect_describe_batch(a, d)
+    d[1].copy_(_t(f[2], cuda))
+    for x in a:
+        x.desc.zero_(); x.num_items.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for x, ref in zip(a, (r[0], r[2])):
+        n = int(x.num_items.item())
+        assert n == ref["n"]
+        _eq(x.desc[:n], ref["desc"], "batched call through a HIP graph")
+
+
+def test_calls_enqueued_from_several_host_threads(nm, oracle, cuda):
+    """bench.py issues its detect calls from a thread pool (the ABI is re-entrant; an arena belongs to one call at a
+    time): results stay bit-exact."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    w, h, cap = 256, 192, 4096
+    frames = [H.blurred_frame(80 + i, w, h) for i in range(8)]
+    refs = [oracle.sift_detect_describe(x, cap) for x in frames]
+    dev = [_t(x, cuda) for x in frames]
+    arenas = [nm.SiftArena(w, h, cap) for _ in frames]
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    torch.cuda.synchronize()
+
+    def work(t):
+        for rep in range(3):
+            with torch.cuda.stream(streams[t]):
+                nm.detect_describe_batch(arenas[2 * t:2 * t + 2], dev[2 * t:2 * t + 2])
+
+    with ThreadPoolExecutor(4) as pool:
+        list(pool.map(work, range(4)))
+    torch.cuda.synchronize()
+    for x, ref in zip(arenas, refs):
+        n = int(x.num_items.item())
+        assert n == ref["n"]
+        _eq(x.desc[:n], ref["desc"], "descriptors with multi-threaded enqueue")

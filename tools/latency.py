@@ -45,7 +45,12 @@ for (w, h) in ((640, 480), (1920, 1080)):
             a0.detect_describe(f[0]); a1.detect_describe(f[1])
             nm.sift_match(a0.desc, a1.desc, 0.8, prior=res, workspace=ws, nA=n0, nB=n1)
 
-    frame(); pair(); torch.cuda.synchronize()
+    def pair_batched():
+        with torch.cuda.stream(s):
+            nm.detect_describe_batch([a0, a1], [f[0], f[1]])
+            nm.sift_match(a0.desc, a1.desc, 0.8, prior=res, workspace=ws, nA=n0, nB=n1)
+
+    frame(); pair(); pair_batched(); torch.cuda.synchronize()
     gf, gp = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
     with torch.cuda.graph(gf, stream=s):
         a0.detect_describe(f[0])
@@ -54,7 +59,8 @@ for (w, h) in ((640, 480), (1920, 1080)):
         nm.sift_match(a0.desc, a1.desc, 0.8, prior=res, workspace=ws, nA=n0, nB=n1)
     out = {"frame": "%dx%d" % (w, h), "keypoints": [n0, n1],
            "frame_us_eager": round(timeit(frame), 1), "frame_us_graph": round(timeit(gf.replay), 1),
-           "pair_us_eager": round(timeit(pair, 100), 1), "pair_us_graph": round(timeit(gp.replay, 100), 1)}
+           "pair_us_eager": round(timeit(pair, 100), 1), "pair_us_graph": round(timeit(gp.replay, 100), 1),
+           "pair_us_batched_call": round(timeit(pair_batched, 100), 1)}
     out["frames_per_s_graph"] = round(1e6 / out["frame_us_graph"], 1)
     out["keypoints_per_s_graph"] = round(n0 * 1e6 / out["frame_us_graph"], 1)
     print(json.dumps(out))
