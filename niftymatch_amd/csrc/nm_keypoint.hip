@@ -230,7 +230,7 @@ __device__ __forceinline__ float dpp_from_upper(float own, float edge)   // lane
 __device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 __device__ __forceinline__ float min3f(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
 
-constexpr int DET_ROWS = 4;      // image rows per workgroup: 6 rows are loaded for 4 tested (1.5x instead of 3x re-reads)
+constexpr int DET_ROWS = 4;      // image rows per workgroup: 6 rows are loaded for 4 tested (measured best of 4, 5, 6, 8)
 
 __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
 {
@@ -246,16 +246,25 @@ __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
     const bool edge_lane = (lane == 0) || (lane == 63);
     const float thr = 0.8f * a.peak;
 
-    // sliding 3-row window per plane: row maxima/minima of (left, mid, right); centre row keeps mid and max/min(l, r)
+    // sliding 3-row window per plane: row maxima/minima of (left, mid, right); centre row keeps mid and max/min(l, r).
+    // Rows are FETCHED one iteration ahead of being absorbed into the window (raw values wait in registers), so the
+    // global-load latency of row y+2 hides behind the tests of row y instead of stalling every iteration.
     float rmax[5][3], rmin[5][3], cmid[5][2], clr_max[5][2], clr_min[5][2];
-    auto load_row = [&](int yy, int slot, int cslot) {
+    float raw_mid[2][5], raw_ev[2][5];
+    auto fetch_row = [&](int yy, int buf) {
         const int yr = min(max(yy, 0), oh - 1);
 #pragma unroll
         for (int p = 0; p < 5; ++p) {
             const float *row = a.dog[p] + (size_t)yr * ow;
-            const float mid = row[xc];
-            float ev = 0.f;
-            if (edge_lane) ev = row[xe];
+            raw_mid[buf][p] = row[xc];
+            raw_ev[buf][p] = 0.f;
+            if (edge_lane) raw_ev[buf][p] = row[xe];
+        }
+    };
+    auto absorb_row = [&](int buf, int slot, int cslot) {
+#pragma unroll
+        for (int p = 0; p < 5; ++p) {
+            const float mid = raw_mid[buf][p], ev = raw_ev[buf][p];
             const float lf = dpp_from_lower(mid, ev), rt = dpp_from_upper(mid, ev);
             rmax[p][slot] = max3f(lf, mid, rt);
             rmin[p][slot] = min3f(lf, mid, rt);
@@ -264,15 +273,19 @@ __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
             clr_min[p][cslot] = __builtin_fminf(lf, rt);
         }
     };
-    // rows y0-1 and y0 first; the loop brings in y0+j+1. Slots are compile-time after unrolling.
-    load_row(y0 - 1, 0, 0);
-    load_row(y0, 1, 1);
+    // rows y0-1, y0 absorbed, y0+1 in flight before the loop; iteration j absorbs y+1 and fetches y+2
+    fetch_row(y0 - 1, 0);
+    fetch_row(y0, 1);
+    absorb_row(0, 0, 0);
+    fetch_row(y0 + 1, 0);
+    absorb_row(1, 1, 1);
 #pragma unroll
     for (int j = 0; j < DET_ROWS; ++j) {
         const int y = y0 + j;
         const int s_up = j % 3, s_c = (j + 1) % 3, s_dn = (j + 2) % 3;     // rows y-1, y, y+1
         const int cs = (j + 1) & 1;                                        // centre-row slot of row y
-        load_row(y + 1, s_dn, j & 1);
+        if (j + 1 < DET_ROWS) fetch_row(y + 2, (j + 1) & 1);
+        absorb_row(j & 1, s_dn, j & 1);
         const bool interior = xin && x >= 1 && x <= ow - 2 && y >= 1 && y <= oh - 2;
         float m9[5], n9[5], m8[5], n8[5];
 #pragma unroll
