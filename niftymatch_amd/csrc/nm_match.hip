@@ -336,64 +336,90 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(const float *__rest
     emit_match(i, m1, idx, m2, mode, index_offset, ambiguity, result, min1_out, idx_out, min2_out);
 }
 
-// Exact fallback for the queries the finalize pass could not prove: one workgroup per listed query scans ALL candidates
-// exactly (the reference's own arithmetic) and merges (min1, lowest index, multiset second minimum) across threads.
+// Exact fallback for the queries the finalize pass could not prove. A listed query is scanned exactly (the reference's own
+// arithmetic: one thread owns one candidate's 128-step fma chain) by FB_SPLIT workgroups, each over a contiguous slice of
+// the candidates -- typically 0-2 queries are listed, and one workgroup per query would leave the chip idle for ~100 us.
+// Slice results (min1, lowest index, multiset second minimum) go to `part`; match_fallback_merge_kernel combines them in
+// ascending slice order.
+constexpr int FB_SPLIT = 64;
+
+__device__ __forceinline__ void top2_merge(float &m1, int &i1, float &m2, float o1, int oi, float o2)
+{
+    const bool take = (o1 < m1) || (o1 == m1 && oi < i1);
+    const float lo = take ? o1 : m1, hi = take ? m1 : o1;
+    const float s2 = take ? o2 : m2;
+    i1 = take ? oi : i1;
+    m1 = lo;
+    m2 = (hi < s2) ? hi : s2;
+}
+
 __global__ __launch_bounds__(256) void match_fallback_kernel(const float *__restrict__ A, const float *__restrict__ B,
                                                             int nB, const int *__restrict__ fb_count,
-                                                            const int *__restrict__ fb_list, int mode, int index_offset,
-                                                            float ambiguity, int *__restrict__ result,
-                                                            float *__restrict__ min1_out, int *__restrict__ idx_out,
-                                                            float *__restrict__ min2_out)
+                                                            const int *__restrict__ fb_list, float4 *__restrict__ part)
 {
     __shared__ float s_m1[4], s_m2[4];
     __shared__ int s_i1[4];
     const int count = *fb_count;
-    for (int e = blockIdx.x; e < count; e += gridDim.x) {
+    const int slice = (nB + FB_SPLIT - 1) / FB_SPLIT;
+    const int j0 = blockIdx.x * slice, j1 = min(j0 + slice, nB);
+    for (int e = blockIdx.y; e < count; e += gridDim.y) {
         const int i = fb_list[e];
         __syncthreads();
-        float4 x[DIM / 4];                                 // the query row lives in registers
-#pragma unroll
-        for (int k = 0; k < DIM / 4; ++k) x[k] = reinterpret_cast<const float4 *>(A + (size_t)i * DIM)[k];
         float m1 = __builtin_inff(), m2 = __builtin_inff(); int i1 = 0x7fffffff;
-        for (int j = threadIdx.x; j < nB; j += 256) {
-            const float4 *b = reinterpret_cast<const float4 *>(B + (size_t)j * DIM);
-            float4 y[DIM / 4];
+        if (j0 + (int)threadIdx.x < j1) {                      // uniform per wave except the last one of the slice
+            float4 x[DIM / 4];                                 // the query row lives in registers
 #pragma unroll
-            for (int k = 0; k < DIM / 4; ++k) y[k] = b[k];
-            float acc = 0.0f;
+            for (int k = 0; k < DIM / 4; ++k) x[k] = reinterpret_cast<const float4 *>(A + (size_t)i * DIM)[k];
+            for (int j = j0 + threadIdx.x; j < j1; j += 256) {
+                const float4 *b = reinterpret_cast<const float4 *>(B + (size_t)j * DIM);
+                float4 y[DIM / 4];
 #pragma unroll
-            for (int k = 0; k < DIM / 4; ++k) {
-                float tt;
-                tt = x[k].x - y[k].x; acc = __builtin_fmaf(tt, tt, acc);
-                tt = x[k].y - y[k].y; acc = __builtin_fmaf(tt, tt, acc);
-                tt = x[k].z - y[k].z; acc = __builtin_fmaf(tt, tt, acc);
-                tt = x[k].w - y[k].w; acc = __builtin_fmaf(tt, tt, acc);
+                for (int k = 0; k < DIM / 4; ++k) y[k] = b[k];
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < DIM / 4; ++k) {
+                    float tt;
+                    tt = x[k].x - y[k].x; acc = __builtin_fmaf(tt, tt, acc);
+                    tt = x[k].y - y[k].y; acc = __builtin_fmaf(tt, tt, acc);
+                    tt = x[k].z - y[k].z; acc = __builtin_fmaf(tt, tt, acc);
+                    tt = x[k].w - y[k].w; acc = __builtin_fmaf(tt, tt, acc);
+                }
+                if (acc < m1) { m2 = m1; m1 = acc; i1 = j; }
+                else if (acc < m2) m2 = acc;
             }
-            if (acc < m1) { m2 = m1; m1 = acc; i1 = j; }
-            else if (acc < m2) m2 = acc;
         }
-        auto merge = [&](float o1, int oi, float o2) {
-            const bool take = (o1 < m1) || (o1 == m1 && oi < i1);
-            const float lo = take ? o1 : m1, hi = take ? m1 : o1;
-            const float s2 = take ? o2 : m2;
-            i1 = take ? oi : i1;
-            m1 = lo;
-            m2 = (hi < s2) ? hi : s2;
-        };
 #pragma unroll
         for (int sft = 1; sft < 64; sft <<= 1) {
             const float o1 = __shfl_xor(m1, sft), o2 = __shfl_xor(m2, sft);
             const int oi = __shfl_xor(i1, sft);
-            merge(o1, oi, o2);
+            top2_merge(m1, i1, m2, o1, oi, o2);
         }
         const int wave = threadIdx.x >> 6;
         if ((threadIdx.x & 63) == 0) { s_m1[wave] = m1; s_m2[wave] = m2; s_i1[wave] = i1; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            for (int w = 1; w < 4; ++w) merge(s_m1[w], s_i1[w], s_m2[w]);
-            if (MIN2_INIT < m2) m2 = MIN2_INIT;
-            emit_match(i, m1, i1, m2, mode, index_offset, ambiguity, result, min1_out, idx_out, min2_out);
+            for (int w = 1; w < 4; ++w) top2_merge(m1, i1, m2, s_m1[w], s_i1[w], s_m2[w]);
+            part[(size_t)e * FB_SPLIT + blockIdx.x] = make_float4(m1, __int_as_float(i1), m2, 0.f);
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void match_fallback_merge_kernel(const int *__restrict__ fb_count,
+                                                                  const int *__restrict__ fb_list,
+                                                                  const float4 *__restrict__ part, int mode,
+                                                                  int index_offset, float ambiguity, int *__restrict__ result,
+                                                                  float *__restrict__ min1_out, int *__restrict__ idx_out,
+                                                                  float *__restrict__ min2_out)
+{
+    const int count = *fb_count;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < count; e += gridDim.x * 256) {
+        float m1 = __builtin_inff(), m2 = __builtin_inff(); int i1 = 0x7fffffff;
+        for (int sl = 0; sl < FB_SPLIT; ++sl) {
+            const float4 p = part[(size_t)e * FB_SPLIT + sl];
+            top2_merge(m1, i1, m2, p.x, __float_as_int(p.y), p.z);
+        }
+        if (MIN2_INIT < m2) m2 = MIN2_INIT;
+        emit_match(fb_list[e], m1, i1, m2, mode, index_offset, ambiguity, result, min1_out, idx_out, min2_out);
     }
 }
 
@@ -532,10 +558,12 @@ static MatchWs carve(void *workspace, int nA, int nB, const MatchPlan &p)
     char *base = static_cast<char *>(workspace);
     w.na = reinterpret_cast<float *>(base); base += align256((size_t)nA * 4);
     w.nb = reinterpret_cast<float *>(base); base += align256((size_t)nB * 4);
-    w.partial = reinterpret_cast<float4 *>(base); base += align256((size_t)nA * p.S * sizeof(float4));
-    w.partial3 = reinterpret_cast<float *>(base); base += align256((size_t)nA * p.S * sizeof(float));
     w.fb_count = reinterpret_cast<int *>(base); base += 256;
-    w.fb_list = reinterpret_cast<int *>(base);
+    w.fb_list = reinterpret_cast<int *>(base); base += align256((size_t)nA * 4);
+    // partial / partial3 are dead once match_finalize_kernel has run: the fallback reuses the space from `partial` on
+    // for its FB_SPLIT slice results per listed query (<= nA * MAX_CHUNKS float4, covered by the workspace bound)
+    w.partial = reinterpret_cast<float4 *>(base); base += align256((size_t)nA * p.S * sizeof(float4));
+    w.partial3 = reinterpret_cast<float *>(base);
     return w;
 }
 
@@ -560,7 +588,10 @@ static int run_fused(const float *A, int nA, const float *B, int nB, int mode, i
     hipLaunchKernelGGL(match_finalize_kernel, dim3(nm_divup(4 * nA, 256)), dim3(256), 0, st, A, nA, B, nB, p.S, w.partial,
                        w.partial3, w.na, mode, index_offset, ambiguity, result, min1, idx1, min2, w.fb_count, w.fb_list);
     NM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(match_fallback_kernel, dim3(256), dim3(256), 0, st, A, B, nB, w.fb_count, w.fb_list, mode,
+    static_assert(FB_SPLIT <= MAX_CHUNKS, "fallback slices reuse the partial area");
+    hipLaunchKernelGGL(match_fallback_kernel, dim3(FB_SPLIT, 64), dim3(256), 0, st, A, B, nB, w.fb_count, w.fb_list, w.partial);
+    NM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(match_fallback_merge_kernel, dim3(64), dim3(256), 0, st, w.fb_count, w.fb_list, w.partial, mode,
                        index_offset, ambiguity, result, min1, idx1, min2);
     NM_LAUNCH_CHECK();
     return 0;
