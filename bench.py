@@ -116,9 +116,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=32, help="frame pairs per GPU per step")
-    ap.add_argument("--streams", type=int, default=16)
-    ap.add_argument("--batch", type=int, default=4, help="frames per nm_sift_detect_describe_batch call (4 = two pairs)")
-    ap.add_argument("--host-threads", type=int, default=8, help="host threads that enqueue the detect calls")
+    ap.add_argument("--streams", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=16, help="frames per nm_sift_detect_describe_batch call (16 = 8 pairs)")
+    ap.add_argument("--host-threads", type=int, default=1, help="host threads that enqueue the detect calls")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allpairs", action="store_true", help="skip the secondary config-5 measurement")
     args = ap.parse_args()
@@ -178,8 +178,8 @@ def main():
 
     def enqueue_detect(t):
         # calls t, t+T, ... of the step, each on its stream (torch's current stream is per host thread; the C ABI
-        # itself takes the stream as an argument). Interleaved issue from several threads mixes the kernels of
-        # different calls in the hardware queues, which the GPU overlaps better than one call after the other.
+        # itself takes the stream as an argument). With 16-frame calls one host thread is enough (~16 us of host time
+        # per frame); several threads matter for small batches, where interleaved issue mixes the calls' kernels.
         for c in range(t, NB - 1, T):
             with torch.cuda.stream(streams[c % S]):
                 nm.detect_describe_batch(arenas[c * B:(c + 1) * B], frames[c * B:(c + 1) * B])

@@ -217,13 +217,13 @@ NM_API size_t nm_sift_arena_bytes(const nm_sift_arena *arena);
  * siftfunctions.cu:165-169). kpts (capacity float4) and orients (capacity float2) are optional (NULL).        */
 NM_API int nm_sift_detect_describe(nm_sift_arena *arena, const float *gray, float *desc, float *x, float *y,
                                    float *kpts, float *orients, int *d_num_items, void *stream);
-/* The same for n <= NM_SIFT_MAX_BATCH frames of equal size in ONE launch sequence (arrays of n pointers; arenas must be
- * distinct; kpts, orients, d_num_items may be NULL or hold NULLs). The scale-space launches cover all frames at once --
- * a single 1080p frame is only ~4 workgroups per CU at octave 0, a frame pair fills the chip -- while detection and
- * description of the individual frames run concurrently on the arenas' internal side streams. Results are identical
- * to n separate nm_sift_detect_describe calls. No reference counterpart (the reference processes one frame per call
- * sequence, sift/siftfunctions.cu:42-181).                                                                        */
-#define NM_SIFT_MAX_BATCH 4
+/* The same for n <= NM_SIFT_MAX_BATCH frames in ONE launch sequence (arrays of n pointers; the arenas must be distinct
+ * and of equal width, height and capacity; kpts, orients, d_num_items may be NULL or hold NULLs). EVERY launch covers
+ * all frames of the call (the frame is a grid dimension): a single 1080p frame is only ~4 workgroups per CU at octave
+ * 0 and its higher octaves are pure launch latency, a batch fills the chip and shares the ~60 launches. Results are
+ * identical to n separate nm_sift_detect_describe calls. No reference counterpart (the reference processes one frame
+ * per call sequence, sift/siftfunctions.cu:42-181).                                                               */
+#define NM_SIFT_MAX_BATCH 16
 NM_API int nm_sift_detect_describe_batch(nm_sift_arena *const *arenas, int n, const float *const *gray,
                                          float *const *desc, float *const *x, float *const *y, float *const *kpts,
                                          float *const *orients, int *const *d_num_items, void *stream);

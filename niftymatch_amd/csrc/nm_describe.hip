@@ -266,13 +266,15 @@ __global__ __launch_bounds__(256) void frame_orient_kernel(NmDescribeArgs a)
 {
     __shared__ float s_part[4][ORI_LDS];
     const int wave = threadIdx.x >> 6;
-    const int n = a.book->num_items;
-    const float4 *kpts = reinterpret_cast<const float4 *>(a.kpts);
-    float2 *orients = reinterpret_cast<float2 *>(a.orients);
+    const int frame = blockIdx.y;
+    const NmFrameBook *book = a.book[frame];
+    const int n = book->num_items;
+    const float4 *kpts = reinterpret_cast<const float4 *>(a.kpts[frame]);
+    float2 *orients = reinterpret_cast<float2 *>(a.orients[frame]);
     for (int pt = blockIdx.x * 4 + wave; pt < n; pt += gridDim.x * 4) {
-        const int o = octave_of(a.book, a.num_octaves, pt);
+        const int o = octave_of(book, a.num_octaves, pt);
         float th0, th1;                           // unset components stay -1 (pyramidata.cu:90)
-        orient_wave(kpts[pt], reinterpret_cast<const float2 *>(a.geom[o].grad), a.geom[o].ow, a.geom[o].oh, 1.5f,
+        orient_wave(kpts[pt], reinterpret_cast<const float2 *>(a.grad[frame][o]), a.geom[o].ow, a.geom[o].oh, 1.5f,
                     a.geom[o].xper, th0, th1, s_part[wave]);
         if ((threadIdx.x & 63) == 0) orients[pt] = make_float2(th0, th1);
     }
@@ -281,13 +283,16 @@ __global__ __launch_bounds__(256) void frame_orient_kernel(NmDescribeArgs a)
 __global__ __launch_bounds__(64) void frame_desc_kernel(NmDescribeArgs a)
 {
     __shared__ __attribute__((aligned(16))) float part[DESC_LDS];
-    const int n = a.book->num_items;
-    const float4 *kpts = reinterpret_cast<const float4 *>(a.kpts);
-    const float2 *orients = reinterpret_cast<const float2 *>(a.orients);
+    const int frame = blockIdx.y;
+    const NmFrameBook *book = a.book[frame];
+    const int n = book->num_items;
+    const float4 *kpts = reinterpret_cast<const float4 *>(a.kpts[frame]);
+    const float2 *orients = reinterpret_cast<const float2 *>(a.orients[frame]);
     for (int pt = blockIdx.x; pt < n; pt += gridDim.x) {
-        const int o = octave_of(a.book, a.num_octaves, pt);
-        describe_wave(kpts[pt], orients[pt].x, reinterpret_cast<const float2 *>(a.geom[o].grad), a.geom[o].ow,
-                      a.geom[o].oh, a.num_dogs, a.geom[o].xper, a.desc + (size_t)pt * 128, a.x + pt, a.y + pt, part);
+        const int o = octave_of(book, a.num_octaves, pt);
+        describe_wave(kpts[pt], orients[pt].x, reinterpret_cast<const float2 *>(a.grad[frame][o]), a.geom[o].ow,
+                      a.geom[o].oh, a.num_dogs, a.geom[o].xper, a.desc[frame] + (size_t)pt * 128, a.x[frame] + pt,
+                      a.y[frame] + pt, part);
     }
 }
 
@@ -295,9 +300,10 @@ __global__ __launch_bounds__(64) void frame_desc_kernel(NmDescribeArgs a)
 
 int nm_launch_frame_describe(const NmDescribeArgs &a, hipStream_t stream)
 {
-    hipLaunchKernelGGL(frame_orient_kernel, dim3(1024), dim3(256), 0, stream, a);
+    if (a.n <= 0) return 0;
+    hipLaunchKernelGGL(frame_orient_kernel, dim3(1024, a.n), dim3(256), 0, stream, a);
     NM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(frame_desc_kernel, dim3(4096), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(frame_desc_kernel, dim3(4096, a.n), dim3(64), 0, stream, a);
     NM_LAUNCH_CHECK();
     return 0;
 }

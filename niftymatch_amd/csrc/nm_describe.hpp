@@ -3,20 +3,22 @@
 #include "nm_common.hpp"
 
 struct NmOctGeom {
-    const float *grad;   // float2 planes of gradient levels 0..2 of this octave, stride ow*oh
     int ow, oh;
     float xper;
 };
 
+// Per-frame pointers are arrays over the frames of a batched call; blockIdx.y selects the frame.
 struct NmDescribeArgs {
+    int n;                                       // frames
     NmOctGeom geom[20];
+    const float *grad[NM_MAX_BATCH][20];         // float2 planes of gradient levels 0..2 of octave o, stride ow*oh
     int num_octaves;
     int num_dogs;
-    const NmFrameBook *book;
-    const float *kpts;   // float4, output order
-    float *orients;      // float2, output order
-    float *desc;         // capacity x 128
-    float *x, *y;
+    const NmFrameBook *book[NM_MAX_BATCH];
+    const float *kpts[NM_MAX_BATCH];   // float4, output order
+    float *orients[NM_MAX_BATCH];      // float2, output order
+    float *desc[NM_MAX_BATCH];         // capacity x 128
+    float *x[NM_MAX_BATCH], *y[NM_MAX_BATCH];
 };
 
 int nm_launch_frame_describe(const NmDescribeArgs &a, hipStream_t stream);

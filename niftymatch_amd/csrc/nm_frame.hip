@@ -193,11 +193,12 @@ int nm_sift_octave_pyramid(nm_sift_arena *a, int ow, int oh, void *stream)
     return octave_pyramid(&a, 1, 0, ow, oh, true, nm_stream(stream));
 }
 
-// Frame driver for n <= NM_MAX_BATCH equally sized frames. The scale-space chain (base blur, decimations, 5 fused
-// Gaussian launches per octave) is ONE launch sequence on the caller's stream covering all frames; extrema + ordered
-// compaction of (frame f, octave o) run on arena f's side stream as soon as that octave's DoG planes exist, i.e.
-// concurrently with the pyramid of octave o+1 and with the other frames' detection; orientation + descriptors of frame
-// f follow on the same side stream; the caller's stream joins all side streams at the end. Capture-safe (events only).
+// Frame driver for n <= NM_MAX_BATCH equally sized frames: EVERY launch covers all frames of the call (the frame index is
+// a grid dimension), so a call of 4 frames issues the same ~60 launches as a call of one, each 4x fatter. The
+// scale-space chain (base blur, decimations, 5 fused Gaussian launches per octave) runs on the caller's stream; extrema +
+// ordered compaction of octave o run on the first arena's side stream as soon as that octave's DoG planes exist, i.e.
+// concurrently with the pyramid of octave o+1; orientation + descriptors follow on the side stream, which the caller's
+// stream joins at the end. Capture-safe (events only).
 int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *const *gray, float *const *desc,
                                   float *const *x, float *const *y, float *const *kpts, float *const *orients,
                                   int *const *d_num_items, void *stream)
@@ -205,7 +206,8 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
     if (!as || n <= 0 || n > NM_MAX_BATCH || !gray || !desc || !x || !y) return (int)hipErrorInvalidValue;
     for (int f = 0; f < n; ++f) {
         if (!as[f] || !gray[f] || !desc[f] || !x[f] || !y[f]) return (int)hipErrorInvalidValue;
-        if (as[f]->width != as[0]->width || as[f]->height != as[0]->height) return (int)hipErrorInvalidValue;
+        if (as[f]->width != as[0]->width || as[f]->height != as[0]->height || as[f]->capacity != as[0]->capacity)
+            return (int)hipErrorInvalidValue;
         for (int g = 0; g < f; ++g)
             if (as[g] == as[f]) return (int)hipErrorInvalidValue;
     }
@@ -218,17 +220,17 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
     int rc = nm_launch_convolve_batch(base, W, H, as[0]->taps_base, as[0]->base_radius, st);
     if (rc) return rc;
 
-    NmDescribeArgs da[NM_MAX_BATCH];
+    NmDescribeArgs da{};
     float *kp[NM_MAX_BATCH];
+    da.n = n; da.num_octaves = P._num_octaves; da.num_dogs = P._num_dog_levels;
     for (int f = 0; f < n; ++f) {
         nm_sift_arena *a = as[f];
-        da[f] = NmDescribeArgs{};
-        da[f].num_octaves = P._num_octaves; da[f].num_dogs = P._num_dog_levels; da[f].book = a->book;
         kp[f] = (kpts && kpts[f]) ? kpts[f] : a->kpts;
-        da[f].kpts = kp[f];
-        da[f].orients = (orients && orients[f]) ? orients[f] : a->orients;
-        da[f].desc = desc[f]; da[f].x = x[f]; da[f].y = y[f];
+        da.book[f] = a->book; da.kpts[f] = kp[f];
+        da.orients[f] = (orients && orients[f]) ? orients[f] : a->orients;
+        da.desc[f] = desc[f]; da.x[f] = x[f]; da.y[f] = y[f];
     }
+    hipStream_t side = as[0]->side;          // every detection / description launch covers all frames of the call
     for (int o = 0; o < P._num_octaves; ++o) {
         const int ow = W >> o, oh = H >> o;
         const float xper = (float)std::pow(2.0, o);
@@ -242,34 +244,38 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
         rc = octave_pyramid(as, n, o, ow, oh, false, st);
         if (rc) return rc;
         NM_RETURN_IF(hipEventRecord(as[0]->ev_pyr[o], st));
+        NM_RETURN_IF(hipStreamWaitEvent(side, as[0]->ev_pyr[o], 0));
 
         const int nseg = nm_divup(ow, 256);
         const int n_blocks = oh * nseg;
+        NmDetectArgs d{};
+        NmScanArgs s{};
+        NmGatherArgs g{};
+        d.n = s.n = g.n = n;
+        d.ow = ow; d.oh = oh; d.peak = P._peak_threshold; d.edge = P._edge_threshold; d.xper = xper;
+        d.sigma0 = P._sigma_0; d.num_dogs = P._num_dog_levels; d.stage_stride = as[0]->stage_stride;
+        d.n_blocks = n_blocks; d.nseg = nseg;
+        s.n_blocks = n_blocks; s.octave = o;
+        g.stage_stride = as[0]->stage_stride; g.n_blocks = n_blocks; g.octave = o;
+        s.capacity = as[0]->capacity;
         for (int f = 0; f < n; ++f) {
             nm_sift_arena *a = as[f];
-            NM_RETURN_IF(hipStreamWaitEvent(as[f]->side, as[0]->ev_pyr[o], 0));
-            NmDetectArgs d{};
-            for (int i = 0; i < 5; ++i) d.dog[i] = a->dog[o][i];
-            d.ow = ow; d.oh = oh; d.peak = P._peak_threshold; d.edge = P._edge_threshold; d.xper = xper;
-            d.sigma0 = P._sigma_0; d.num_dogs = P._num_dog_levels; d.staging = a->staging; d.stage_stride = a->stage_stride;
-            d.counts = a->counts; d.n_blocks = n_blocks; d.nseg = nseg;
-            NmScanArgs s{};
-            s.counts = a->counts; s.offsets = a->offsets; s.n_blocks = n_blocks; s.octave = o; s.capacity = a->capacity;
-            s.book = a->book; s.d_num_items = d_num_items ? d_num_items[f] : nullptr;
-            NmGatherArgs g{};
-            g.staging = a->staging; g.stage_stride = a->stage_stride; g.counts = a->counts; g.offsets = a->offsets;
-            g.n_blocks = n_blocks; g.octave = o; g.book = a->book; g.kpts = kp[f];
-            rc = nm_launch_detect_octave(d, s, g, as[f]->side);
-            if (rc) return rc;
-            da[f].geom[o].grad = a->grad[o]; da[f].geom[o].ow = ow; da[f].geom[o].oh = oh; da[f].geom[o].xper = xper;
+            for (int i = 0; i < 5; ++i) d.dog[f][i] = a->dog[o][i];
+            d.staging[f] = a->staging; d.counts[f] = a->counts;
+            s.counts[f] = a->counts; s.offsets[f] = a->offsets; s.book[f] = a->book;
+            s.d_num_items[f] = d_num_items ? d_num_items[f] : nullptr;
+            g.staging[f] = a->staging; g.counts[f] = a->counts; g.offsets[f] = a->offsets; g.book[f] = a->book;
+            g.kpts[f] = kp[f];
+            da.grad[f][o] = a->grad[o];
         }
-    }
-    for (int f = 0; f < n; ++f) {
-        rc = nm_launch_frame_describe(da[f], as[f]->side);
+        rc = nm_launch_detect_octave(d, s, g, side);
         if (rc) return rc;
-        NM_RETURN_IF(hipEventRecord(as[f]->ev_join, as[f]->side));
-        NM_RETURN_IF(hipStreamWaitEvent(st, as[f]->ev_join, 0));
+        da.geom[o].ow = ow; da.geom[o].oh = oh; da.geom[o].xper = xper;
     }
+    rc = nm_launch_frame_describe(da, side);
+    if (rc) return rc;
+    NM_RETURN_IF(hipEventRecord(as[0]->ev_join, side));
+    NM_RETURN_IF(hipStreamWaitEvent(st, as[0]->ev_join, 0));
     return 0;
 }
 

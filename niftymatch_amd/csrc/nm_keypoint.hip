@@ -235,6 +235,8 @@ constexpr int DET_ROWS = 4;      // image rows per workgroup: 6 rows are loaded 
 __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
 {
     __shared__ int s_cnt[2][4][3];
+    const int frame = blockIdx.y;
+    const float *const *dog = a.dog[frame];
     const int seg = blockIdx.x % a.nseg, yg = blockIdx.x / a.nseg;
     const int y0 = yg * DET_ROWS;
     const int x = seg * 256 + threadIdx.x;
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
         const int yr = min(max(yy, 0), oh - 1);
 #pragma unroll
         for (int p = 0; p < 5; ++p) {
-            const float *row = a.dog[p] + (size_t)yr * ow;
+            const float *row = dog[p] + (size_t)yr * ow;
             raw_mid[buf][p] = row[xc];
             raw_ev[buf][p] = 0.f;
             if (edge_lane) raw_ev[buf][p] = row[xe];
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
             f[level] = interior && ((cv <= thr && is_min) || (cv >= thr && is_max));
             kp[level] = make_float4(-1.f, -1.f, -1.f, -1.f);
             if (f[level])
-                f[level] = refine(a.dog[level + 1], a.dog[level], a.dog[level + 2], x, y, ow, a.peak, a.edge, a.xper,
+                f[level] = refine(dog[level + 1], dog[level], dog[level + 2], x, y, ow, a.peak, a.edge, a.xper,
                                   a.sigma0, a.num_dogs, level, kp[level]);
         }
         // ordered compaction of the row segment (= one unit), 3 levels with one barrier
@@ -328,9 +330,9 @@ __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
                     if (w < wave) off += c;
                     total += c;
                 }
-                float4 *st = reinterpret_cast<float4 *>(a.staging) + (size_t)level * a.stage_stride + (size_t)unit * 256;
+                float4 *st = reinterpret_cast<float4 *>(a.staging[frame]) + (size_t)level * a.stage_stride + (size_t)unit * 256;
                 if (f[level]) st[off + rank[level]] = kp[level];
-                if (threadIdx.x == 0) a.counts[level * a.n_blocks + unit] = total;
+                if (threadIdx.x == 0) a.counts[frame][level * a.n_blocks + unit] = total;
             }
         }
     }
@@ -340,13 +342,14 @@ __global__ __launch_bounds__(1024) void scan_book_kernel(NmScanArgs a)
 {
     __shared__ int s[1024];
     __shared__ int totals[3];
+    const int frame = blockIdx.x;
     for (int l = 0; l < 3; ++l) {
-        const int tot = block_exclusive_scan_1024(a.counts + l * a.n_blocks, a.offsets + l * a.n_blocks, a.n_blocks, s);
+        const int tot = block_exclusive_scan_1024(a.counts[frame] + l * a.n_blocks, a.offsets[frame] + l * a.n_blocks, a.n_blocks, s);
         if (threadIdx.x == 0) totals[l] = tot;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        NmFrameBook *b = a.book;
+        NmFrameBook *b = a.book[frame];
         int num_items = (a.octave == 0) ? 0 : b->num_items;
         b->oct_base[a.octave] = num_items;
         bool live = true;                         // sift/siftfunctions.cu:145,160: an empty level ends the octave
@@ -363,31 +366,32 @@ __global__ __launch_bounds__(1024) void scan_book_kernel(NmScanArgs a)
         }
         b->num_items = num_items;
         b->oct_base[a.octave + 1] = num_items;
-        if (a.d_num_items) *a.d_num_items = num_items;
+        if (a.d_num_items[frame]) *a.d_num_items[frame] = num_items;
     }
 }
 
 __global__ __launch_bounds__(256) void gather_stage_kernel(NmGatherArgs a)
 {
-    const int level = blockIdx.y;
-    const int cnt = a.counts[level * a.n_blocks + blockIdx.x];
+    const int level = blockIdx.y, frame = blockIdx.z;
+    const int cnt = a.counts[frame][level * a.n_blocks + blockIdx.x];
     if ((int)threadIdx.x >= cnt) return;
-    const int pos = a.offsets[level * a.n_blocks + blockIdx.x] + threadIdx.x;
-    if (pos >= a.book->lvl_n[a.octave][level]) return;
-    const float4 *st = reinterpret_cast<const float4 *>(a.staging) + (size_t)level * a.stage_stride + (size_t)blockIdx.x * 256;
-    reinterpret_cast<float4 *>(a.kpts)[a.book->lvl_base[a.octave][level] + pos] = st[threadIdx.x];
+    const int pos = a.offsets[frame][level * a.n_blocks + blockIdx.x] + threadIdx.x;
+    const NmFrameBook *book = a.book[frame];
+    if (pos >= book->lvl_n[a.octave][level]) return;
+    const float4 *st = reinterpret_cast<const float4 *>(a.staging[frame]) + (size_t)level * a.stage_stride + (size_t)blockIdx.x * 256;
+    reinterpret_cast<float4 *>(a.kpts[frame])[book->lvl_base[a.octave][level] + pos] = st[threadIdx.x];
 }
 
 }  // namespace
 
 int nm_launch_detect_octave(const NmDetectArgs &d, const NmScanArgs &s, const NmGatherArgs &g, hipStream_t stream)
 {
-    if (d.n_blocks <= 0) return 0;
-    hipLaunchKernelGGL(detect_stage_kernel, dim3(d.nseg * nm_divup(d.oh, DET_ROWS)), dim3(256), 0, stream, d);
+    if (d.n_blocks <= 0 || d.n <= 0) return 0;
+    hipLaunchKernelGGL(detect_stage_kernel, dim3(d.nseg * nm_divup(d.oh, DET_ROWS), d.n), dim3(256), 0, stream, d);
     NM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(scan_book_kernel, dim3(1), dim3(1024), 0, stream, s);
+    hipLaunchKernelGGL(scan_book_kernel, dim3(s.n), dim3(1024), 0, stream, s);
     NM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gather_stage_kernel, dim3(g.n_blocks, 3), dim3(256), 0, stream, g);
+    hipLaunchKernelGGL(gather_stage_kernel, dim3(g.n_blocks, 3, g.n), dim3(256), 0, stream, g);
     NM_LAUNCH_CHECK();
     return 0;
 }

@@ -2,37 +2,41 @@
 #pragma once
 #include "nm_common.hpp"
 
+// Per-frame pointers are arrays over the frames of a batched call (NM_MAX_BATCH); blockIdx selects the frame.
 struct NmDetectArgs {
-    const float *dog[5];   // DoG planes 0..4 of the octave
+    int n;                                  // frames
+    const float *dog[NM_MAX_BATCH][5];      // DoG planes 0..4 of the octave
     int ow, oh;
     float peak, edge, xper, sigma0;
     int num_dogs;
-    float *staging;        // 3 x stage_stride float4: block b of level l writes its survivors at [l][b*256 ...]
+    float *staging[NM_MAX_BATCH];   // 3 x stage_stride float4: block b of level l writes its survivors at [l][b*256 ...]
     size_t stage_stride;   // in float4 elements
-    int *counts;           // 3 x n_blocks
+    int *counts[NM_MAX_BATCH];      // 3 x n_blocks
     int n_blocks;          // oh * nseg units: a unit is one 256-pixel segment of one row, units in raster order
     int nseg;              // ceil(ow / 256)
 };
 
 struct NmScanArgs {
-    const int *counts;
-    int *offsets;
+    int n;
+    const int *counts[NM_MAX_BATCH];
+    int *offsets[NM_MAX_BATCH];
     int n_blocks;
     int octave;
     int capacity;
-    NmFrameBook *book;
-    int *d_num_items;      // optional mirror of book->num_items
+    NmFrameBook *book[NM_MAX_BATCH];
+    int *d_num_items[NM_MAX_BATCH];      // optional mirror of book->num_items
 };
 
 struct NmGatherArgs {
-    const float *staging;
+    int n;
+    const float *staging[NM_MAX_BATCH];
     size_t stage_stride;
-    const int *counts;
-    const int *offsets;
+    const int *counts[NM_MAX_BATCH];
+    const int *offsets[NM_MAX_BATCH];
     int n_blocks;
     int octave;
-    const NmFrameBook *book;
-    float *kpts;           // output-ordered float4 list
+    const NmFrameBook *book[NM_MAX_BATCH];
+    float *kpts[NM_MAX_BATCH];           // output-ordered float4 lists
 };
 
 int nm_launch_detect_octave(const NmDetectArgs &d, const NmScanArgs &s, const NmGatherArgs &g, hipStream_t stream);

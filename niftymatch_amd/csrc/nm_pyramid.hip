@@ -331,13 +331,10 @@ __global__ __launch_bounds__(256) void conv_pk_kernel(NmConvBatch batch, int wid
     if (slot >= band || tile >= ntiles) return;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int x0 = tx * TW, y0 = ty * TH;
-    // uniform selects, not dynamic indexing: a by-value kernel argument indexed at run time would be copied to scratch
-#define NM_PICK(A) (frame == 0 ? batch.A[0] : frame == 1 ? batch.A[1] : frame == 2 ? batch.A[2] : batch.A[3])
-    float *__restrict__ result = NM_PICK(result);
-    const float *__restrict__ image = NM_PICK(image);
-    float *__restrict__ dog = NM_PICK(dog);
-    float2 *__restrict__ grad = reinterpret_cast<float2 *>(NM_PICK(grad));
-#undef NM_PICK
+    float *__restrict__ result = batch.result[frame];           // uniform index into the kernarg segment: scalar loads
+    const float *__restrict__ image = batch.image[frame];
+    float *__restrict__ dog = batch.dog[frame];
+    float2 *__restrict__ grad = reinterpret_cast<float2 *>(batch.grad[frame]);
 
     float w[2 * R + 1];
 #pragma unroll
@@ -674,9 +671,8 @@ __global__ __launch_bounds__(256) void downsample2_batch_kernel(NmPlaneBatch b, 
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= rw || y >= rh) return;
-    const int f = blockIdx.z;
-    float *__restrict__ dst = f == 0 ? b.dst[0] : f == 1 ? b.dst[1] : f == 2 ? b.dst[2] : b.dst[3];
-    const float *__restrict__ src = f == 0 ? b.src[0] : f == 1 ? b.src[1] : f == 2 ? b.src[2] : b.src[3];
+    float *__restrict__ dst = b.dst[blockIdx.z];
+    const float *__restrict__ src = b.src[blockIdx.z];
     dst[(size_t)y * rw + x] = src[(size_t)(y * 2) * sw + (x * 2)];
 }
 

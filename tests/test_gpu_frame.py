@@ -106,7 +106,7 @@ def test_frame_batch_rejects_bad_arguments(nm, cuda):
     with pytest.raises(nm.NmError):
         nm.detect_describe_batch([a, a], [f64, f64])           # the same arena twice
     with pytest.raises(nm.NmError):
-        nm.detect_describe_batch([a] * 5, [f64] * 5)           # more than SIFT_MAX_BATCH
+        nm.detect_describe_batch([a] * (nm.SIFT_MAX_BATCH + 1), [f64] * (nm.SIFT_MAX_BATCH + 1))   # too many
     a.close(); b.close()
 
 
