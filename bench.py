@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--streams", type=int, default=4)
     ap.add_argument("--batch", type=int, default=16, help="frames per nm_sift_detect_describe_batch call (16 = 8 pairs)")
     ap.add_argument("--host-threads", type=int, default=1, help="host threads that enqueue the detect calls")
+    ap.add_argument("--overlap", action="store_true",
+                    help="pipeline the matches of a detect call with the next call's detection (higher throughput; the "
+                         "matcher then shares the chip, so its roofline reading drops -- not the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allpairs", action="store_true", help="skip the secondary config-5 measurement")
     args = ap.parse_args()
@@ -184,6 +187,30 @@ def main():
             with torch.cuda.stream(streams[c % S]):
                 nm.detect_describe_batch(arenas[c * B:(c + 1) * B], frames[c * B:(c + 1) * B])
 
+    call_done = [torch.cuda.Event() for _ in range(NB)]
+
+    def step_overlapped(timed):
+        """--overlap: the matches of the pairs of call c are queued (one match stream) as soon as call c has finished,
+        while the next calls' detection proceeds on the other streams. Same work, no probes of isolated sequences."""
+        for c in range(NB):
+            with torch.cuda.stream(streams[c % S]):
+                nm.detect_describe_batch(arenas[c * B:(c + 1) * B], frames[c * B:(c + 1) * B])
+                call_done[c].record()
+            mstream.wait_event(call_done[c])
+            with torch.cuda.stream(mstream):
+                for i in range(c * B // 2, (c + 1) * B // 2):
+                    nA, nB = counts[i]
+                    if timed:
+                        nm.profile_events(nm.PROF_MATCH_TOP2, ev_match[i][0], ev_match[i][1])
+                    nm.sift_match(arenas[2 * i].desc, arenas[2 * i + 1].desc, 0.8, prior=results[i], workspace=ws, nA=nA, nB=nB)
+                if timed:
+                    nm.profile_events(nm.PROF_MATCH_TOP2, None, None)
+        for s in range(S):
+            streams[s].wait_stream(mstream)
+        if timed:
+            mstream.synchronize()
+            match_ms.extend(a.elapsed_time(b) for a, b in ev_match)
+
     def step(timed):
         """One batch. Detect+describe of the 2P frames = NB calls of B frames each (B = 2: one frame pair per call),
         spread over S streams; the P fused matches then run back to back on one stream (a match launch fills the chip
@@ -223,12 +250,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    overlap = args.overlap and B % 2 == 0
+    run_step = step_overlapped if overlap else step
     for _ in range(args.warmup):
-        step(False)
+        run_step(False)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(True)
+        run_step(True)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -256,7 +285,7 @@ def main():
         pairs_total = P * world * args.steps
         nA, nB = counts[0]
         m_ms = sum(match_ms) / len(match_ms)            # every match launch of the timed region
-        p_ms = sum(pyr_ms) / len(pyr_ms)
+        p_ms = sum(pyr_ms) / len(pyr_ms) if pyr_ms else float("nan")
         flops = 256.0 * sum(a * b for a, b in counts) / len(counts)      # 2*N*M*128 per launch
         # octave 0, levels 1..5 of the B frames of one call: 40 (Gaussian) + 60 (DoG) + 36 (gradients) B/px
         pyr_bytes = 136.0 * W * H * B
@@ -273,7 +302,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[2]: SIFT detect+describe x2 + fused BF L2 match per 1920x1080 pair",
                        "pairs_per_gpu_per_step": P, "detect_streams": S, "frames_per_detect_call": B,
-                       "host_enqueue_threads": T,
+                       "host_enqueue_threads": T, "phases": "overlapped" if overlap else "detect then match",
                        "keypoints_pair0": [nA, nB], "capacity": CAP,
                        "parallelism": "frame-pair sharding, %d rank(s), no data-path collective" % world},
             "keypoints_per_s": round(kp_all * args.steps / dt, 1),

@@ -17,14 +17,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=4)
     ap.add_argument("--size", default="1920x1080")
+    ap.add_argument("--batch", type=int, default=1, help="frames per detect call")
     args = ap.parse_args()
     w, h = map(int, args.size.split("x"))
     bench.W, bench.H = w, h
     dev = torch.device("cuda:0")
     frames = bench.make_frames(nm, torch, dev, list(range(args.frames)))
-    arenas = [nm.SiftArena(w, h, bench.CAP, device=dev) for _ in range(2)]
+    arenas = [nm.SiftArena(w, h, bench.CAP, device=dev) for _ in range(max(2, args.batch))]
     ws = nm.MatchWorkspace(bench.CAP, bench.CAP, dev)
     res = torch.full((bench.CAP,), -1, dtype=torch.int32, device=dev)
+    if args.batch > 1:
+        for rep in range(3):
+            nm.detect_describe_batch(arenas[:args.batch], [frames[i % args.frames] for i in range(args.batch)])
+            torch.cuda.synchronize()
     for rep in range(2):
         for i in range(0, args.frames, 2):
             arenas[0].detect_describe(frames[i]); torch.cuda.synchronize()
