@@ -27,31 +27,39 @@ constexpr int QB = 256;            // queries per workgroup (32 per wave, fragme
 constexpr float MIN2_INIT = 2139095040.0f;   // (float)0x7f800000, match.cu:91
 constexpr int MAX_CHUNKS = 64;     // upper bound of the candidate-chunk count S of any grid plan
 
-struct MatchPlan { int qblocks, S, chunk; };
+// Work = qblocks x T units, a unit being (256 queries) x (one 128-candidate tile), linearised query-block-major. The grid
+// is G persistent workgroups (one per CU: the kernel owns the LDS), each taking a contiguous range of `base` or `base+1`
+// units: every CU carries the same MFMA load to within one tile and the chip drains at once. A range that crosses a
+// query-block boundary is processed as separate SEGMENTS (fragments of the new block are reloaded). A query block is
+// covered by at most S consecutive workgroups; segment k of a block writes partial slot k, the workgroup that reaches
+// the block's end also blanks the slots up to S.
+struct MatchPlan { int qblocks, T, G, base, rem, S; };
 
-// Grid = qblocks x S workgroups, one resident per CU (LDS). S is chosen to maximise
-//   (fill of the last round of workgroups over the 256 CUs) x (tiles / (tiles + 0.4)),
-// the second factor being the per-workgroup prologue (staging 256 queries) expressed in 128-candidate tiles.
+static inline int plan_owner(const MatchPlan &p, long u)           // workgroup whose range holds unit u
+{
+    const long cut = (long)p.rem * (p.base + 1);
+    return (u < cut) ? (int)(u / (p.base + 1)) : p.rem + (int)((u - cut) / p.base);
+}
+
 static MatchPlan make_plan(int nA, int nB)
 {
     MatchPlan p;
     const int n_cu = 256;
     p.qblocks = nm_divup(nA > 0 ? nA : 1, QB);
-    const int tiles = nm_divup(nB > 0 ? nB : 1, TILE_C);
-    double best = -1.0;
-    int bestS = 1;
-    for (int S = 1; S <= tiles && S <= MAX_CHUNKS; ++S) {
-        const int tpc = nm_divup(tiles, S);                    // tiles per chunk
-        const int Seff = nm_divup(tiles, tpc);
-        if (Seff != S) continue;
-        const long blocks = (long)p.qblocks * S;
-        const long rounds = (blocks + n_cu - 1) / n_cu;
-        const double fill = (double)blocks / (double)(rounds * n_cu);
-        const double score = fill * ((double)tpc / ((double)tpc + 0.4));
-        if (score > best + 1e-9) { best = score; bestS = S; }
+    p.T = nm_divup(nB > 0 ? nB : 1, TILE_C);
+    const long U = (long)p.qblocks * p.T;
+    const int min_len = nm_divup(p.T, MAX_CHUNKS - 2);            // a block spans <= MAX_CHUNKS - 2 whole ranges + 2 ends
+    long G = U / min_len;
+    if (G > n_cu) G = n_cu;
+    if (G < 1) G = 1;
+    p.G = (int)G;
+    p.base = (int)(U / G);
+    p.rem = (int)(U % G);
+    p.S = 1;
+    for (int qb = 0; qb < p.qblocks; ++qb) {
+        const int span = plan_owner(p, (long)qb * p.T + p.T - 1) - plan_owner(p, (long)qb * p.T) + 1;
+        if (span > p.S) p.S = span;
     }
-    p.chunk = nm_divup(tiles, bestS) * TILE_C;
-    p.S = nm_divup(nB > 0 ? nB : 1, p.chunk);
     return p;
 }
 
@@ -74,8 +82,42 @@ __global__ __launch_bounds__(256) void norms_kernel(const float *__restrict__ A,
     out[i] = acc;
 }
 
-// running best / second best with indices + the VALUE of the third best (m3): the finalize pass uses m3 to prove that
-// no candidate dropped here could have beaten the exact second best (otherwise the query takes the exact fallback).
+// Running best / second best / third best of one lane's query, as integer KEYS. The MFMA pipe and the VALU do not overlap
+// on a SIMD here (measured: every epilogue instruction adds to the kernel time), so the selection is written for the
+// fewest instructions: a key is the distance's bit pattern with its low 5 bits replaced by the slot (0..31) of the
+// candidate inside the current 64-candidate group (v_and_or_b32), keys order like the distances under signed integer
+// comparison (positive floats; the slightly negative values that rounding can produce for near-duplicates all lie
+// within the finalize margin of zero), and inserting a key into a sorted triple is min + med3 + med3 -- the slot
+// travels inside the key. Per group the triple of the 32 accumulator values is built this way (4 instructions per
+// element) and its three keys are merged into the running triple, whose two best also carry the group number.
+// Truncating 5 mantissa bits lowers a value by < 2^-18 relative: the finalize margin accounts for it.
+constexpr int KEY_SLOT_BITS = 5;
+constexpr int KEY_INF = 0x7fffffff;
+
+__device__ __forceinline__ int imed3(int a, int b, int c)        // the compiler only recognises some of the min/max forms
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ void key_insert3(int &k1, int &k2, int &k3, int k)
+{
+    const int n3 = imed3(k2, k3, k), n2 = imed3(k1, k2, k);
+    k1 = min(k1, k); k2 = n2; k3 = n3;
+}
+struct Top3 { int k1, k2, k3, t1, t2; };                          // keys + group tags of the two best
+__device__ __forceinline__ void top3_merge(Top3 &t, int k, int tag)
+{
+    t.k3 = imed3(t.k2, t.k3, k);
+    const bool lt1 = k < t.k1, lt2 = k < t.k2;
+    t.k2 = lt1 ? t.k1 : (lt2 ? k : t.k2);
+    t.t2 = lt1 ? t.t1 : (lt2 ? tag : t.t2);
+    t.k1 = lt1 ? k : t.k1;
+    t.t1 = lt1 ? tag : t.t1;
+}
+__device__ __forceinline__ float key_value(int k) { return __int_as_float(k & ~((1 << KEY_SLOT_BITS) - 1)); }
+
+// used by the lane-half merge at the end of the kernel (values + full indices)
 struct Top2 { float m1, m2, m3; int i1, i2; };
 
 __device__ __forceinline__ void top2_insert(Top2 &t, float d, int j)
@@ -88,138 +130,167 @@ __device__ __forceinline__ void top2_insert(Top2 &t, float d, int j)
     t.i1 = lt1 ? j : t.i1;
 }
 
-// grid = (qblocks, S), 512 threads = 8 waves (2 per SIMD, so one wave's epilogue / staging overlaps the other's MFMAs).
-// Wave w owns queries i0 + 32 w .. +31 with their MFMA fragments resident in VGPRs; candidate tiles of 128 rows stream
-// through a double-buffered LDS image (row pitch KP). Dynamic LDS: 2 * TILE_C * KP floats.
+// grid = G persistent workgroups (see MatchPlan), 512 threads = 8 waves (2 per SIMD). Wave w owns queries i0 + 32 w .. +31
+// of the current query block with their MFMA fragments resident in VGPRs; candidate tiles of 128 rows stream through a
+// double-buffered LDS image (row pitch KP). Dynamic LDS: 2 * TILE_C * KP floats.
 // MFMA orientation: rows (accumulator registers) = candidates, columns (lanes) = queries, so every lane scans its own
 // query's candidates in increasing index order and the running best/second-best never crosses lanes in the loop.
 __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restrict__ A, int nA,
                                                            const float *__restrict__ B, int nB,
                                                            const float *__restrict__ na, const float *__restrict__ nb,
-                                                           int chunk, int S, float4 *__restrict__ partial,
+                                                           MatchPlan plan, float4 *__restrict__ partial,
                                                            float *__restrict__ partial3)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int i0 = blockIdx.x * QB;
-    const int s = blockIdx.y;
-    const int c0 = s * chunk;
-    const int cend = min(c0 + chunk, nB);
-    const int ntiles = (cend > c0) ? (cend - c0 + TILE_C - 1) / TILE_C : 0;
     const int srow = tid >> 5, scol = (tid & 31) * 4;     // staging coordinates: 16 rows x 32 float4 per pass
-
-    // ---- prologue: queries -> LDS (coalesced) -> per-lane MFMA fragments in VGPRs ----
-#pragma unroll 4
-    for (int it = 0; it < QB / 16; ++it) {
-        const int row = srow + 16 * it;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i0 + row < nA) v = *reinterpret_cast<const float4 *>(A + (size_t)(i0 + row) * DIM + scol);
-        *reinterpret_cast<float4 *>(&lds[row * KP + scol]) = v;
-    }
-    __syncthreads();
-    float4 qf[16];
-    const int qi = i0 + wave * 32 + r;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) qf[t] = *reinterpret_cast<const float4 *>(&lds[(wave * 32 + r) * KP + 8 * t + 4 * h]);
-    const float nav = (qi < nA) ? na[qi] : 0.f;
-    const float nq = (h == 0) ? 1.0f : nav;
-    __syncthreads();
-
-    Top2 best;
-    best.m1 = best.m2 = best.m3 = __builtin_inff(); best.i1 = best.i2 = -1;
+    const int T = plan.T, S = plan.S;
+    const int wg = blockIdx.x;
+    long u = (long)wg * plan.base + min(wg, plan.rem);
+    const long u_end = u + plan.base + (wg < plan.rem ? 1 : 0);
 
     float4 st[8];
     float stn = 0.f;
-    auto stage_load = [&](int n) {
-        const int jb = c0 + n * TILE_C;
+    auto stage_load = [&](int tile) {                     // candidates tile*128 .. +127 -> registers
+        const int jb = tile * TILE_C;
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int j = jb + srow + 16 * it;
             st[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < cend) st[it] = *reinterpret_cast<const float4 *>(B + (size_t)j * DIM + scol);
+            if (j < nB) st[it] = *reinterpret_cast<const float4 *>(B + (size_t)j * DIM + scol);
         }
-        if (tid < TILE_C) stn = (jb + tid < cend) ? nb[jb + tid] : __builtin_inff();
+        if (tid < TILE_C) stn = (jb + tid < nB) ? nb[jb + tid] : __builtin_inff();
     };
     auto stage_write = [&](float *buf) {
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int row = srow + 16 * it;
-            const float4 v = st[it];
-            *reinterpret_cast<float4 *>(&buf[row * KP + scol]) = make_float4(-2.f * v.x, -2.f * v.y, -2.f * v.z, -2.f * v.w);
+            *reinterpret_cast<float4 *>(&buf[row * KP + scol]) = st[it];
         }
         if (tid < TILE_C) buf[tid * KP + DIM] = stn;
     };
 
-    if (ntiles > 0) { stage_load(0); stage_write(lds); }
-    __syncthreads();
+    while (u < u_end) {
+        const int qb = (int)(u / T), t0 = (int)(u - (long)qb * T);
+        const int ntiles = min(T - t0, (int)(u_end - u));
+        const int i0 = qb * QB;
+        const int c0 = t0 * TILE_C;
 
-    for (int n = 0; n < ntiles; ++n) {
-        float *buf = lds + (n & 1) * (TILE_C * KP);
-        if (n + 1 < ntiles) stage_load(n + 1);
-        const int jb = c0 + n * TILE_C;
+        // ---- segment prologue: the first candidate tile is requested first (its latency hides behind the query staging),
+        //      queries -> LDS (coalesced) -> per-lane MFMA fragments in VGPRs ----
+        stage_load(t0);
+#pragma unroll 4
+        for (int it = 0; it < QB / 16; ++it) {
+            const int row = srow + 16 * it;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i0 + row < nA) v = *reinterpret_cast<const float4 *>(A + (size_t)(i0 + row) * DIM + scol);
+            *reinterpret_cast<float4 *>(&lds[row * KP + scol]) = v;
+        }
+        __syncthreads();
+        float4 qf[16];
+        const int qi = i0 + wave * 32 + r;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {      // the -2 of  |a|^2 + |b|^2 - 2 a.b  rides on the query fragments (once per segment)
+            const float4 v = *reinterpret_cast<const float4 *>(&lds[(wave * 32 + r) * KP + 8 * t + 4 * h]);
+            qf[t] = make_float4(-2.f * v.x, -2.f * v.y, -2.f * v.z, -2.f * v.w);
+        }
+        const float nav = (qi < nA) ? na[qi] : 0.f;
+        const float nq = (h == 0) ? 1.0f : nav;
+        __syncthreads();
+        stage_write(lds);
+        __syncthreads();
+
+        Top3 best;
+        best.k1 = best.k2 = best.k3 = KEY_INF; best.t1 = best.t2 = 0;
+
+        // A wave multiplies its 32 queries with 64 candidates at a time (two 32 x 32 accumulators), then folds the 32
+        // values each lane holds into its running triple. Within a lane the candidate index increases with (tile, half, g, e).
+        f32x16 acc[2];
+        for (int n = 0; n < ntiles; ++n) {
+            float *buf = lds + (n & 1) * (TILE_C * KP);
+            if (n + 1 < ntiles) stage_load(t0 + n + 1);
 #pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
-            f32x16 acc[2];
+            for (int half = 0; half < 2; ++half) {
+                const float *rowp[2];
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
-            const float *rowp[2];
-#pragma unroll
-            for (int g = 0; g < 2; ++g) rowp[g] = buf + (half * 64 + 32 * g + r) * KP;
-            // augmented k-pair: (nb_j * 1) + (1 * na_i)
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const float nbv = rowp[g][DIM];
-                const float cn = (h == 0) ? nbv : 1.0f;
-                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(cn, nq, acc[g], 0, 0, 0);
-            }
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                float4 cf[2];
-#pragma unroll
-                for (int g = 0; g < 2; ++g) cf[g] = *reinterpret_cast<const float4 *>(rowp[g] + 8 * t + 4 * h);
+                for (int g = 0; g < 2; ++g) rowp[g] = buf + (half * 64 + 32 * g + r) * KP;
+                // augmented k-pair: (nb_j * 1) + (1 * na_i), accumulators start from the inline constant 0
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[g].x, qf[t].x, acc[g], 0, 0, 0);
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[g].y, qf[t].y, acc[g], 0, 0, 0);
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[g].z, qf[t].z, acc[g], 0, 0, 0);
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[g].w, qf[t].w, acc[g], 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+                    const float nbv = rowp[g][DIM];
+                    const float cn = (h == 0) ? nbv : 1.0f;
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(cn, nq, acc[g], 0, 0, 0);
+                }
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    float4 cf[2];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) cf[g] = *reinterpret_cast<const float4 *>(rowp[g] + 8 * t + 4 * h);
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[g].x, qf[t].x, acc[g], 0, 0, 0);
+                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[g].y, qf[t].y, acc[g], 0, 0, 0);
+                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[g].z, qf[t].z, acc[g], 0, 0, 0);
+                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[g].w, qf[t].w, acc[g], 0, 0, 0);
+                    }
+                }
+                int g1 = KEY_INF, g2 = KEY_INF, g3 = KEY_INF;
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        key_insert3(g1, g2, g3, (__float_as_int(acc[g][e]) & ~((1 << KEY_SLOT_BITS) - 1)) | (g * 16 + e));
+                if (__any(g1 < best.k3)) {
+                    const int tag = 2 * n + half;
+                    top3_merge(best, g1, tag);
+                    top3_merge(best, g2, tag);
+                    top3_merge(best, g3, tag);
                 }
             }
-            // running best / second best. Within a lane the candidate index increases with (half, g, e).
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                float mn = __builtin_fminf(acc[g][0], acc[g][1]);
-#pragma unroll
-                for (int e = 2; e < 16; e += 2) mn = __builtin_fminf(mn, __builtin_fminf(acc[g][e], acc[g][e + 1]));
-                if (__any(mn < best.m3)) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int j = jb + half * 64 + 32 * g + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        top2_insert(best, acc[g][e], j);
+            if (n + 1 < ntiles) stage_write(lds + ((n + 1) & 1) * (TILE_C * KP));
+            __syncthreads();
+        }
+
+        // decode (value, candidate index) of the two best, merge the two lane halves (same query, disjoint candidates),
+        // publish into this segment's slot of the query block
+        {
+            auto index_of = [&](int k, int tag) {
+                const int slot = k & ((1 << KEY_SLOT_BITS) - 1), g = slot >> 4, e = slot & 15;
+                return c0 + tag * 64 + 32 * g + (e & 3) + 8 * (e >> 2) + 4 * h;
+            };
+            Top2 m;
+            m.m1 = key_value(best.k1); m.m2 = key_value(best.k2); m.m3 = key_value(best.k3);
+            m.i1 = (best.k1 != KEY_INF) ? index_of(best.k1, best.t1) : -1;
+            m.i2 = (best.k2 != KEY_INF) ? index_of(best.k2, best.t2) : -1;
+            if (best.k1 == KEY_INF) m.m1 = __builtin_inff();
+            if (best.k2 == KEY_INF) m.m2 = __builtin_inff();
+            if (best.k3 == KEY_INF) m.m3 = __builtin_inff();
+            Top2 o;
+            o.m1 = __shfl_xor(m.m1, 32); o.m2 = __shfl_xor(m.m2, 32); o.m3 = __shfl_xor(m.m3, 32);
+            o.i1 = __shfl_xor(m.i1, 32); o.i2 = __shfl_xor(m.i2, 32);
+            if (o.i1 >= 0) top2_insert(m, o.m1, o.i1);
+            if (o.i2 >= 0) top2_insert(m, o.m2, o.i2);
+            m.m3 = __builtin_fminf(m.m3, o.m3);         // o.m3 >= o.m2 >= the merged m2: only the third value can change
+            // slot = how many workgroups before this one also work on this query block
+            const long ub = (long)qb * T, cut = (long)plan.rem * (plan.base + 1);
+            const int first = (ub < cut) ? (int)(ub / (plan.base + 1)) : plan.rem + (int)((ub - cut) / plan.base);
+            const int slot = wg - first;
+            if (h == 0 && qi < nA) {
+                partial[(size_t)qi * S + slot] = make_float4(m.m1, __int_as_float(m.i1), m.m2, __int_as_float(m.i2));
+                partial3[(size_t)qi * S + slot] = m.m3;
+                if (t0 + ntiles == T) {                 // this segment ends the block: blank the slots nobody writes
+                    for (int k = slot + 1; k < S; ++k) {
+                        partial[(size_t)qi * S + k] = make_float4(__builtin_inff(), __int_as_float(-1), __builtin_inff(), __int_as_float(-1));
+                        partial3[(size_t)qi * S + k] = __builtin_inff();
                     }
                 }
             }
         }
-        if (n + 1 < ntiles) stage_write(lds + ((n + 1) & 1) * (TILE_C * KP));
-        __syncthreads();
-    }
-
-    // merge the two lane halves (same query, disjoint candidates) and publish
-    {
-        Top2 o;
-        o.m1 = __shfl_xor(best.m1, 32); o.m2 = __shfl_xor(best.m2, 32); o.m3 = __shfl_xor(best.m3, 32);
-        o.i1 = __shfl_xor(best.i1, 32); o.i2 = __shfl_xor(best.i2, 32);
-        Top2 m = best;
-        if (o.i1 >= 0) top2_insert(m, o.m1, o.i1);
-        if (o.i2 >= 0) top2_insert(m, o.m2, o.i2);
-        m.m3 = __builtin_fminf(m.m3, o.m3);             // o.m3 >= o.m2 >= the merged m2: only the third value can change
-        if (h == 0 && qi < nA) {
-            partial[(size_t)qi * S + s] = make_float4(m.m1, __int_as_float(m.i1), m.m2, __int_as_float(m.i2));
-            partial3[(size_t)qi * S + s] = m.m3;
-        }
+        u += ntiles;
+        __syncthreads();                                  // the next segment's prologue reuses the LDS
     }
 }
 
@@ -327,7 +398,9 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(const float *__rest
     // and has probability < 2^-129). A candidate within the margin of min2 (or a tie of min1 hiding among them) sends
     // the query to the exact fallback.
     const float nai = na[i];
-    const float margin = 2.4e-6f * (3.0f * nai + 2.0f * __builtin_fminf(m2, 4.0f * nai + 4.0f * m1));
+    // The selection keys drop 5 mantissa bits: a reported value undershoots its distance by < 2^-18 relative (3.9e-6).
+    float margin = 2.4e-6f * (3.0f * nai + 2.0f * __builtin_fminf(m2, 4.0f * nai + 4.0f * m1));
+    margin += 4.0e-6f * (m2 + margin);
     if (rest <= m2 + margin && rest < __builtin_inff()) {
         const int pos = atomicAdd(fb_count, 1);
         fb_list[pos] = i;
@@ -580,8 +653,8 @@ static int run_fused(const float *A, int nA, const float *B, int nB, int mode, i
     NM_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     nm_prof_begin(NM_PROF_MATCH_TOP2, st);
-    hipLaunchKernelGGL(match_top2_kernel, dim3(p.qblocks, p.S), dim3(512), lds_bytes, st, A, nA, B, nB, w.na, w.nb,
-                       p.chunk, p.S, w.partial, w.partial3);
+    hipLaunchKernelGGL(match_top2_kernel, dim3(p.G), dim3(512), lds_bytes, st, A, nA, B, nB, w.na, w.nb, p, w.partial,
+                       w.partial3);
     nm_prof_end(NM_PROF_MATCH_TOP2, st);
     NM_LAUNCH_CHECK();
     NM_RETURN_IF(hipMemsetAsync(w.fb_count, 0, sizeof(int), st));
