@@ -257,7 +257,7 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
         d.n_blocks = n_blocks; d.nseg = nseg;
         s.n_blocks = n_blocks; s.octave = o;
         g.stage_stride = as[0]->stage_stride; g.n_blocks = n_blocks; g.octave = o;
-        s.capacity = as[0]->capacity;
+        s.capacity = as[0]->capacity; g.capacity = as[0]->capacity;
         for (int f = 0; f < n; ++f) {
             nm_sift_arena *a = as[f];
             for (int i = 0; i < 5; ++i) d.dog[f][i] = a->dog[o][i];

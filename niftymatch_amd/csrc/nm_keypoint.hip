@@ -370,16 +370,23 @@ __global__ __launch_bounds__(1024) void scan_book_kernel(NmScanArgs a)
     }
 }
 
+// One thread per OUTPUT slot of (frame, level): the unit that holds slot `pos` is the last one whose exclusive offset is
+// <= pos (binary search over the scanned offsets; empty units share their successor's offset and are skipped by the
+// upper bound). A grid over the units instead would launch hundreds of thousands of empty workgroups per octave.
 __global__ __launch_bounds__(256) void gather_stage_kernel(NmGatherArgs a)
 {
     const int level = blockIdx.y, frame = blockIdx.z;
-    const int cnt = a.counts[frame][level * a.n_blocks + blockIdx.x];
-    if ((int)threadIdx.x >= cnt) return;
-    const int pos = a.offsets[frame][level * a.n_blocks + blockIdx.x] + threadIdx.x;
     const NmFrameBook *book = a.book[frame];
+    const int pos = blockIdx.x * 256 + threadIdx.x;
     if (pos >= book->lvl_n[a.octave][level]) return;
-    const float4 *st = reinterpret_cast<const float4 *>(a.staging[frame]) + (size_t)level * a.stage_stride + (size_t)blockIdx.x * 256;
-    reinterpret_cast<float4 *>(a.kpts[frame])[book->lvl_base[a.octave][level] + pos] = st[threadIdx.x];
+    const int *off = a.offsets[frame] + level * a.n_blocks;
+    int lo = 0, hi = a.n_blocks;                      // invariant: off[lo] <= pos, (hi == n_blocks or off[hi] > pos)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (off[mid] <= pos) lo = mid; else hi = mid;
+    }
+    const float4 *st = reinterpret_cast<const float4 *>(a.staging[frame]) + (size_t)level * a.stage_stride + (size_t)lo * 256;
+    reinterpret_cast<float4 *>(a.kpts[frame])[book->lvl_base[a.octave][level] + pos] = st[pos - off[lo]];
 }
 
 }  // namespace
@@ -391,7 +398,7 @@ int nm_launch_detect_octave(const NmDetectArgs &d, const NmScanArgs &s, const Nm
     NM_LAUNCH_CHECK();
     hipLaunchKernelGGL(scan_book_kernel, dim3(s.n), dim3(1024), 0, stream, s);
     NM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gather_stage_kernel, dim3(g.n_blocks, 3, g.n), dim3(256), 0, stream, g);
+    hipLaunchKernelGGL(gather_stage_kernel, dim3(nm_divup(min(g.capacity, g.n_blocks * 256), 256), 3, g.n), dim3(256), 0, stream, g);
     NM_LAUNCH_CHECK();
     return 0;
 }

@@ -35,6 +35,7 @@ struct NmGatherArgs {
     const int *offsets[NM_MAX_BATCH];
     int n_blocks;
     int octave;
+    int capacity;          // upper bound of any level's output count
     const NmFrameBook *book[NM_MAX_BATCH];
     float *kpts[NM_MAX_BATCH];           // output-ordered float4 lists
 };
