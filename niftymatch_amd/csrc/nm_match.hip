@@ -662,9 +662,11 @@ static int run_fused(const float *A, int nA, const float *B, int nB, int mode, i
                        w.partial3, w.na, mode, index_offset, ambiguity, result, min1, idx1, min2, w.fb_count, w.fb_list);
     NM_LAUNCH_CHECK();
     static_assert(FB_SPLIT <= MAX_CHUNKS, "fallback slices reuse the partial area");
-    hipLaunchKernelGGL(match_fallback_kernel, dim3(FB_SPLIT, 64), dim3(256), 0, st, A, B, nB, w.fb_count, w.fb_list, w.partial);
+    // few rows are ever listed (0-2 of 12k on SIFT data): a small grid drains fastest when the list is empty, and its
+    // workgroups loop over the entries when it is not
+    hipLaunchKernelGGL(match_fallback_kernel, dim3(FB_SPLIT, 8), dim3(256), 0, st, A, B, nB, w.fb_count, w.fb_list, w.partial);
     NM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(match_fallback_merge_kernel, dim3(64), dim3(256), 0, st, w.fb_count, w.fb_list, w.partial, mode,
+    hipLaunchKernelGGL(match_fallback_merge_kernel, dim3(8), dim3(256), 0, st, w.fb_count, w.fb_list, w.partial, mode,
                        index_offset, ambiguity, result, min1, idx1, min2);
     NM_LAUNCH_CHECK();
     return 0;
