@@ -5,13 +5,15 @@
 //   1. norms_kernel        ||a||^2, ||b||^2
 //   2. match_top2_kernel   fp32 MFMA (v_mfma_f32_32x32x2_f32): d~[j][i] = nb_j + na_i - 2 a_i.b_j as ONE accumulation
 //                          chain (K = 128 products + 1 augmented k-pair carrying the norms); every lane keeps a running
-//                          best/second-best per query over the candidates it sees; partial lists per candidate chunk.
+//                          best/second-best/third-best per query over the candidates it sees (integer keys, see Top3);
+//                          256 persistent workgroups over balanced unit ranges, a partial list per segment (MatchPlan).
 //   3. match_finalize_kernel  per query: pick the 4 best partial candidates, recompute their distances EXACTLY in the
 //                          reference's order (sum_k fma(t,t,acc), t = a_k - b_k, k ascending: match.cu:36-42), then apply
 //                          the scan semantics of match.cu:91-116 (lowest index wins ties, min2 initial 2139095040.0f,
-//                          result untouched when min2 <= 0). Each chunk also reports the VALUE of its third best; when
-//                          anything not recomputed comes within the MFMA error margin of the exact min2, the query goes to
-//   4. match_fallback_kernel  which scans all candidates exactly (a fraction of a percent of the queries).
+//                          result untouched when min2 <= 0). Each segment also reports the VALUE of its third best; when
+//                          anything not recomputed comes within the error margin of the exact min2, the query goes to
+//   4. match_fallback_kernel (+ match_fallback_merge_kernel), which scan all candidates exactly (a fraction of a
+//                          percent of the queries), 64 candidate slices per listed query.
 // API building blocks (transpose / bf_distance / get_sift_matches) keep the reference's layouts and are exact.
 #include "nm_common.hpp"
 #include "../../include/nm_abi.h"
@@ -25,7 +27,7 @@ constexpr int KP = 132;            // LDS row pitch (floats): 128 data + norm sl
 constexpr int TILE_C = 128;        // candidates per LDS tile
 constexpr int QB = 256;            // queries per workgroup (32 per wave, fragments resident in VGPRs)
 constexpr float MIN2_INIT = 2139095040.0f;   // (float)0x7f800000, match.cu:91
-constexpr int MAX_CHUNKS = 64;     // upper bound of the candidate-chunk count S of any grid plan
+constexpr int MAX_CHUNKS = 64;     // upper bound of the number S of segments (partial lists) per query block of any plan
 
 // Work = qblocks x T units, a unit being (256 queries) x (one 128-candidate tile), linearised query-block-major. The grid
 // is G persistent workgroups (one per CU: the kernel owns the LDS), each taking a contiguous range of `base` or `base+1`
