@@ -119,6 +119,11 @@ def main():
     ap.add_argument("--streams", type=int, default=4)
     ap.add_argument("--batch", type=int, default=16, help="frames per nm_sift_detect_describe_batch call (16 = 8 pairs)")
     ap.add_argument("--host-threads", type=int, default=1, help="host threads that enqueue the detect calls")
+    ap.add_argument("--match-streams", type=int, default=1,
+                    help="streams the fused matches alternate over. 2 hides the small norms/finalize/fallback launches of "
+                         "one match under the next match's MFMA kernel (+7 %% frame-pairs/s), but the MFMA kernels of the "
+                         "two streams then also contend for CUs and each reads ~20 %% longer: default 1 keeps the "
+                         "event-timed matcher launches the isolated-kernel figure")
     ap.add_argument("--overlap", action="store_true",
                     help="pipeline the matches of a detect call with the next call's detection (higher throughput; the "
                          "matcher then shares the chip, so its roofline reading drops -- not the default)")
@@ -153,7 +158,10 @@ def main():
     mstream = torch.cuda.Stream(device=dev)
     # one arena per frame of the batch (0.4 GB each): nothing on the hot path is reused before it has been consumed
     arenas = [nm.SiftArena(W, H, CAP, device=dev) for _ in range(2 * P)]
-    ws = nm.MatchWorkspace(CAP, CAP, dev)
+    MS = max(1, args.match_streams)
+    mstreams = [mstream] + [torch.cuda.Stream(device=dev) for _ in range(MS - 1)]
+    wss = [nm.MatchWorkspace(CAP, CAP, dev) for _ in range(MS)]
+    ws = wss[0]
     results = [torch.full((CAP,), -1, dtype=torch.int32, device=dev) for _ in range(P)]
 
     # keypoint counts are data-dependent but deterministic: one untimed pass gives the host-side sizes of each pair
@@ -229,14 +237,19 @@ def main():
             nm.detect_describe_batch(arenas[(NB - 1) * B:], frames[(NB - 1) * B:])
             if timed:
                 nm.profile_events(nm.PROF_PYRAMID_O0, None, None)
-        with torch.cuda.stream(mstream):
-            for i in range(P):
-                nA, nB = counts[i]
+        for k in range(1, MS):
+            mstreams[k].wait_stream(mstream)            # the matches start when the last detect call has finished
+        for i in range(P):
+            nA, nB = counts[i]
+            with torch.cuda.stream(mstreams[i % MS]):
                 if timed:
                     nm.profile_events(nm.PROF_MATCH_TOP2, ev_match[i][0], ev_match[i][1])
-                nm.sift_match(arenas[2 * i].desc, arenas[2 * i + 1].desc, 0.8, prior=results[i], workspace=ws, nA=nA, nB=nB)
-            if timed:
-                nm.profile_events(nm.PROF_MATCH_TOP2, None, None)
+                nm.sift_match(arenas[2 * i].desc, arenas[2 * i + 1].desc, 0.8, prior=results[i], workspace=wss[i % MS],
+                              nA=nA, nB=nB)
+        if timed:
+            nm.profile_events(nm.PROF_MATCH_TOP2, None, None)
+        for k in range(1, MS):
+            mstream.wait_stream(mstreams[k])
         for s in range(S):                      # the next step's detects overwrite the arenas: wait for the matches
             streams[s].wait_stream(mstream)
         if timed:
@@ -302,7 +315,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[2]: SIFT detect+describe x2 + fused BF L2 match per 1920x1080 pair",
                        "pairs_per_gpu_per_step": P, "detect_streams": S, "frames_per_detect_call": B,
-                       "host_enqueue_threads": T, "phases": "overlapped" if overlap else "detect then match",
+                       "host_enqueue_threads": T, "match_streams": MS, "phases": "overlapped" if overlap else "detect then match",
                        "keypoints_pair0": [nA, nB], "capacity": CAP,
                        "parallelism": "frame-pair sharding, %d rank(s), no data-path collective" % world},
             "keypoints_per_s": round(kp_all * args.steps / dt, 1),
