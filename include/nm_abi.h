@@ -128,6 +128,11 @@ NM_API int nm_get_sift_matches_f32(const float *distance, int rows, int cols, in
  * (match.cu:107-116). Match decisions are made on distances recomputed exactly in the reference's summation
  * order; rows whose best two cannot be proven from the MFMA pass are re-scanned exactly. workspace: nm_sift_match_workspace_bytes(nA, nB) bytes of device scratch.                            */
 NM_API size_t nm_sift_match_workspace_bytes(int nA, int nB);
+/* HOST function (no device access): the work distribution the matcher would use for (nA, nB). plan[0..5] = query blocks
+ * of 256 rows, candidate tiles of 128 rows per block, persistent workgroups G, units per workgroup (base), workgroups
+ * with one unit more (rem), partial lists per query S (<= 64, what the workspace bound assumes). Units = blocks x tiles
+ * are dealt to the workgroups as contiguous ranges: G * base + rem units in total. For tests and capacity planning. */
+NM_API int nm_sift_match_plan(int nA, int nB, int plan[6]);
 NM_API int nm_sift_match_f32(const float *A, int nA, const float *B, int nB, float *distance, int *result,
                              float ambiguity, void *workspace, void *stream);
 /* Diagnostics: number of query rows of the LAST nm_sift_match_f32 / _shard_f32 call on `workspace` (same nA, nB) that took

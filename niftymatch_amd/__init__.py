@@ -37,6 +37,7 @@ _SIGNATURES = {
     "nm_transpose_f32": (_I, [_P, _P, _I, _I, _P]),
     "nm_bf_distance_f32": (_I, [_P, _I, _P, _I, _I, _P, _P]),
     "nm_get_sift_matches_f32": (_I, [_P, _I, _I, _I, _P, _F, _P]),
+    "nm_sift_match_plan": (_I, [_I, _I, _P]),
     "nm_sift_match_workspace_bytes": (_SZ, [_I, _I]),
     "nm_sift_match_f32": (_I, [_P, _I, _P, _I, _P, _P, _F, _P, _P]),
     "nm_sift_match_fallback_count": (_I, [_P, _I, _I, _P, _P]),

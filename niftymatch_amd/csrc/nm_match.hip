@@ -720,6 +720,14 @@ size_t nm_sift_match_workspace_bytes(int nA, int nB)
            align256((size_t)nA * MAX_CHUNKS * sizeof(float)) + 256 + align256((size_t)nA * 4) + 256;
 }
 
+int nm_sift_match_plan(int nA, int nB, int plan[6])
+{
+    if (!plan || nA < 0 || nB < 0) return (int)hipErrorInvalidValue;
+    const MatchPlan p = make_plan(nA, nB);
+    plan[0] = p.qblocks; plan[1] = p.T; plan[2] = p.G; plan[3] = p.base; plan[4] = p.rem; plan[5] = p.S;
+    return 0;
+}
+
 int nm_sift_match_fallback_count(const void *workspace, int nA, int nB, int *host_count, void *stream)
 {
     if (!workspace || !host_count || nA <= 0 || nB <= 0) return (int)hipErrorInvalidValue;

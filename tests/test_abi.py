@@ -98,3 +98,37 @@ def test_cmake_find_package_dropin(tmp_path, nm):
     subprocess.check_call(["cmake", "--build", "."], cwd=build, stdout=subprocess.DEVNULL)
     out = subprocess.check_output([str(build / "app")]).decode().split()
     assert out == ["6", "5", "4"]
+
+
+def test_match_plan_invariants(nm):
+    """Host logic of the matcher's work distribution (nm_sift_match_plan, no GPU needed): every unit is owned by exactly
+    one workgroup range, ranges differ by at most one unit, a query block is covered by at most S <= 64 consecutive
+    workgroups, and the workspace bound holds for every smaller shape served by the same buffer."""
+    import ctypes as C
+    lib = nm.lib()
+
+    def plan(nA, nB):
+        out = (C.c_int * 6)()
+        assert lib.nm_sift_match_plan(nA, nB, out) == 0
+        return list(out)
+
+    shapes = [(1, 1), (255, 127), (256, 128), (257, 129), (1000, 50), (50, 1000), (12223, 12080), (16384, 16384),
+              (300, 100000), (100000, 300), (100000, 100000), (100000, 12500), (4097, 8193)]
+    for nA, nB in shapes:
+        qb, T, G, base, rem, S = plan(nA, nB)
+        assert qb == -(-nA // 256) and T == -(-nB // 128)
+        U = qb * T
+        assert 1 <= G <= 256 and G * base + rem == U and 0 <= rem < G and base >= 1
+        assert 1 <= S <= 64
+
+        def owner(u):
+            cut = rem * (base + 1)
+            return u // (base + 1) if u < cut else rem + (u - cut) // base
+        spans = [owner(b * T + T - 1) - owner(b * T) + 1 for b in range(qb)]
+        assert max(spans) == S and owner(U - 1) == G - 1 and owner(0) == 0
+        # partial lists (nA * S * 20 B) stay inside what the workspace bound reserves for them (nA * 64 * 20 B)
+        assert lib.nm_sift_match_workspace_bytes(nA, nB) >= nA * S * 20 + 4 * (nA + nB) + 4 * nA
+    # a workspace sized for the largest shape serves every smaller one
+    big = lib.nm_sift_match_workspace_bytes(16384, 16384)
+    for nA, nB in [(12223, 12080), (16384, 1), (1, 16384), (5000, 16000)]:
+        assert lib.nm_sift_match_workspace_bytes(nA, nB) <= big
