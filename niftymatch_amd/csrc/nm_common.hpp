@@ -48,6 +48,7 @@ struct NmConvBatch {
     const float *image[NM_MAX_BATCH];
     float *dog[NM_MAX_BATCH];
     float *grad[NM_MAX_BATCH];
+    float *down[NM_MAX_BATCH];      // optional: `result` decimated by 2 ((width/2) x (height/2), kernels/downsample.cu:6-17)
     int n;
 };
 int nm_launch_convolve_batch(const NmConvBatch &b, int width, int height, const float *taps_dev, int radius,

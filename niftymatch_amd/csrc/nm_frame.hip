@@ -164,7 +164,8 @@ float *nm_sift_arena_level(nm_sift_arena *a, int l) { return (a && l >= 0 && l <
 float *nm_sift_arena_dog(nm_sift_arena *a, int d) { return (a && d >= 0 && d < 5) ? a->dog[0][d] : nullptr; }
 float *nm_sift_arena_grad(nm_sift_arena *a) { return a ? a->grad[0] : nullptr; }
 
-static int octave_pyramid(nm_sift_arena *const *as, int n, int o, int ow, int oh, bool store_top, hipStream_t st)
+static int octave_pyramid(nm_sift_arena *const *as, int n, int o, int ow, int oh, bool store_top, bool decimate,
+                          hipStream_t st)
 {
     if (o == 0) nm_prof_begin(NM_PROF_PYRAMID_O0, st);
     const size_t plane = (size_t)ow * oh;
@@ -180,6 +181,9 @@ static int octave_pyramid(nm_sift_arena *const *as, int n, int o, int ow, int oh
             b.image[f] = a->level[i - 1];
             b.dog[f] = a->dog[o][i - 1];
             b.grad[f] = (i >= 2 && i <= 4) ? a->grad[o] + 2 * (size_t)(i - 2) * plane : nullptr;
+            // level 3 decimated IS the next octave's level 0 (pyramidata / downsample.cu); level[0] of this octave was
+            // consumed by the first launch of the sequence, so its plane can take it straight away
+            b.down[f] = (decimate && i == 3) ? a->level[0] : nullptr;
         }
         rc = nm_launch_convolve_batch(b, ow, oh, as[0]->taps[i - 1], as[0]->radii[i - 1], st);
     }
@@ -190,7 +194,7 @@ static int octave_pyramid(nm_sift_arena *const *as, int n, int o, int ow, int oh
 int nm_sift_octave_pyramid(nm_sift_arena *a, int ow, int oh, void *stream)
 {
     if (!a || ow <= 0 || oh <= 0 || (size_t)ow * oh > a->npix) return (int)hipErrorInvalidValue;
-    return octave_pyramid(&a, 1, 0, ow, oh, true, nm_stream(stream));
+    return octave_pyramid(&a, 1, 0, ow, oh, true, false, nm_stream(stream));
 }
 
 // Frame driver for n <= NM_MAX_BATCH equally sized frames: EVERY launch covers all frames of the call (the frame index is
@@ -234,14 +238,7 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
     for (int o = 0; o < P._num_octaves; ++o) {
         const int ow = W >> o, oh = H >> o;
         const float xper = (float)std::pow(2.0, o);
-        if (o > 0) {
-            NmPlaneBatch d{};
-            d.n = n;
-            for (int f = 0; f < n; ++f) { d.dst[f] = as[f]->level[0]; d.src[f] = as[f]->level[3]; }
-            rc = nm_launch_downsample2_batch(d, ow, oh, W >> (o - 1), st);
-            if (rc) return rc;
-        }
-        rc = octave_pyramid(as, n, o, ow, oh, false, st);
+        rc = octave_pyramid(as, n, o, ow, oh, false, o + 1 < P._num_octaves, st);
         if (rc) return rc;
         NM_RETURN_IF(hipEventRecord(as[0]->ev_pyr[o], st));
         NM_RETURN_IF(hipStreamWaitEvent(side, as[0]->ev_pyr[o], 0));

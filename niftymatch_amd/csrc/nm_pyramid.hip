@@ -335,6 +335,7 @@ __global__ __launch_bounds__(256) void conv_pk_kernel(NmConvBatch batch, int wid
     const float *__restrict__ image = batch.image[frame];
     float *__restrict__ dog = batch.dog[frame];
     float2 *__restrict__ grad = reinterpret_cast<float2 *>(batch.grad[frame]);
+    float *__restrict__ down = batch.down[frame];
 
     float w[2 * R + 1];
 #pragma unroll
@@ -435,6 +436,10 @@ __global__ __launch_bounds__(256) void conv_pk_kernel(NmConvBatch batch, int wid
                 if (gy < height) {
                     const unsigned off = (unsigned)gy * row_bytes + (unsigned)gx * 4u;       // < 4 GiB: checked by the host
                     if (result) *reinterpret_cast<float2 *>(reinterpret_cast<char *>(result) + off) = make_float2(o[i].x, o[i].y);
+                    if (down && !(gy & 1)) {         // next octave's level 0 = every other pixel of every other row (gx is even)
+                        const int dw = width >> 1, dx = gx >> 1, dy = gy >> 1;
+                        if (dx < dw && dy < (height >> 1)) down[(size_t)dy * dw + dx] = o[i].x;
+                    }
                     if (WRITE_DOG) {
                         const v2f d = o[i] - mid[i + 1];
                         *reinterpret_cast<float2 *>(reinterpret_cast<char *>(dog) + off) = make_float2(d.x, d.y);
@@ -637,7 +642,7 @@ int nm_launch_convolve_batch(const NmConvBatch &b, int width, int height, const 
     for (int f = 0; f < b.n; ++f) {
         pk = pk && ((reinterpret_cast<uintptr_t>(b.image[f]) & 15) == 0);
         pk = pk && ((b.result[f] != nullptr) == (b.result[0] != nullptr)) && ((b.dog[f] != nullptr) == (b.dog[0] != nullptr)) &&
-             ((b.grad[f] != nullptr) == (b.grad[0] != nullptr));
+             ((b.grad[f] != nullptr) == (b.grad[0] != nullptr)) && ((b.down[f] != nullptr) == (b.down[0] != nullptr));
     }
     if (pk) {
         switch (radius) {
@@ -654,6 +659,13 @@ int nm_launch_convolve_batch(const NmConvBatch &b, int width, int height, const 
     for (int f = 0; f < b.n; ++f) {
         const int rc = nm_launch_convolve(b.result[f], b.image[f], nullptr, b.dog[f], b.grad[f], width, height, taps, radius, stream);
         if (rc) return rc;
+    }
+    if (b.down[0]) {                  // the packed kernel decimates in its epilogue; here it is a launch of its own
+        if (!b.result[0]) return (int)hipErrorInvalidValue;
+        NmPlaneBatch d{};
+        d.n = b.n;
+        for (int f = 0; f < b.n; ++f) { d.dst[f] = b.down[f]; d.src[f] = b.result[f]; }
+        return nm_launch_downsample2_batch(d, width >> 1, height >> 1, width, stream);
     }
     return 0;
 }
