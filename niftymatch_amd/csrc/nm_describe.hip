@@ -138,12 +138,17 @@ __device__ __forceinline__ void describe_wave(const float4 kp, const float angle
     // Gradient samples of a chunk are fetched together (4 independent loads per lane) and the next chunk's loads are
     // issued before the current chunk is processed, so the gather latency is paid once, not per sample.
     float2 cur[4], nxt[4];
+    // 32-bit element offsets relative to the keypoint's pixel (a level plane has < 2^31 elements): chunk c starts at
+    // (xmin + 16 c, ymin + 16 c), a lane's q-th sample lies 4 q rows further down
+    const int lane_off = (tyg + ymin) * ow + (tx + xmin);
+    const int chunk_step = 16 * (ow + 1), row4 = 4 * ow;
     auto fetch = [&](int c, float2 (&dst)[4]) {
+        const int off0 = lane_off + c * chunk_step;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int cx = tx + xmin + 16 * c, cy = 4 * q + tyg + ymin + 16 * c;
             dst[q] = make_float2(0.f, 0.f);
-            if (cx <= xmax && cy <= ymax) dst[q] = gptr[(long)cy * ow + cx];
+            if (cx <= xmax && cy <= ymax) dst[q] = gptr[off0 + q * row4];
         }
     };
     if (chunks > 0) fetch(0, cur);
@@ -180,6 +185,13 @@ __device__ __forceinline__ void describe_wave(const float4 kp, const float angle
             float wt[8];
             int loc[8];
             const int dummy = 16 - 80 * DESC_PITCH - tx;
+            // histogram word = (binx * 8 + biny * 32 + bint) * DESC_PITCH with 24-bit multiplies (v_mad_i32_i24 is full
+            // rate; the 32-bit v_mul_lo_u32 the plain expression compiles to costs four VALU slots, eight times per sample)
+            const int base = __mul24(binx, 8 * DESC_PITCH) + __mul24(biny, 32 * DESC_PITCH);
+            const int t0 = bint & 7, t1 = (bint + 1) & 7;           // bint in [0, 8]
+            const int tw[2] = {__mul24(t0, DESC_PITCH), __mul24(t1, DESC_PITCH)};
+            const bool okx[2] = {(unsigned)(binx + 2) < 4u, (unsigned)(binx + 3) < 4u};
+            const bool oky[2] = {(unsigned)(biny + 2) < 4u, (unsigned)(biny + 3) < 4u};
 #pragma unroll
             for (int dbx = 0; dbx < 2; ++dbx)
 #pragma unroll
@@ -187,11 +199,11 @@ __device__ __forceinline__ void describe_wave(const float4 kp, const float angle
 #pragma unroll
                     for (int dbt = 0; dbt < 2; ++dbt) {
                         const int j = dbx * 4 + dby * 2 + dbt;
-                        const bool ok = inwin && binx + dbx >= -2 && binx + dbx < 2 && biny + dby >= -2 && biny + dby < 2;
+                        const bool ok = inwin && okx[dbx] && oky[dby];
                         const float w3 = wm * __builtin_fabsf((1.f - dbx) - rbinx) * __builtin_fabsf((1.f - dby) - rbiny) *
                                          __builtin_fabsf((1.f - dbt) - rbint);
                         wt[j] = ok ? w3 : 0.f;
-                        loc[j] = ok ? ((binx + dbx) * 8 + (biny + dby) * 32 + ((bint + dbt) % 8)) * DESC_PITCH : dummy;
+                        loc[j] = ok ? base + (dbx * 8 + dby * 32) * DESC_PITCH + tw[dbt] : dummy;
                     }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {          // rows of this pass in increasing cy: 16 lanes per group, LDS in order
