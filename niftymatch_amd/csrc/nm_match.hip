@@ -67,9 +67,11 @@ static MatchPlan make_plan(int nA, int nB)
 
 // ||x||^2 of every row of A (nA rows) and B (nB rows) in one launch.
 __global__ __launch_bounds__(256) void norms_kernel(const float *__restrict__ A, int nA, float *__restrict__ na,
-                                                   const float *__restrict__ B, int nB, float *__restrict__ nb)
+                                                   const float *__restrict__ B, int nB, float *__restrict__ nb,
+                                                   int *__restrict__ fb_count)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && fb_count) *fb_count = 0;           // first launch of a match call: resets the fallback list (no memset node)
     const float *X = A;
     float *out = na;
     if (i >= nA) { i -= nA; X = B; out = nb; if (i >= nB) return; }
@@ -648,7 +650,7 @@ static int run_fused(const float *A, int nA, const float *B, int nB, int mode, i
     if (nA <= 0 || nB <= 0) return 0;
     const MatchPlan p = make_plan(nA, nB);
     MatchWs w = carve(workspace, nA, nB, p);
-    hipLaunchKernelGGL(norms_kernel, dim3(nm_divup(nA + nB, 256)), dim3(256), 0, st, A, nA, w.na, B, nB, w.nb);
+    hipLaunchKernelGGL(norms_kernel, dim3(nm_divup(nA + nB, 256)), dim3(256), 0, st, A, nA, w.na, B, nB, w.nb, w.fb_count);
     NM_LAUNCH_CHECK();
     const size_t lds_bytes = (size_t)2 * TILE_C * KP * sizeof(float);
     // per call: the attribute is per device, and a process may drive several (cheap host-side call, not a stream op)
@@ -659,7 +661,6 @@ static int run_fused(const float *A, int nA, const float *B, int nB, int mode, i
                        w.partial3);
     nm_prof_end(NM_PROF_MATCH_TOP2, st);
     NM_LAUNCH_CHECK();
-    NM_RETURN_IF(hipMemsetAsync(w.fb_count, 0, sizeof(int), st));
     hipLaunchKernelGGL(match_finalize_kernel, dim3(nm_divup(4 * nA, 256)), dim3(256), 0, st, A, nA, B, nB, p.S, w.partial,
                        w.partial3, w.na, mode, index_offset, ambiguity, result, min1, idx1, min2, w.fb_count, w.fb_list);
     NM_LAUNCH_CHECK();
