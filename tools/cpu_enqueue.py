@@ -14,6 +14,8 @@ import niftymatch_amd as nm  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 P = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+if len(sys.argv) > 5:
+    bench.W, bench.H = map(int, sys.argv[5].split("x"))
 dev = torch.device("cuda:0")
 frames = bench.make_frames(nm, torch, dev, list(range(2 * P)))
 arenas = [nm.SiftArena(bench.W, bench.H, bench.CAP, device=dev) for _ in range(2 * P)]
@@ -51,5 +53,5 @@ for _ in range(5):
     t2 = time.perf_counter()
     host.append(t1 - t0)
     total.append(t2 - t0)
-print("threads %d streams %d batch %d: %d frames: host enqueue %.2f ms, until GPU done %.2f ms -> %.0f us/frame host, %.0f us/frame total"
-      % (T, S, B, 2 * P, 1e3 * min(host), 1e3 * min(total), 1e6 * min(host) / (2 * P), 1e6 * min(total) / (2 * P)))
+print("%dx%d threads %d streams %d batch %d: %d frames: host enqueue %.2f ms, until GPU done %.2f ms -> %.0f us/frame host, %.0f us/frame total"
+      % (bench.W, bench.H, T, S, B, 2 * P, 1e3 * min(host), 1e3 * min(total), 1e6 * min(host) / (2 * P), 1e6 * min(total) / (2 * P)))
