@@ -78,4 +78,55 @@ for it in range(n_match):
         bad += 1
         print("MATCH MISMATCH", it, na, nb, kind, amb, flush=True)
 print("matches done: %d cases, total mismatches %d, %.1fs" % (n_match, bad, time.time() - t0), flush=True)
+
+# ---- side stages: front end, warps, blend, RANSAC ----
+t0 = time.time()
+n_side = max(10, n_frames // 5)
+for it in range(n_side):
+    w = int(rng.integers(8, 500)); h = int(rng.integers(8, 400))
+    cols = int(rng.integers(8, 500)); rows = int(rng.integers(8, 400))
+    img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    a = rng.uniform(-0.3, 0.3); sc = rng.uniform(0.7, 1.4)
+    Hm = np.array([[sc * np.cos(a), -sc * np.sin(a), rng.uniform(-40, 40)], [sc * np.sin(a), sc * np.cos(a), rng.uniform(-40, 40)],
+                   [rng.uniform(-3e-4, 3e-4), rng.uniform(-3e-4, 3e-4), 1.0]], np.float32)
+    ok = True
+    for inv in (True, False):
+        out, xp, yp = nm.resample_perspective(t(img), cols, rows, t(Hm), inv)
+        o_out, o_xp, o_yp = O.resample_perspective(img, cols, rows, Hm, inv)
+        ok = ok and np.array_equal(out.cpu().numpy(), o_out) and np.array_equal(xp.cpu().numpy().view(np.uint32), o_xp.view(np.uint32))
+    tex = rng.uniform(0, 1, (h, w)).astype(np.float32) if it % 2 else rng.integers(0, 256, (h, w), dtype=np.uint8)
+    ok = ok and np.array_equal(nm.resample_undistort(t(tex), xp, yp).cpu().numpy().view(np.uint32),
+                               O.resample_undistort(tex, o_xp, o_yp).view(np.uint32))
+    ok = ok and np.array_equal(nm.resample_mask(t(tex), xp, yp, 0.3).cpu().numpy(), O.resample_mask(tex, o_xp, o_yp, 0.3))
+    cam = np.array([rng.uniform(0.5, 2) * w, rng.uniform(0.5, 2) * w, w / 2 + rng.uniform(-5, 5), h / 2 + rng.uniform(-5, 5)], np.float32)
+    dist = rng.uniform(-0.3, 0.3, 3).astype(np.float32)
+    u, v = nm.undistort_map(xp, yp, t(cam), t(dist))
+    ou, ov = O.undistort_map(o_xp, o_yp, cam, dist)
+    ok = ok and np.array_equal(u.cpu().numpy().view(np.uint32), ou.view(np.uint32)) and np.array_equal(v.cpu().numpy().view(np.uint32), ov.view(np.uint32))
+    cw, ch = int(rng.integers(16, 600)), int(rng.integers(16, 500))
+    canvas = rng.integers(0, 256, (ch, cw, 4), dtype=np.uint8); cwts = (rng.uniform(0, 1, (ch, cw)) * (rng.uniform(0, 1, (ch, cw)) > 0.5)).astype(np.float32)
+    mask = (rng.uniform(0, 1, (h, w)) > 0.2).astype(np.float32); wts = rng.uniform(0.01, 2, (h, w)).astype(np.float32)
+    tcan, tcw = t(canvas), t(cwts)
+    tx, ty = int(rng.integers(-50, 50)), int(rng.integers(-50, 50))
+    nm.transform_blend(tcan, tcw, t(img), w + 7, h + 5, t(Hm), tx, ty, t(mask), t(wts))
+    ocan, ocw = O.transform_blend(canvas, cwts, img, w + 7, h + 5, Hm, tx, ty, mask, wts)
+    ok = ok and np.array_equal(tcan.cpu().numpy(), ocan) and np.array_equal(tcw.cpu().numpy().view(np.uint32), ocw.view(np.uint32))
+    ok = ok and np.array_equal(nm.grayscale(t(img)).cpu().numpy().view(np.uint32), O.grayscale(img).view(np.uint32))
+    n = int(rng.integers(8, 4000))
+    sx = rng.uniform(0, 1920, n).astype(np.float32); sy = rng.uniform(0, 1080, n).astype(np.float32)
+    p3 = Hm.astype(np.float64) @ np.stack([sx, sy, np.ones(n)])
+    dx = (p3[0] / p3[2]).astype(np.float32); dy = (p3[1] / p3[2]).astype(np.float32)
+    outl = rng.random(n) < 0.3
+    dx[outl] = rng.uniform(0, 1920, outl.sum()); dy[outl] = rng.uniform(0, 1080, outl.sum())
+    for model, ns in ((0, 1), (1, 2), (2, 4)):
+        rl = rng.integers(0, n, (int(rng.integers(1, 700)), ns)).astype(np.int32)
+        thr = float(rng.uniform(0.5, 9))
+        pos, Hb, Ha, inl = nm.ransac(model, t(sx), t(sy), t(dx), t(dy), t(rl), thr)
+        pos_r, Hb_r, Ha_r, inl_r = O.ransac(model, sx, sy, dx, dy, rl, thr)
+        ok = ok and int(pos.item()) == pos_r and np.array_equal(inl.cpu().numpy(), inl_r)
+        ok = ok and np.array_equal(Ha.cpu().numpy().view(np.uint32), Ha_r.view(np.uint32))
+    if not ok:
+        bad += 1
+        print("SIDE MISMATCH", it, w, h, cols, rows, flush=True)
+print("side stages done: %d cases, total mismatches %d, %.1fs" % (n_side, bad, time.time() - t0), flush=True)
 sys.exit(1 if bad else 0)
