@@ -21,4 +21,6 @@ struct NmDescribeArgs {
     float *x[NM_MAX_BATCH], *y[NM_MAX_BATCH];
 };
 
+static_assert(sizeof(NmDescribeArgs) <= 4096, "kernel arguments are limited to 4 KB: lower NM_MAX_BATCH");
+
 int nm_launch_frame_describe(const NmDescribeArgs &a, hipStream_t stream);

@@ -40,4 +40,7 @@ struct NmGatherArgs {
     float *kpts[NM_MAX_BATCH];           // output-ordered float4 lists
 };
 
+static_assert(sizeof(NmDetectArgs) <= 4096 && sizeof(NmScanArgs) <= 4096 && sizeof(NmGatherArgs) <= 4096,
+              "kernel arguments are limited to 4 KB: lower NM_MAX_BATCH");
+
 int nm_launch_detect_octave(const NmDetectArgs &d, const NmScanArgs &s, const NmGatherArgs &g, hipStream_t stream);
