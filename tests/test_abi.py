@@ -132,3 +132,23 @@ def test_match_plan_invariants(nm):
     big = lib.nm_sift_match_workspace_bytes(16384, 16384)
     for nA, nB in [(12223, 12080), (16384, 1), (1, 16384), (5000, 16000)]:
         assert lib.nm_sift_match_workspace_bytes(nA, nB) <= big
+
+
+def test_abi_headers_are_plain_c(tmp_path, nm):
+    """include/*.h must be consumable by a C compiler (the boundary is a C ABI): compile and link a C99 client with
+    -pedantic against libnm_hip.so and call a host-only entry point."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        import pytest
+        pytest.skip("gcc not available")
+    src = tmp_path / "client.c"
+    src.write_text('#include "nm_abi.h"\n#include "nm_client.h"\n#include <stdio.h>\n'
+                   "int main(void) { int p[6]; if (nm_sift_match_plan(12223, 12080, p)) return 1;\n"
+                   '  printf("%d %d %d %d\\n", p[0], p[1], p[2], DivUp(7, 2)); return 0; }\n')
+    exe = tmp_path / "client"
+    libdir = os.path.join(ROOT, "niftymatch_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe), "-L", libdir, "-lnm_hip", "-Wl,-rpath," + libdir])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    assert out == ["48", "95", "256", "4"]
