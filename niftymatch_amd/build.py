@@ -75,6 +75,15 @@ def build(force=False, verbose=False):
             if os.path.exists(ar):
                 os.remove(ar)
             subprocess.check_call(["ar", "rcs", ar] + [objs[s] for s in srcs])
+    # native example client of the C ABI (no Python, no torch): examples/pairs_native.cpp -> lib/pairs_native
+    example = os.path.join(ROOT, "..", "examples", "pairs_native.cpp")
+    exe = os.path.join(LIBDIR, "pairs_native")
+    if os.path.exists(example) and (force or not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(example), os.path.getmtime(LIB))):
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-O2", "-std=c++17", "-I", os.path.join(ROOT, "..", "include"), example,
+               "-L", LIBDIR, "-lnm_hip", "-Wl,-rpath,$ORIGIN", "-o", exe]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("example build failed:\n%s\n%s" % (r.stdout, r.stderr))
     if verbose:
         print("built", LIB)
     return LIB

@@ -77,3 +77,28 @@ def test_mosaic_pipeline_end_to_end(nm, oracle, cuda):
     assert both.mean() > 0.7 and np.median(diff[both]) <= 3
     for a in arenas:
         a.close()
+
+
+def test_native_client_matches_python_path(nm, cuda):
+    """examples/pairs_native.cpp (C ABI + HIP runtime only, built by niftymatch_amd.build) generates the same synthetic
+    pair, finds the same keypoints and the same number of matches as the Python-bound path."""
+    import json
+    import os
+    import subprocess
+    import torch
+    exe = os.path.join(os.path.dirname(nm.LIB_PATH), "pairs_native")
+    if not os.path.exists(exe):
+        pytest.skip("native example not built")
+    out = subprocess.check_output([exe, "2", "2", "1", "640x480"], timeout=240).decode().strip().splitlines()[-1]
+    rep = json.loads(out)
+    from niftymatch_amd import synth
+    taps, r = nm.create_kernel_for_sigma(synth.preblur_sigma(640, 480))
+    td = torch.from_numpy(taps).to(cuda)
+    arenas = [nm.SiftArena(640, 480, 16384) for _ in range(2)]
+    grays = [nm.convolve(torch.from_numpy(synth.noise_frame(s, 640, 480)).to(cuda), td, r) for s in (0, 1)]
+    nm.detect_describe_batch(arenas, grays)
+    torch.cuda.synchronize()
+    n = [int(a.num_items.item()) for a in arenas]
+    res, _ = nm.sift_match(arenas[0].desc, arenas[1].desc, 0.8, nA=n[0], nB=n[1])
+    assert rep["keypoints_pair0"] == n and rep["matches_pair0"] == int((res >= 0).sum().item())
+    assert rep["frame_pairs_per_s"] > 0
