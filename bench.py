@@ -125,6 +125,10 @@ def main():
     ap.add_argument("--overlap", action="store_true",
                     help="pipeline the matches of a detect call with the next call's detection (higher throughput; the "
                          "matcher then shares the chip, so its roofline reading drops -- not the default)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1. nccl (= RCCL over xGMI) is the real thing; gloo exists to "
+                         "rehearse the multi-rank logic with several ranks sharing one GPU (timing tensors then live on the "
+                         "host; combine with --no-allpairs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allpairs", action="store_true", help="skip the secondary config-5 measurement")
     args = ap.parse_args()
@@ -137,10 +141,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(1, torch.cuda.device_count())     # rehearsals may put several ranks on one GPU
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")   # where the few collective payload tensors live
     nm.lib()
 
     P = args.pairs
@@ -272,13 +281,13 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     kp_rank = sum(a + b for a, b in counts)
     cmp_rank = sum(a * b for a, b in counts)
-    tot = torch.tensor([float(kp_rank), float(cmp_rank)], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(kp_rank), float(cmp_rank)], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     kp_all, cmp_all = float(tot[0].item()), float(tot[1].item())
