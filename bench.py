@@ -47,14 +47,13 @@ def cpu_baseline():
     r0 = O.sift_detect_describe(Hh.blurred_frame(0, W, H), CAP)
     r1 = O.sift_detect_describe(Hh.blurred_frame(1, W, H), CAP)
     t_detect = time.time() - t0
-    rows = min(4096, r0["n"])
     t0 = time.time()
-    O.sift_matches(r0["desc"][:rows], r1["desc"], 0.8, want_distance=False)
-    t_match = (time.time() - t0) * (r0["n"] / rows)
+    O.sift_matches(r0["desc"], r1["desc"], 0.8, want_distance=False)
+    t_match = time.time() - t0
     pair_s = t_detect + t_match
     return {"value": round(1.0 / pair_s, 4), "unit": "frame-pairs/s", "cores": int(threads), "kind": "port",
-            "sample": "one 1080p pair: both frames detect+describe (%.2fs) + %d of %d match rows against %d candidates, "
-                      "scaled (%.2fs)" % (t_detect, rows, r0["n"], r1["n"], t_match)}
+            "sample": "one whole 1080p pair, nothing scaled: both frames detect+describe (%.2fs) + %d x %d match (%.2fs)"
+                      % (t_detect, r0["n"], r1["n"], t_match)}
 
 
 def allpairs_100k(nm, torch, dist, dev, rank, world, steps=3):
