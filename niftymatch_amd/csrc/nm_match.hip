@@ -335,7 +335,7 @@ __device__ __forceinline__ void emit_match(int i, float m1, int idx, float m2, i
 // third-best values and everything that dropped out of a top-4 list). If rest is not safely above the exact min2
 // (margin = bound on the MFMA formulation's error), the query is appended to the fallback list instead of being emitted.
 __global__ __launch_bounds__(256) void match_finalize_kernel(const float *__restrict__ A, int nA,
-                                                            const float *__restrict__ B, int nB, int S,
+                                                            const float *__restrict__ B, int /*nB*/, int S,
                                                             const float4 *__restrict__ partial,
                                                             const float *__restrict__ partial3,
                                                             const float *__restrict__ na, int mode, int index_offset,
