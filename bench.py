@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--streams", type=int, default=4)
     ap.add_argument("--batch", type=int, default=16, help="frames per nm_sift_detect_describe_batch call (16 = 8 pairs)")
     ap.add_argument("--host-threads", type=int, default=1, help="host threads that enqueue the detect calls")
+    ap.add_argument("--match-batch", type=int, default=16,
+                    help="pairs per nm_sift_match_batch_f32 call (1 = one nm_sift_match_f32 call per pair)")
     ap.add_argument("--match-streams", type=int, default=1,
                     help="streams the fused matches alternate over. 2 hides the small norms/finalize/fallback launches of "
                          "one match under the next match's MFMA kernel (+7 %% frame-pairs/s), but the MFMA kernels of the "
@@ -164,6 +166,8 @@ def main():
     mstream = torch.cuda.Stream(device=dev)
     # one arena per frame of the batch (0.4 GB each): nothing on the hot path is reused before it has been consumed
     arenas = [nm.SiftArena(W, H, CAP, device=dev) for _ in range(2 * P)]
+    MB = max(1, min(args.match_batch, nm.MATCH_MAX_BATCH, P))
+    bws = nm.MatchBatchWorkspace(MB, CAP, CAP, dev) if MB > 1 else None
     MS = max(1, args.match_streams)
     mstreams = [mstream] + [torch.cuda.Stream(device=dev) for _ in range(MS - 1)]
     wss = [nm.MatchWorkspace(CAP, CAP, dev) for _ in range(MS)]
@@ -243,19 +247,32 @@ def main():
             nm.detect_describe_batch(arenas[(NB - 1) * B:], frames[(NB - 1) * B:])
             if timed:
                 nm.profile_events(nm.PROF_PYRAMID_O0, None, None)
-        for k in range(1, MS):
-            mstreams[k].wait_stream(mstream)            # the matches start when the last detect call has finished
-        for i in range(P):
-            nA, nB = counts[i]
-            with torch.cuda.stream(mstreams[i % MS]):
-                if timed:
-                    nm.profile_events(nm.PROF_MATCH_TOP2, ev_match[i][0], ev_match[i][1])
-                nm.sift_match(arenas[2 * i].desc, arenas[2 * i + 1].desc, 0.8, prior=results[i], workspace=wss[i % MS],
-                              nA=nA, nB=nB)
-        if timed:
-            nm.profile_events(nm.PROF_MATCH_TOP2, None, None)
-        for k in range(1, MS):
-            mstream.wait_stream(mstreams[k])
+        if MB > 1:
+            # batched matches: norms / finalize / fallback once per call for all its pairs, the MFMA kernel once per pair
+            with torch.cuda.stream(mstream):
+                for i0 in range(0, P, MB):
+                    idx = list(range(i0, min(i0 + MB, P)))
+                    keep = nm.profile_event_pairs(nm.PROF_MATCH_TOP2, [ev_match[i] for i in idx]) if timed else None
+                    nm.sift_match_batch([arenas[2 * i].desc for i in idx], [arenas[2 * i + 1].desc for i in idx],
+                                        [counts[i][0] for i in idx], [counts[i][1] for i in idx],
+                                        [results[i] for i in idx], 0.8, workspace=bws)
+                    if timed:
+                        nm.profile_event_pairs(nm.PROF_MATCH_TOP2, [])
+                    del keep
+        else:
+            for k in range(1, MS):
+                mstreams[k].wait_stream(mstream)        # the matches start when the last detect call has finished
+            for i in range(P):
+                nA, nB = counts[i]
+                with torch.cuda.stream(mstreams[i % MS]):
+                    if timed:
+                        nm.profile_events(nm.PROF_MATCH_TOP2, ev_match[i][0], ev_match[i][1])
+                    nm.sift_match(arenas[2 * i].desc, arenas[2 * i + 1].desc, 0.8, prior=results[i], workspace=wss[i % MS],
+                                  nA=nA, nB=nB)
+            if timed:
+                nm.profile_events(nm.PROF_MATCH_TOP2, None, None)
+            for k in range(1, MS):
+                mstream.wait_stream(mstreams[k])
         for s in range(S):                      # the next step's detects overwrite the arenas: wait for the matches
             streams[s].wait_stream(mstream)
         if timed:
@@ -321,7 +338,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[2]: SIFT detect+describe x2 + fused BF L2 match per 1920x1080 pair",
                        "pairs_per_gpu_per_step": P, "detect_streams": S, "frames_per_detect_call": B,
-                       "host_enqueue_threads": T, "match_streams": MS, "phases": "overlapped" if overlap else "detect then match",
+                       "host_enqueue_threads": T, "match_streams": MS, "pairs_per_match_call": MB, "phases": "overlapped" if overlap else "detect then match",
                        "keypoints_pair0": [nA, nB], "capacity": CAP,
                        "parallelism": "frame-pair sharding, %d rank(s), no data-path collective" % world},
             "keypoints_per_s": round(kp_all * args.steps / dt, 1),

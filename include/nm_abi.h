@@ -55,6 +55,9 @@ NM_API int nm_fill_u32(void *dst, size_t count, unsigned int pattern, void *stre
 #define NM_PROF_PYRAMID_O0 1
 #define NM_PROF_SITES 2
 NM_API int nm_profile_events(int site, void *start_event, void *stop_event);
+/* The same with a caller-owned list of npairs (start, stop) hipEvent_t pairs, events[2k], events[2k+1], consumed by the
+ * k-th launch of the site (a batched call launches the MFMA kernel once per pair). npairs = 0 clears. */
+NM_API int nm_profile_event_pairs(int site, void *const *events, int npairs);
 
 /* Self-test (no reference counterpart): the gradient's fast correctly-rounded square root is compared with the IEEE
  * expansion for EVERY float of its domain [2^-96, 2^96) and 0; *d_mismatches (device) receives the number of differing
@@ -128,6 +131,14 @@ NM_API int nm_get_sift_matches_f32(const float *distance, int rows, int cols, in
  * (match.cu:107-116). Match decisions are made on distances recomputed exactly in the reference's summation
  * order; rows whose best two cannot be proven from the MFMA pass are re-scanned exactly. workspace: nm_sift_match_workspace_bytes(nA, nB) bytes of device scratch.                            */
 NM_API size_t nm_sift_match_workspace_bytes(int nA, int nB);
+/* n <= 16 independent matches in one call (arrays of n): the norms, finalize and fallback launches cover all pairs at
+ * once (the pair is a grid dimension), only the MFMA kernel runs once per pair -- 4 + n stream operations instead of
+ * 5 n. result[k] as in nm_sift_match_f32 (no distance matrices). workspace: nm_sift_match_batch_workspace_bytes bytes
+ * (the per-pair bounds laid end to end, in order). */
+#define NM_SIFT_MATCH_MAX_BATCH 16
+NM_API size_t nm_sift_match_batch_workspace_bytes(int n, const int *nA, const int *nB);
+NM_API int nm_sift_match_batch_f32(int n, const float *const *A, const int *nA, const float *const *B, const int *nB,
+                                   int *const *result, float ambiguity, void *workspace, void *stream);
 /* HOST function (no device access): the work distribution the matcher would use for (nA, nB). plan[0..5] = query blocks
  * of 256 rows, candidate tiles of 128 rows per block, persistent workgroups G, units per workgroup (base), workgroups
  * with one unit more (rem), partial lists per query S (<= 64, what the workspace bound assumes). Units = blocks x tiles

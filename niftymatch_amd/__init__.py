@@ -38,6 +38,9 @@ _SIGNATURES = {
     "nm_bf_distance_f32": (_I, [_P, _I, _P, _I, _I, _P, _P]),
     "nm_get_sift_matches_f32": (_I, [_P, _I, _I, _I, _P, _F, _P]),
     "nm_sift_match_plan": (_I, [_I, _I, _P]),
+    "nm_profile_event_pairs": (_I, [_I, _P, _I]),
+    "nm_sift_match_batch_workspace_bytes": (_SZ, [_I, _P, _P]),
+    "nm_sift_match_batch_f32": (_I, [_I, _P, _P, _P, _P, _P, _F, _P, _P]),
     "nm_sift_match_workspace_bytes": (_SZ, [_I, _I]),
     "nm_sift_match_f32": (_I, [_P, _I, _P, _I, _P, _P, _F, _P, _P]),
     "nm_sift_match_fallback_count": (_I, [_P, _I, _I, _P, _P]),
@@ -129,6 +132,15 @@ def profile_events(site, start=None, stop=None):
     """Register (torch.cuda.Event, torch.cuda.Event) to be recorded around a kernel site; None clears."""
     _check(lib().nm_profile_events(site, start.cuda_event if start is not None else None,
                                    stop.cuda_event if stop is not None else None), "nm_profile_events")
+
+
+def profile_event_pairs(site, pairs):
+    """pairs: list of (start, stop) torch.cuda.Event, consumed one per launch of the site; [] clears. The returned ctypes
+    array must stay alive until the hook is cleared."""
+    n = len(pairs)
+    arr = (C.c_void_p * (2 * n))(*[e.cuda_event for p in pairs for e in p]) if n else None
+    _check(lib().nm_profile_event_pairs(site, arr, n), "nm_profile_event_pairs")
+    return arr
 
 
 def create_kernel_for_sigma(sigma):
@@ -270,6 +282,40 @@ def sift_match(A, B, ambiguity=0.8, want_distance=False, prior=None, workspace=N
                                    _dev(D) if D is not None else None, _dev(res, torch.int32), ambiguity,
                                    _dev(ws.buf), _stream()), "nm_sift_match_f32")
     return res, D
+
+
+MATCH_MAX_BATCH = 16
+
+
+class MatchBatchWorkspace:
+    """Device scratch for nm_sift_match_batch_f32 with at most n pairs of at most (nA, nB) rows."""
+
+    def __init__(self, n, nA, nB, device):
+        torch = _torch()
+        self.n, self.nA, self.nB = n, nA, nB
+        self.buf = torch.empty(n * lib().nm_sift_match_workspace_bytes(nA, nB), dtype=torch.uint8, device=device)
+
+
+def sift_match_batch(As, Bs, nAs, nBs, results, ambiguity=0.8, workspace=None):
+    """len(As) <= MATCH_MAX_BATCH matches in one call; results[k] (int32, >= nAs[k]) is updated in place like the
+    `prior` of sift_match."""
+    torch = _torch()
+    n = len(As)
+    if not (n == len(Bs) == len(nAs) == len(nBs) == len(results)) or not 0 < n <= MATCH_MAX_BATCH:
+        raise NmError("bad batch")
+    ia = (C.c_int * n)(*nAs)
+    ib = (C.c_int * n)(*nBs)
+    need = lib().nm_sift_match_batch_workspace_bytes(n, ia, ib)
+    if workspace is None:
+        workspace = MatchBatchWorkspace(n, max(nAs), max(nBs), As[0].device)
+    if workspace.buf.numel() < need:
+        raise NmError("batch workspace too small")
+    arr = lambda vals: (C.c_void_p * n)(*vals)
+    _check(lib().nm_sift_match_batch_f32(n, arr([_dev(a, torch.float32) for a in As]), ia,
+                                         arr([_dev(b, torch.float32) for b in Bs]), ib,
+                                         arr([_dev(r, torch.int32) for r in results]), ambiguity, _dev(workspace.buf),
+                                         _stream()), "nm_sift_match_batch_f32")
+    return workspace
 
 
 def match_fallback_count(workspace, nA, nB):

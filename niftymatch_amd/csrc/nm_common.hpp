@@ -21,11 +21,23 @@
 static inline int nm_divup(int a, int b) { return (a + b - 1) / b; }
 static inline hipStream_t nm_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
-// ---- profiling hook (nm_profile_events) ----
-struct NmProfSite { hipEvent_t start, stop; };
+// ---- profiling hook (nm_profile_events / nm_profile_event_pairs) ----
+// Either one (start, stop) pair, re-recorded by every launch of the site, or a caller-owned list of pairs consumed in
+// launch order (a batched call launches the site several times).
+struct NmProfSite { hipEvent_t start, stop; void *const *list; int n, next; };
 extern thread_local NmProfSite nm_prof_sites[2];
-static inline void nm_prof_begin(int site, hipStream_t st) { if (nm_prof_sites[site].start) (void)hipEventRecord(nm_prof_sites[site].start, st); }
-static inline void nm_prof_end(int site, hipStream_t st) { if (nm_prof_sites[site].stop) (void)hipEventRecord(nm_prof_sites[site].stop, st); }
+static inline void nm_prof_begin(int site, hipStream_t st)
+{
+    NmProfSite &p = nm_prof_sites[site];
+    if (p.list) { if (p.next < p.n) (void)hipEventRecord(static_cast<hipEvent_t>(p.list[2 * p.next]), st); }
+    else if (p.start) (void)hipEventRecord(p.start, st);
+}
+static inline void nm_prof_end(int site, hipStream_t st)
+{
+    NmProfSite &p = nm_prof_sites[site];
+    if (p.list) { if (p.next < p.n) { (void)hipEventRecord(static_cast<hipEvent_t>(p.list[2 * p.next + 1]), st); ++p.next; } }
+    else if (p.stop) (void)hipEventRecord(p.stop, st);
+}
 
 // ---- internal launchers shared between translation units (not part of the C ABI) ----
 struct NmGradBatch {            // up to 3 planes per launch (gradient levels 0..2 of one octave)

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void fill_u32_kernel(unsigned int *__restrict_
 
 }  // namespace
 
-thread_local NmProfSite nm_prof_sites[2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+thread_local NmProfSite nm_prof_sites[2] = {{nullptr, nullptr, nullptr, 0, 0}, {nullptr, nullptr, nullptr, 0, 0}};
 
 struct nm_sift_arena {
     int width, height, capacity;
@@ -68,6 +68,16 @@ int nm_profile_events(int site, void *start_event, void *stop_event)
     if (site < 0 || site >= NM_PROF_SITES) return (int)hipErrorInvalidValue;
     nm_prof_sites[site].start = static_cast<hipEvent_t>(start_event);
     nm_prof_sites[site].stop = static_cast<hipEvent_t>(stop_event);
+    nm_prof_sites[site].list = nullptr; nm_prof_sites[site].n = nm_prof_sites[site].next = 0;
+    return 0;
+}
+
+int nm_profile_event_pairs(int site, void *const *events, int npairs)
+{
+    if (site < 0 || site >= NM_PROF_SITES || npairs < 0) return (int)hipErrorInvalidValue;
+    nm_prof_sites[site].start = nm_prof_sites[site].stop = nullptr;
+    nm_prof_sites[site].list = npairs ? events : nullptr;
+    nm_prof_sites[site].n = npairs; nm_prof_sites[site].next = 0;
     return 0;
 }
 

@@ -65,13 +65,37 @@ static MatchPlan make_plan(int nA, int nB)
     return p;
 }
 
-// ||x||^2 of every row of A (nA rows) and B (nB rows) in one launch.
-__global__ __launch_bounds__(256) void norms_kernel(const float *__restrict__ A, int nA, float *__restrict__ na,
-                                                   const float *__restrict__ B, int nB, float *__restrict__ nb,
-                                                   int *__restrict__ fb_count)
+// Everything the small launches around the MFMA kernel need for one (A, B) pair. A batched call (nm_sift_match_batch_f32)
+// runs norms / finalize / fallback / merge ONCE for all its pairs (the pair is a grid dimension) and only the MFMA
+// kernel once per pair: the ~45 us of dependent-launch gaps and tiny launches per match shrink to a few per call.
+struct MatchPair {
+    const float *A, *B;
+    float *na, *nb;
+    float4 *partial;
+    float *partial3;
+    int *fb_count, *fb_list;
+    int *result;
+    float *min1, *min2;
+    int *idx1;
+    int nA, nB, S, mode, index_offset;
+};
+constexpr int MATCH_MAX_BATCH = 16;
+struct MatchBatch {
+    MatchPair p[MATCH_MAX_BATCH];
+    int n;
+    float ambiguity;
+};
+static_assert(sizeof(MatchBatch) <= 4096, "kernel arguments are limited to 4 KB");
+
+// ||x||^2 of every row of A (nA rows) and B (nB rows) of every pair in one launch.
+__global__ __launch_bounds__(256) void norms_kernel(MatchBatch bt)
 {
+    const MatchPair &c = bt.p[blockIdx.y];
+    const float *__restrict__ A = c.A, *__restrict__ B = c.B;
+    float *__restrict__ na = c.na, *__restrict__ nb = c.nb;
+    const int nA = c.nA, nB = c.nB;
     int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0 && fb_count) *fb_count = 0;           // first launch of a match call: resets the fallback list (no memset node)
+    if (i == 0 && c.fb_count) *c.fb_count = 0;       // first launch of a match call: resets the fallback list (no memset node)
     const float *X = A;
     float *out = na;
     if (i >= nA) { i -= nA; X = B; out = nb; if (i >= nB) return; }
@@ -334,16 +358,19 @@ __device__ __forceinline__ void emit_match(int i, float m1, int idx, float m2, i
 // Proof obligation: every candidate NOT recomputed has an approximate distance >= rest (the minimum over the chunks'
 // third-best values and everything that dropped out of a top-4 list). If rest is not safely above the exact min2
 // (margin = bound on the MFMA formulation's error), the query is appended to the fallback list instead of being emitted.
-__global__ __launch_bounds__(256) void match_finalize_kernel(const float *__restrict__ A, int nA,
-                                                            const float *__restrict__ B, int /*nB*/, int S,
-                                                            const float4 *__restrict__ partial,
-                                                            const float *__restrict__ partial3,
-                                                            const float *__restrict__ na, int mode, int index_offset,
-                                                            float ambiguity, int *__restrict__ result,
-                                                            float *__restrict__ min1_out, int *__restrict__ idx_out,
-                                                            float *__restrict__ min2_out, int *__restrict__ fb_count,
-                                                            int *__restrict__ fb_list)
+__global__ __launch_bounds__(256) void match_finalize_kernel(MatchBatch bt)
 {
+    const MatchPair &c = bt.p[blockIdx.y];
+    const float *__restrict__ A = c.A, *__restrict__ B = c.B;
+    const int nA = c.nA, S = c.S, mode = c.mode, index_offset = c.index_offset;
+    const float4 *__restrict__ partial = c.partial;
+    const float *__restrict__ partial3 = c.partial3;
+    const float *__restrict__ na = c.na;
+    const float ambiguity = bt.ambiguity;
+    int *__restrict__ result = c.result;
+    float *__restrict__ min1_out = c.min1, *__restrict__ min2_out = c.min2;
+    int *__restrict__ idx_out = c.idx1;
+    int *__restrict__ fb_count = c.fb_count, *__restrict__ fb_list = c.fb_list;
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int i = t >> 2, sub = t & 3;
     const bool live = i < nA;
@@ -430,10 +457,13 @@ __device__ __forceinline__ void top2_merge(float &m1, int &i1, float &m2, float 
     m2 = (hi < s2) ? hi : s2;
 }
 
-__global__ __launch_bounds__(256) void match_fallback_kernel(const float *__restrict__ A, const float *__restrict__ B,
-                                                            int nB, const int *__restrict__ fb_count,
-                                                            const int *__restrict__ fb_list, float4 *__restrict__ part)
+__global__ __launch_bounds__(256) void match_fallback_kernel(MatchBatch bt)
 {
+    const MatchPair &c = bt.p[blockIdx.z];
+    const float *__restrict__ A = c.A, *__restrict__ B = c.B;
+    const int nB = c.nB;
+    const int *__restrict__ fb_count = c.fb_count, *__restrict__ fb_list = c.fb_list;
+    float4 *__restrict__ part = c.partial;
     __shared__ float s_m1[4], s_m2[4];
     __shared__ int s_i1[4];
     const int count = *fb_count;
@@ -481,13 +511,16 @@ __global__ __launch_bounds__(256) void match_fallback_kernel(const float *__rest
     }
 }
 
-__global__ __launch_bounds__(256) void match_fallback_merge_kernel(const int *__restrict__ fb_count,
-                                                                  const int *__restrict__ fb_list,
-                                                                  const float4 *__restrict__ part, int mode,
-                                                                  int index_offset, float ambiguity, int *__restrict__ result,
-                                                                  float *__restrict__ min1_out, int *__restrict__ idx_out,
-                                                                  float *__restrict__ min2_out)
+__global__ __launch_bounds__(256) void match_fallback_merge_kernel(MatchBatch bt)
 {
+    const MatchPair &c = bt.p[blockIdx.y];
+    const int *__restrict__ fb_count = c.fb_count, *__restrict__ fb_list = c.fb_list;
+    const float4 *__restrict__ part = c.partial;
+    const int mode = c.mode, index_offset = c.index_offset;
+    const float ambiguity = bt.ambiguity;
+    int *__restrict__ result = c.result;
+    float *__restrict__ min1_out = c.min1, *__restrict__ min2_out = c.min2;
+    int *__restrict__ idx_out = c.idx1;
     const int count = *fb_count;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < count; e += gridDim.x * 256) {
         float m1 = __builtin_inff(), m2 = __builtin_inff(); int i1 = 0x7fffffff;
@@ -644,35 +677,77 @@ static MatchWs carve(void *workspace, int nA, int nB, const MatchPlan &p)
     return w;
 }
 
-static int run_fused(const float *A, int nA, const float *B, int nB, int mode, int index_offset, float ambiguity,
-                     int *result, float *min1, int *idx1, float *min2, void *workspace, hipStream_t st)
+static size_t pair_workspace_bytes(int nA, int nB)
 {
-    if (nA <= 0 || nB <= 0) return 0;
-    const MatchPlan p = make_plan(nA, nB);
-    MatchWs w = carve(workspace, nA, nB, p);
-    hipLaunchKernelGGL(norms_kernel, dim3(nm_divup(nA + nB, 256)), dim3(256), 0, st, A, nA, w.na, B, nB, w.nb, w.fb_count);
+    if (nA < 0) nA = 0;
+    if (nB < 0) nB = 0;
+    return align256((size_t)nA * 4) + align256((size_t)nB * 4) + align256((size_t)nA * MAX_CHUNKS * sizeof(float4)) +
+           align256((size_t)nA * MAX_CHUNKS * sizeof(float)) + 256 + align256((size_t)nA * 4) + 256;
+}
+
+struct MatchJob {                 // host-side description of one pair of a (possibly batched) call
+    const float *A, *B;
+    int nA, nB, mode, index_offset;
+    int *result;
+    float *min1, *min2;
+    int *idx1;
+    void *workspace;
+};
+
+// norms (1 launch for all pairs) -> MFMA top-2 (1 launch per pair) -> finalize, fallback, merge (1 launch each)
+static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    if (n > MATCH_MAX_BATCH) return (int)hipErrorInvalidValue;
+    MatchBatch bt{};
+    MatchPlan plans[MATCH_MAX_BATCH];
+    bt.ambiguity = ambiguity;
+    int max_rows = 0, max_a = 0;
+    for (int k = 0; k < n; ++k) {
+        const MatchJob &j = jobs[k];
+        if (j.nA <= 0 || j.nB <= 0) continue;                 // empty sets: a no-op for this pair, as in the reference
+        const int q = bt.n++;
+        plans[q] = make_plan(j.nA, j.nB);
+        const MatchWs w = carve(j.workspace, j.nA, j.nB, plans[q]);
+        MatchPair &c = bt.p[q];
+        c.A = j.A; c.B = j.B; c.nA = j.nA; c.nB = j.nB; c.na = w.na; c.nb = w.nb; c.partial = w.partial;
+        c.partial3 = w.partial3; c.fb_count = w.fb_count; c.fb_list = w.fb_list; c.S = plans[q].S; c.mode = j.mode;
+        c.index_offset = j.index_offset; c.result = j.result; c.min1 = j.min1; c.min2 = j.min2; c.idx1 = j.idx1;
+        max_rows = max(max_rows, j.nA + j.nB);
+        max_a = max(max_a, j.nA);
+    }
+    if (bt.n == 0) return 0;
+    hipLaunchKernelGGL(norms_kernel, dim3(nm_divup(max_rows, 256), bt.n), dim3(256), 0, st, bt);
     NM_LAUNCH_CHECK();
     const size_t lds_bytes = (size_t)2 * TILE_C * KP * sizeof(float);
     // per call: the attribute is per device, and a process may drive several (cheap host-side call, not a stream op)
     NM_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    nm_prof_begin(NM_PROF_MATCH_TOP2, st);
-    hipLaunchKernelGGL(match_top2_kernel, dim3(p.G), dim3(512), lds_bytes, st, A, nA, B, nB, w.na, w.nb, p, w.partial,
-                       w.partial3);
-    nm_prof_end(NM_PROF_MATCH_TOP2, st);
-    NM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(match_finalize_kernel, dim3(nm_divup(4 * nA, 256)), dim3(256), 0, st, A, nA, B, nB, p.S, w.partial,
-                       w.partial3, w.na, mode, index_offset, ambiguity, result, min1, idx1, min2, w.fb_count, w.fb_list);
+    for (int q = 0; q < bt.n; ++q) {
+        const MatchPair &c = bt.p[q];
+        nm_prof_begin(NM_PROF_MATCH_TOP2, st);
+        hipLaunchKernelGGL(match_top2_kernel, dim3(plans[q].G), dim3(512), lds_bytes, st, c.A, c.nA, c.B, c.nB, c.na, c.nb,
+                           plans[q], c.partial, c.partial3);
+        nm_prof_end(NM_PROF_MATCH_TOP2, st);
+        NM_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(match_finalize_kernel, dim3(nm_divup(4 * max_a, 256), bt.n), dim3(256), 0, st, bt);
     NM_LAUNCH_CHECK();
     static_assert(FB_SPLIT <= MAX_CHUNKS, "fallback slices reuse the partial area");
     // few rows are ever listed (0-2 of 12k on SIFT data): a small grid drains fastest when the list is empty, and its
     // workgroups loop over the entries when it is not
-    hipLaunchKernelGGL(match_fallback_kernel, dim3(FB_SPLIT, 8), dim3(256), 0, st, A, B, nB, w.fb_count, w.fb_list, w.partial);
+    hipLaunchKernelGGL(match_fallback_kernel, dim3(FB_SPLIT, 8, bt.n), dim3(256), 0, st, bt);
     NM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(match_fallback_merge_kernel, dim3(8), dim3(256), 0, st, w.fb_count, w.fb_list, w.partial, mode,
-                       index_offset, ambiguity, result, min1, idx1, min2);
+    hipLaunchKernelGGL(match_fallback_merge_kernel, dim3(8, bt.n), dim3(256), 0, st, bt);
     NM_LAUNCH_CHECK();
     return 0;
+}
+
+static int run_fused(const float *A, int nA, const float *B, int nB, int mode, int index_offset, float ambiguity,
+                     int *result, float *min1, int *idx1, float *min2, void *workspace, hipStream_t st)
+{
+    const MatchJob j{A, B, nA, nB, mode, index_offset, result, min1, min2, idx1, workspace};
+    return run_fused_batch(&j, 1, ambiguity, st);
 }
 
 }  // namespace
@@ -713,12 +788,27 @@ int nm_get_sift_matches_f32(const float *distance, int rows, int cols, int buffe
 
 // Upper bound for every call with nA' <= nA and nB' <= nB on the same workspace (the grid plan, hence the number of
 // candidate chunks S <= MAX_CHUNKS, depends on the actual sizes).
-size_t nm_sift_match_workspace_bytes(int nA, int nB)
+size_t nm_sift_match_workspace_bytes(int nA, int nB) { return pair_workspace_bytes(nA, nB); }
+
+size_t nm_sift_match_batch_workspace_bytes(int n, const int *nA, const int *nB)
 {
-    if (nA < 0) nA = 0;
-    if (nB < 0) nB = 0;
-    return align256((size_t)nA * 4) + align256((size_t)nB * 4) + align256((size_t)nA * MAX_CHUNKS * sizeof(float4)) +
-           align256((size_t)nA * MAX_CHUNKS * sizeof(float)) + 256 + align256((size_t)nA * 4) + 256;
+    size_t total = 0;
+    for (int k = 0; k < n; ++k) total += pair_workspace_bytes(nA ? nA[k] : 0, nB ? nB[k] : 0);
+    return total;
+}
+
+int nm_sift_match_batch_f32(int n, const float *const *A, const int *nA, const float *const *B, const int *nB,
+                            int *const *result, float ambiguity, void *workspace, void *stream)
+{
+    if (n <= 0) return 0;
+    if (n > MATCH_MAX_BATCH || !A || !nA || !B || !nB || !result || !workspace) return (int)hipErrorInvalidValue;
+    MatchJob jobs[MATCH_MAX_BATCH];
+    char *ws = static_cast<char *>(workspace);
+    for (int k = 0; k < n; ++k) {
+        jobs[k] = MatchJob{A[k], B[k], nA[k], nB[k], 0, 0, result[k], nullptr, nullptr, nullptr, ws};
+        ws += pair_workspace_bytes(nA[k], nB[k]);
+    }
+    return run_fused_batch(jobs, n, ambiguity, nm_stream(stream));
 }
 
 int nm_sift_match_plan(int nA, int nB, int plan[6])

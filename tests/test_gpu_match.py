@@ -225,3 +225,30 @@ def test_oversized_workspace_is_valid_for_smaller_calls(nm, oracle, cuda):
         res, _ = nm.sift_match(_t(A, cuda), _t(B, cuda), 0.8, workspace=ws)
         torch.cuda.synchronize()
         assert np.array_equal(res.cpu().numpy(), ref), (na, nb)
+
+
+def test_match_batch_equals_single_matches(nm, oracle, cuda):
+    """nm_sift_match_batch_f32: norms / finalize / fallback once for all pairs, the MFMA kernel once per pair. Pairs of
+    different sizes incl. an empty one, near-ties that take the fallback, prior values that must survive."""
+    import torch
+    rng = np.random.default_rng(5)
+    shapes = [(700, 900), (1, 1), (1300, 257), (0, 50), (2049, 1500), (300, 4000)]
+    As = [H.synth.descriptors(300 + k, max(na, 1))[:na] for k, (na, nb) in enumerate(shapes)]
+    Bs = [H.synth.descriptors(400 + k, max(nb, 1))[:nb] for k, (na, nb) in enumerate(shapes)]
+    Bs[0][7] = As[0][3]; Bs[0][800] = As[0][3]              # duplicate candidates: tie on the lowest index
+    Bs[4][10] = Bs[4][11]                                   # equal best and second best for some queries
+    tA = [_t(a if len(a) else np.zeros((1, 128), np.float32), cuda) for a in As]
+    tB = [_t(b if len(b) else np.zeros((1, 128), np.float32), cuda) for b in Bs]
+    results = [torch.full((max(na, 1),), -9, dtype=torch.int32, device=cuda) for na, _ in shapes]
+    nm.sift_match_batch(tA, tB, [s[0] for s in shapes], [s[1] for s in shapes], results, 0.8)
+    torch.cuda.synchronize()
+    for k, (na, nb) in enumerate(shapes):
+        if na == 0 or nb == 0:
+            assert bool((results[k] == -9).all())
+            continue
+        ref, _, _ = oracle.sift_matches(As[k], Bs[k], 0.8, want_distance=False, prior=np.full(na, -9, np.int32))
+        assert np.array_equal(results[k][:na].cpu().numpy(), ref), (k, na, nb)
+    # more pairs than the limit is refused
+    many = [tA[0]] * (nm.MATCH_MAX_BATCH + 1)
+    with pytest.raises(nm.NmError):
+        nm.sift_match_batch(many, many, [1] * len(many), [1] * len(many), [results[0]] * len(many))
