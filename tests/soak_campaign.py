@@ -79,6 +79,36 @@ for it in range(n_match):
         print("MATCH MISMATCH", it, na, nb, kind, amb, flush=True)
 print("matches done: %d cases, total mismatches %d, %.1fs" % (n_match, bad, time.time() - t0), flush=True)
 
+# ---- batched matcher: random groups of pairs through nm_sift_match_batch_f32 ----
+t0 = time.time()
+n_groups = max(5, n_match // 10)
+for it in range(n_groups):
+    k = int(rng.integers(1, nm.MATCH_MAX_BATCH + 1))
+    As, Bs, refs = [], [], []
+    for _ in range(k):
+        na = int(rng.integers(0, 1500)) if rng.random() < 0.9 else 0
+        nb = int(rng.integers(1, 1500))
+        A = (rng.uniform(0, 1, (max(na, 1), 128)).astype(np.float32) * np.float32(rng.choice([1, 50, 400])))[:na]
+        B = rng.uniform(0, 1, (nb, 128)).astype(np.float32) * np.float32(rng.choice([1, 50, 400]))
+        if na and rng.random() < 0.5:
+            B[int(rng.integers(0, nb))] = A[int(rng.integers(0, na))]
+        As.append(A); Bs.append(B)
+    amb = float(rng.choice([0.8, 0.7, 1.2]))
+    res = [torch.full((max(len(a), 1),), -5, dtype=torch.int32, device=dev) for a in As]
+    nm.sift_match_batch([t(a if len(a) else np.zeros((1, 128), np.float32)) for a in As], [t(b) for b in Bs],
+                        [len(a) for a in As], [len(b) for b in Bs], res, amb)
+    torch.cuda.synchronize()
+    for a, b, r in zip(As, Bs, res):
+        if len(a) == 0:
+            ok = bool((r == -5).all())
+        else:
+            ref, _, _ = O.sift_matches(a, b, amb, want_distance=False, prior=np.full(len(a), -5, np.int32))
+            ok = np.array_equal(r[:len(a)].cpu().numpy(), ref)
+        if not ok:
+            bad += 1
+            print("BATCH MATCH MISMATCH", it, len(a), len(b), amb, flush=True)
+print("batched matches done: %d groups, total mismatches %d, %.1fs" % (n_groups, bad, time.time() - t0), flush=True)
+
 # ---- side stages: front end, warps, blend, RANSAC ----
 t0 = time.time()
 n_side = max(10, n_frames // 5)
