@@ -30,30 +30,48 @@ def make_frames(nm, torch, dev, seeds):
     taps_d = torch.from_numpy(taps).to(dev)
     out = []
     for s in seeds:
-        raw = torch.from_numpy(synth.noise_frame(s, W, H)).to(dev)
+        raw = synth.noise_frame_torch(s, W, H, dev)      # bit-identical to synth.noise_frame, made on the device
         out.append(nm.convolve(raw, taps_d, r))
     torch.cuda.synchronize()
     return out
 
 
 def cpu_baseline():
-    """The CPU oracle (a port of the reference's semantics; the reference has no CPU path) on a bounded sample."""
+    """The CPU oracle (a port of the reference's semantics; the reference has no CPU path, src/utils/macros.h:1-8 is the
+    whole directory) on one 1080p pair, BASELINE.md section 2: median of 3 repetitions at all host threads (the whole
+    pair, nothing scaled) and at 1 thread (both frames whole + the first 1024 query rows of the match, scaled to all
+    rows: the scan is linear in the rows). Also returns the oracle's outputs for pair 0 so that the bench can check
+    what it timed."""
     sys.path.insert(0, os.path.join(_ROOT, "tests"))
-    import numpy as np
+    import statistics
     import oracle_lib as O
     import helpers as Hh
+    f0, f1 = Hh.blurred_frame(0, W, H), Hh.blurred_frame(1, W, H)
+
+    def timed(fn):
+        t0 = time.time()
+        r = fn()
+        return time.time() - t0, r
+
+    def one(rows):
+        td, (r0, r1) = timed(lambda: (O.sift_detect_describe(f0, CAP), O.sift_detect_describe(f1, CAP)))
+        n = r0["n"] if rows is None else min(rows, r0["n"])
+        tm, m = timed(lambda: O.sift_matches(r0["desc"][:n], r1["desc"], 0.8, want_distance=False))
+        return td, tm * (r0["n"] / float(n)), r0, r1, m
+
     threads = O.set_threads(0)
-    t0 = time.time()
-    r0 = O.sift_detect_describe(Hh.blurred_frame(0, W, H), CAP)
-    r1 = O.sift_detect_describe(Hh.blurred_frame(1, W, H), CAP)
-    t_detect = time.time() - t0
-    t0 = time.time()
-    O.sift_matches(r0["desc"], r1["desc"], 0.8, want_distance=False)
-    t_match = time.time() - t0
-    pair_s = t_detect + t_match
-    return {"value": round(1.0 / pair_s, 4), "unit": "frame-pairs/s", "cores": int(threads), "kind": "port",
-            "sample": "one whole 1080p pair, nothing scaled: both frames detect+describe (%.2fs) + %d x %d match (%.2fs)"
-                      % (t_detect, r0["n"], r1["n"], t_match)}
+    reps_all = [one(None) for _ in range(3)]
+    O.set_threads(1)
+    reps_1 = [one(1024) for _ in range(3)]
+    O.set_threads(0)
+    med = lambda reps: statistics.median(td + tm for td, tm, *_ in reps)
+    td, tm, r0, r1, m = sorted(reps_all, key=lambda r: r[0] + r[1])[1]
+    out = {"value": round(1.0 / med(reps_all), 4), "unit": "frame-pairs/s", "cores": int(threads), "kind": "port",
+           "value_1_thread": round(1.0 / med(reps_1), 5), "reps": 3,
+           "sample": "median of 3: one whole 1080p pair, nothing scaled, %d threads: both frames detect+describe (%.2fs) + "
+                     "%d x %d match (%.2fs); 1 thread: both frames whole + 1024 of the query rows, scaled to all rows"
+                     % (threads, td, r0["n"], r1["n"], tm)}
+    return out, (r0, r1, m[0])
 
 
 def allpairs_100k(nm, torch, dist, dev, rank, world, steps=3):
@@ -107,7 +125,70 @@ def allpairs_100k(nm, torch, dist, dev, rank, world, steps=3):
             "verified_sample_vs_fp64": ok}
 
 
-def main():
+def detect_256(nm, torch, dist, dev, cdev, rank, world, arenas, streams, B):
+    """BASELINE configs[3] as a secondary, separately timed measurement: 256 1080p frames (seeds 0..255), contiguous
+    blocks of 256 / world frames per rank (parallel.frames_of_rank), detect+describe only, in B-frame calls spread over
+    the detect streams; no data-path collective. Not part of `value`."""
+    from niftymatch_amd import parallel
+    mine = parallel.frames_of_rank(256, world, rank)
+    frames = make_frames(nm, torch, dev, mine)
+    B = max(1, min(B, len(arenas)))
+    S = max(1, min(len(streams), len(arenas) // B))
+    calls = [(k, min(k + B, len(frames))) for k in range(0, len(frames), B)]
+    kp = torch.zeros(1, dtype=torch.int64, device=dev)
+    kps = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(S)]
+
+    def run(count):
+        for c, (b, e) in enumerate(calls):
+            s = c % S
+            ar = arenas[s * B: s * B + (e - b)]             # a fixed arena set per stream: reuse is ordered by the stream
+            with torch.cuda.stream(streams[s]):
+                nm.detect_describe_batch(ar, frames[b:e])
+                if count:
+                    kps[s] += torch.stack([a.num_items[0] for a in ar]).sum()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(False)
+    barrier()
+    t0 = time.perf_counter()
+    run(True)
+    barrier()
+    dt = time.perf_counter() - t0
+    for k in kps:
+        kp += k
+    tot = torch.tensor([dt, float(kp.item()), float(len(frames))], dtype=torch.float64, device=cdev)
+    if world > 1:
+        mx = tot[:1].clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        tot[0] = mx[0]
+    dt, kp_all, n_all = float(tot[0]), float(tot[1]), int(tot[2])
+    return {"workload": "configs[3]: %d x 1080p frames, SIFT detect+describe only, %d per rank in %d-frame calls, %d rank(s)"
+                        % (n_all, len(frames), B, world),
+            "frames_per_s": round(n_all / dt, 1), "keypoints_per_s": round(kp_all / dt, 1),
+            "ms_total": round(1e3 * dt, 3), "keypoints_total": int(kp_all), "collective": "none"}
+
+
+def launcher_command(gpus, argv, environ):
+    """`python bench.py --gpus N` with N > 1 outside torchrun: the command that re-runs this script as N ranks (one per
+    GPU), or None when this process is already a rank (WORLD_SIZE set) or N == 1. Pure function: no GPU, no torch."""
+    if gpus <= 1 or "WORLD_SIZE" in environ:
+        return None
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -132,7 +213,20 @@ def main():
                          "host; combine with --no-allpairs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allpairs", action="store_true", help="skip the secondary config-5 measurement")
-    args = ap.parse_args()
+    ap.add_argument("--no-detect256", action="store_true", help="skip the secondary configs[3] measurement")
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    # Before anything touches the GPU: the driver's plain `python bench.py --gpus N` form becomes N ranks as a CHILD
+    # process (a process that has initialised HIP must never exec another program on this pool).
+    cmd = launcher_command(args.gpus, sys.argv[1:], os.environ)
+    if cmd is not None:
+        import subprocess
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.run(cmd, env=env).returncode)
 
     import torch
     import torch.distributed as dist
@@ -141,6 +235,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d: launch one rank per GPU" % (args.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     dev_index = local_rank % max(1, torch.cuda.device_count())     # rehearsals may put several ranks on one GPU
     torch.cuda.set_device(dev_index)
@@ -308,6 +403,21 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     kp_all, cmp_all = float(tot[0].item()), float(tot[1].item())
 
+    # what the timed loop left in the arenas / results of pair 0 (rank 0: seeds 0 and 1), for the oracle check below
+    snap = None
+    if rank == 0:
+        nA, nB = counts[0]
+        snap = {"n": (nA, nB), "kpts": [arenas[k].kpts[:n].cpu().numpy() for k, n in ((0, nA), (1, nB))],
+                "desc": [arenas[k].desc[:n].cpu().numpy() for k, n in ((0, nA), (1, nB))],
+                "match": results[0][:nA].cpu().numpy()}
+
+    detect256 = None
+    if not args.no_detect256:
+        try:
+            detect256 = detect_256(nm, torch, dist, dev, cdev, rank, world, arenas, streams, B)
+        except Exception as exc:
+            detect256 = {"error": repr(exc)}
+
     extra = None
     if not args.no_allpairs:
         for a in arenas:                     # give the memory back before the 100k x 100k workspaces
@@ -354,10 +464,19 @@ def main():
                                  "unit": "GB/s", "frac": round(pyr_bytes / (p_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                  "traffic": (t_pyr * B if t_pyr else None), "algorithmic_bytes": pyr_bytes, "avg_ms": round(p_ms, 4)},
         }
+        if detect256 is not None:
+            out["detect_256"] = detect256
         if extra is not None:
             out["allpairs_100k"] = extra
         if not args.no_cpu_baseline and world == 1:        # reported at N = 1 only (the other ranks would wait for it)
-            out["cpu_baseline"] = cpu_baseline()
+            import numpy as np
+            out["cpu_baseline"], (r0, r1, m) = cpu_baseline()
+            # the oracle's pair 0 against what the timed loop produced, bit for bit (siftfunctions.cu:100-181, match.cu:83-117)
+            ok = snap["n"] == (r0["n"], r1["n"])
+            ok = ok and all(np.array_equal(snap["kpts"][k], r["kpts"]) and np.array_equal(snap["desc"][k], r["desc"])
+                            for k, r in ((0, r0), (1, r1)))
+            ok = ok and np.array_equal(snap["match"], m)
+            out["verified_pair0_vs_oracle"] = bool(ok)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -514,6 +514,9 @@ def detect_describe_batch(arenas, grays):
     for a, g in zip(arenas, grays):
         if tuple(g.shape) != (a.height, a.width):
             raise NmError("frame shape %s does not match the arena (%d,%d)" % (tuple(g.shape), a.height, a.width))
+        if g.device != a.device or torch.cuda.current_device() != a.device.index:
+            raise NmError("arena lives on %s: frame on %s, current device %d" % (a.device, g.device,
+                                                                                torch.cuda.current_device()))
 
     def arr(vals):
         return (C.c_void_p * n)(*vals)
@@ -531,7 +534,14 @@ class SiftArena:
         torch = _torch()
         self.width, self.height, self.capacity = width, height, capacity
         self._h = C.c_void_p()
-        _check(lib().nm_sift_arena_create(width, height, capacity, C.byref(self._h)), "nm_sift_arena_create")
+        self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        # the native arena (buffers, side stream, events) is created on the CURRENT HIP device: make that `device`,
+        # where the output tensors live; the launchers refuse an arena of another device (hipErrorInvalidDevice)
+        with torch.cuda.device(self.device):
+            _check(lib().nm_sift_arena_create(width, height, capacity, C.byref(self._h)), "nm_sift_arena_create")
+        device = self.device
         self.desc = torch.zeros((capacity, 128), dtype=torch.float32, device=device)
         self.x = torch.zeros(capacity, dtype=torch.float32, device=device)
         self.y = torch.zeros(capacity, dtype=torch.float32, device=device)
@@ -548,6 +558,9 @@ class SiftArena:
         torch = _torch()
         if tuple(gray.shape) != (self.height, self.width):
             raise NmError("frame shape %s does not match the arena (%d,%d)" % (tuple(gray.shape), self.height, self.width))
+        if gray.device != self.device or torch.cuda.current_device() != self.device.index:
+            raise NmError("arena lives on %s: frame on %s, current device %d" % (self.device, gray.device,
+                                                                                torch.cuda.current_device()))
         _check(lib().nm_sift_detect_describe(self._h, _dev(gray, torch.float32), _dev(self.desc), _dev(self.x),
                                              _dev(self.y), _dev(self.kpts), _dev(self.orients), _dev(self.num_items),
                                              _stream()), "nm_sift_detect_describe")

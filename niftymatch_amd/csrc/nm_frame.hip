@@ -26,6 +26,7 @@ thread_local NmProfSite nm_prof_sites[2] = {{nullptr, nullptr, nullptr, 0, 0}, {
 
 struct nm_sift_arena {
     int width, height, capacity;
+    int device;                // the HIP device every buffer, the side stream and the events belong to
     SiftParams params;
     size_t npix;
     size_t bytes;
@@ -117,6 +118,8 @@ int nm_sift_arena_create(int width, int height, int capacity, nm_sift_arena **ou
     if (!a) return (int)hipErrorOutOfMemory;
     a->width = width; a->height = height; a->capacity = capacity;
     a->side = nullptr; a->ev_join = nullptr;
+    a->device = -1;
+    (void)hipGetDevice(&a->device);
     for (int o = 0; o < 20; ++o) a->ev_pyr[o] = nullptr;
     a->params = SiftParams(width, height);
     a->npix = (size_t)width * height;
@@ -225,6 +228,10 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
         for (int g = 0; g < f; ++g)
             if (as[g] == as[f]) return (int)hipErrorInvalidValue;
     }
+    int cur = -1;
+    NM_RETURN_IF(hipGetDevice(&cur));
+    for (int f = 0; f < n; ++f)
+        if (as[f]->device != cur) return (int)hipErrorInvalidDevice;     // arenas live on the device they were created on
     hipStream_t st = nm_stream(stream);
     const SiftParams &P = as[0]->params;
     const int W = as[0]->width, H = as[0]->height;
@@ -245,45 +252,54 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
         da.desc[f] = desc[f]; da.x[f] = x[f]; da.y[f] = y[f];
     }
     hipStream_t side = as[0]->side;          // every detection / description launch covers all frames of the call
-    for (int o = 0; o < P._num_octaves; ++o) {
-        const int ow = W >> o, oh = H >> o;
-        const float xper = (float)std::pow(2.0, o);
-        rc = octave_pyramid(as, n, o, ow, oh, false, o + 1 < P._num_octaves, st);
-        if (rc) return rc;
-        NM_RETURN_IF(hipEventRecord(as[0]->ev_pyr[o], st));
-        NM_RETURN_IF(hipStreamWaitEvent(side, as[0]->ev_pyr[o], 0));
+    bool forked = false;
+    auto body = [&]() -> int {
+        for (int o = 0; o < P._num_octaves; ++o) {
+            const int ow = W >> o, oh = H >> o;
+            const float xper = (float)std::pow(2.0, o);
+            int e = octave_pyramid(as, n, o, ow, oh, false, o + 1 < P._num_octaves, st);
+            if (e) return e;
+            NM_RETURN_IF(hipEventRecord(as[0]->ev_pyr[o], st));
+            NM_RETURN_IF(hipStreamWaitEvent(side, as[0]->ev_pyr[o], 0));
+            forked = true;
 
-        const int nseg = nm_divup(ow, 256);
-        const int n_blocks = oh * nseg;
-        NmDetectArgs d{};
-        NmScanArgs s{};
-        NmGatherArgs g{};
-        d.n = s.n = g.n = n;
-        d.ow = ow; d.oh = oh; d.peak = P._peak_threshold; d.edge = P._edge_threshold; d.xper = xper;
-        d.sigma0 = P._sigma_0; d.num_dogs = P._num_dog_levels; d.stage_stride = as[0]->stage_stride;
-        d.n_blocks = n_blocks; d.nseg = nseg;
-        s.n_blocks = n_blocks; s.octave = o;
-        g.stage_stride = as[0]->stage_stride; g.n_blocks = n_blocks; g.octave = o;
-        s.capacity = as[0]->capacity; g.capacity = as[0]->capacity;
-        for (int f = 0; f < n; ++f) {
-            nm_sift_arena *a = as[f];
-            for (int i = 0; i < 5; ++i) d.dog[f][i] = a->dog[o][i];
-            d.staging[f] = a->staging; d.counts[f] = a->counts;
-            s.counts[f] = a->counts; s.offsets[f] = a->offsets; s.book[f] = a->book;
-            s.d_num_items[f] = d_num_items ? d_num_items[f] : nullptr;
-            g.staging[f] = a->staging; g.counts[f] = a->counts; g.offsets[f] = a->offsets; g.book[f] = a->book;
-            g.kpts[f] = kp[f];
-            da.grad[f][o] = a->grad[o];
+            const int nseg = nm_divup(ow, 256);
+            const int n_blocks = oh * nseg;
+            NmDetectArgs d{};
+            NmScanArgs s{};
+            NmGatherArgs g{};
+            d.n = s.n = g.n = n;
+            d.ow = ow; d.oh = oh; d.peak = P._peak_threshold; d.edge = P._edge_threshold; d.xper = xper;
+            d.sigma0 = P._sigma_0; d.num_dogs = P._num_dog_levels; d.stage_stride = as[0]->stage_stride;
+            d.n_blocks = n_blocks; d.nseg = nseg;
+            s.n_blocks = n_blocks; s.octave = o;
+            g.stage_stride = as[0]->stage_stride; g.n_blocks = n_blocks; g.octave = o;
+            s.capacity = as[0]->capacity; g.capacity = as[0]->capacity;
+            for (int f = 0; f < n; ++f) {
+                nm_sift_arena *a = as[f];
+                for (int i = 0; i < 5; ++i) d.dog[f][i] = a->dog[o][i];
+                d.staging[f] = a->staging; d.counts[f] = a->counts;
+                s.counts[f] = a->counts; s.offsets[f] = a->offsets; s.book[f] = a->book;
+                s.d_num_items[f] = d_num_items ? d_num_items[f] : nullptr;
+                g.staging[f] = a->staging; g.counts[f] = a->counts; g.offsets[f] = a->offsets; g.book[f] = a->book;
+                g.kpts[f] = kp[f];
+                da.grad[f][o] = a->grad[o];
+            }
+            e = nm_launch_detect_octave(d, s, g, side);
+            if (e) return e;
+            da.geom[o].ow = ow; da.geom[o].oh = oh; da.geom[o].xper = xper;
         }
-        rc = nm_launch_detect_octave(d, s, g, side);
-        if (rc) return rc;
-        da.geom[o].ow = ow; da.geom[o].oh = oh; da.geom[o].xper = xper;
+        return nm_launch_frame_describe(da, side);
+    };
+    rc = body();
+    if (forked) {
+        // also on an error path: the side stream must always be joined back, or a stream capture would be left with an
+        // unjoined fork and the next call on these arenas could overtake side-stream work still in flight
+        const hipError_t e1 = hipEventRecord(as[0]->ev_join, side);
+        const hipError_t e2 = (e1 == hipSuccess) ? hipStreamWaitEvent(st, as[0]->ev_join, 0) : e1;
+        if (!rc && e2 != hipSuccess) rc = (int)e2;
     }
-    rc = nm_launch_frame_describe(da, side);
-    if (rc) return rc;
-    NM_RETURN_IF(hipEventRecord(as[0]->ev_join, side));
-    NM_RETURN_IF(hipStreamWaitEvent(st, as[0]->ev_join, 0));
-    return 0;
+    return rc;
 }
 
 int nm_sift_detect_describe(nm_sift_arena *a, const float *gray, float *desc, float *x, float *y, float *kpts,

@@ -553,6 +553,15 @@ __global__ __launch_bounds__(256) void match_merge_kernel(const float *__restric
     }
 }
 
+// An empty candidate shard (world > nB, or uneven tiny sets): the neutral triple, so that the merge ignores the shard.
+__global__ __launch_bounds__(256) void shard_neutral_kernel(float *__restrict__ min1, int *__restrict__ idx1,
+                                                           float *__restrict__ min2, int nA)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nA) return;
+    min1[i] = __builtin_inff(); idx1[i] = -1; min2[i] = MIN2_INIT;
+}
+
 // ---- exact API building blocks ----
 __global__ __launch_bounds__(256) void transpose_kernel(float *__restrict__ odata, const float *__restrict__ idata,
                                                        int width, int height)
@@ -845,6 +854,12 @@ int nm_sift_match_f32(const float *A, int nA, const float *B, int nB, float *dis
 int nm_sift_match_shard_f32(const float *A, int nA, const float *B_shard, int nB_shard, int index_offset, float *min1,
                             int *idx1, float *min2, void *workspace, void *stream)
 {
+    if (nA > 0 && nB_shard <= 0) {      // nothing to scan: (inf, -1, min2 initial) loses against every real candidate
+        hipLaunchKernelGGL(shard_neutral_kernel, dim3(nm_divup(nA, 256)), dim3(256), 0, nm_stream(stream), min1, idx1,
+                           min2, nA);
+        NM_LAUNCH_CHECK();
+        return 0;
+    }
     return run_fused(A, nA, B_shard, nB_shard, 1, index_offset, 0.f, nullptr, min1, idx1, min2, workspace,
                      nm_stream(stream));
 }

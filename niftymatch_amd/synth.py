@@ -32,6 +32,32 @@ def noise_frame(seed, width, height):
     return (uniform01(seed, width * height) * np.float32(255.0)).reshape(height, width)
 
 
+def _s64(v):
+    """Python int (mod 2^64) as the signed value torch.int64 holds."""
+    v &= 0xFFFFFFFFFFFFFFFF
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def uniform01_torch(seed, n, device):
+    """uniform01 computed with torch int64 arithmetic on `device` (wrap-around multiply, logical shifts emulated):
+    bit-identical to the numpy version (tests/test_abi.py::test_synth_torch_equals_numpy); bench.py uses it to make
+    its frames on the GPU instead of shipping them over PCIe."""
+    import torch
+
+    def lsr(z, k):
+        return (z >> k) & ((1 << (64 - k)) - 1)
+    z = torch.arange(n, dtype=torch.int64, device=device) + _s64(int(seed) * (1 << 40))
+    z = z + _s64(0x9E3779B97F4A7C15)
+    z = (z ^ lsr(z, 30)) * _s64(0xBF58476D1CE4E5B9)
+    z = (z ^ lsr(z, 27)) * _s64(0x94D049BB133111EB)
+    z = z ^ lsr(z, 31)
+    return lsr(z, 40).to(torch.float32) * (1.0 / (1 << 24))
+
+
+def noise_frame_torch(seed, width, height, device):
+    return (uniform01_torch(seed, width * height, device) * 255.0).reshape(height, width)
+
+
 def descriptors(seed, n, dim=128):
     """n x dim fp32 Uniform[0,1) descriptor set (BASELINE configs 1 and 5)."""
     return uniform01(seed, n * dim).reshape(n, dim)

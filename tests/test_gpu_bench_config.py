@@ -1,0 +1,108 @@
+"""Parity on EXACTLY what bench.py times (BASELINE configs[2] / configs[3]): 16-frame 1080p nm_sift_detect_describe_batch
+calls (16 pointers per kernarg block, blockIdx.y = 16 detect grids) and 16-pair nm_sift_match_batch_f32 calls on the
+real, un-normalised ~12k x ~12k SIFT descriptors of those frames (the MFMA selector + margin logic on real data).
+Reference semantics: sift/siftfunctions.cu:100-181 (detect/describe orchestration), kernels/match.cu:83-117 (scan)."""
+import numpy as np
+import pytest
+
+import helpers as H
+from test_gpu_stages import _eq
+
+pytestmark = pytest.mark.gpu
+
+W, H_, CAP = 1920, 1080, 16384
+N = 16
+
+
+@pytest.fixture(scope="module")
+def bench16(nm, cuda):
+    """The bench's own frames (bench.make_frames: device-side noise + HIP pre-blur), one 16-frame call, exactly as
+    bench.py issues it; a second identical call checks that re-use of the arenas changes nothing."""
+    import torch
+
+    import bench
+    frames = bench.make_frames(nm, torch, cuda, list(range(N)))
+    arenas = [nm.SiftArena(W, H_, CAP, device=cuda) for _ in range(N)]
+    nm.detect_describe_batch(arenas, frames)
+    torch.cuda.synchronize()
+    first = [(int(a.num_items.item()), a.desc.clone()) for a in arenas]
+    nm.detect_describe_batch(arenas, frames)
+    torch.cuda.synchronize()
+    yield frames, arenas, first
+    for a in arenas:
+        a.close()
+
+
+def test_bench_frames_equal_the_oracle_blur(nm, oracle, cuda, bench16):
+    frames, _, _ = bench16
+    for s in (0, 1, 15):
+        _eq(frames[s], H.blurred_frame(s, W, H_), "bench frame %d (device noise + HIP blur) vs oracle blur" % s)
+
+
+def test_detect_batch_16x1080p(nm, oracle, cuda, bench16):
+    """Frames 0, 1 and 15 of the 16-frame call against the oracle (every output, bit for bit); the other 13 against the
+    single-frame driver; the repeated call is identical."""
+    import torch
+    frames, arenas, first = bench16
+    counts = [int(a.num_items.item()) for a in arenas]
+    for f, (n0, d0) in enumerate(first):
+        assert counts[f] == n0 and torch.equal(arenas[f].desc[:n0], d0[:n0]), "second call differs for frame %d" % f
+    for f in (0, 1, 15):
+        ref = oracle.sift_detect_describe(H.blurred_frame(f, W, H_), CAP)
+        a = arenas[f]
+        assert counts[f] == ref["n"] and ref["n"] > 10000
+        _eq(a.kpts[:counts[f]], ref["kpts"], "keypoints frame %d" % f)
+        _eq(a.orients[:counts[f]], ref["orient"], "orientations frame %d" % f)
+        _eq(a.x[:counts[f]], ref["x"], "x frame %d" % f)
+        _eq(a.y[:counts[f]], ref["y"], "y frame %d" % f)
+        _eq(a.desc[:counts[f]], ref["desc"], "descriptors frame %d" % f)
+    single = nm.SiftArena(W, H_, CAP, device=cuda)
+    for f in range(N):
+        if f in (0, 1, 15):
+            continue
+        single.detect_describe(frames[f])
+        torch.cuda.synchronize()
+        n = int(single.num_items.item())
+        assert n == counts[f]
+        for name in ("kpts", "orients", "x", "y", "desc"):
+            assert torch.equal(getattr(single, name)[:n], getattr(arenas[f], name)[:n]), (name, f)
+    single.close()
+
+
+def test_match_batch_16_pairs_on_real_descriptors(nm, oracle, cuda, bench16):
+    """16 pairs in ONE nm_sift_match_batch_f32 call, as bench.py issues them: the 8 frame pairs (2i, 2i+1) and their
+    reverses (2i+1, 2i). Pairs 0 and 9 (= frames (0,1) and (3,2)) against the oracle's full scan; all 16 against single
+    nm_sift_match_f32 calls; pair 0 also with the materialised distance matrix against the oracle's."""
+    import torch
+    _, arenas, _ = bench16
+    cnt = [int(a.num_items.item()) for a in arenas]
+    pairs = [(2 * i, 2 * i + 1) for i in range(8)] + [(2 * i + 1, 2 * i) for i in range(8)]
+    results = [torch.full((CAP,), -1, dtype=torch.int32, device=cuda) for _ in pairs]
+    ws = nm.MatchBatchWorkspace(16, CAP, CAP, cuda)
+    nm.sift_match_batch([arenas[a].desc for a, _ in pairs], [arenas[b].desc for _, b in pairs],
+                        [cnt[a] for a, _ in pairs], [cnt[b] for _, b in pairs], results, 0.8, workspace=ws)
+    torch.cuda.synchronize()
+    ws1 = nm.MatchWorkspace(CAP, CAP, cuda)
+    for k, (a, b) in enumerate(pairs):
+        single, _ = nm.sift_match(arenas[a].desc, arenas[b].desc, 0.8, workspace=ws1, nA=cnt[a], nB=cnt[b])
+        assert torch.equal(single[:cnt[a]], results[k][:cnt[a]]), "pair %d: batched != single call" % k
+        assert bool((results[k][cnt[a]:] == -1).all())
+    for k in (0, 9):
+        a, b = pairs[k]
+        A = arenas[a].desc[:cnt[a]].cpu().numpy()
+        B = arenas[b].desc[:cnt[b]].cpu().numpy()
+        ref, Dref, (m1, ix, m2) = oracle.sift_matches(A, B, 0.8, want_distance=(k == 0))
+        assert np.array_equal(results[k][:cnt[a]].cpu().numpy(), ref), "pair %d vs oracle" % k
+        t = nm.sift_match_shard(arenas[a].desc[:cnt[a]], arenas[b].desc[:cnt[b]], 0, workspace=ws1)
+        _eq(t[0], m1, "min1 pair %d" % k)
+        assert np.array_equal(t[1].cpu().numpy(), ix)
+        _eq(t[2], m2, "min2 pair %d" % k)
+        if k == 0:
+            res, D = nm.sift_match(arenas[a].desc, arenas[b].desc, 0.8, want_distance=True, workspace=ws1,
+                                   nA=cnt[a], nB=cnt[b])
+            torch.cuda.synchronize()
+            assert np.array_equal(res[:cnt[a]].cpu().numpy(), ref)
+            _eq(D, Dref, "materialised 12k x 12k distance matrix")
+            del D
+    # the last call on ws1 was the shard call of pair 9: real SIFT descriptors rarely need the exact fallback
+    assert 0 <= nm.match_fallback_count(ws1, cnt[pairs[9][0]], cnt[pairs[9][1]]) < 200
