@@ -19,6 +19,12 @@
     } while (0)
 
 static inline int nm_divup(int a, int b) { return (a + b - 1) / b; }
+
+// Compute units / XCDs of the CURRENT device, read once per device from hipDeviceProp_t (a partitioned mode such as CPX
+// shows 32 CUs and one XCD per device). Without a device (host-only planning calls on a CPU box) the MI355X SPX values
+// 256 / 8 are assumed. XCDs are not a device property: 32 CUs per XCD on gfx950.
+int nm_cu_count();
+int nm_xcd_count();
 static inline hipStream_t nm_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 // ---- profiling hook (nm_profile_events / nm_profile_event_pairs) ----

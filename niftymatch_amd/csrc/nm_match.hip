@@ -46,7 +46,7 @@ static inline int plan_owner(const MatchPlan &p, long u)           // workgroup 
 static MatchPlan make_plan(int nA, int nB)
 {
     MatchPlan p;
-    const int n_cu = 256;
+    const int n_cu = nm_cu_count();          // one persistent workgroup per CU of the current device (256 on MI355X SPX)
     p.qblocks = nm_divup(nA > 0 ? nA : 1, QB);
     p.T = nm_divup(nB > 0 ? nB : 1, TILE_C);
     const long U = (long)p.qblocks * p.T;
@@ -87,6 +87,8 @@ struct MatchBatch {
 };
 static_assert(sizeof(MatchBatch) <= 4096, "kernel arguments are limited to 4 KB");
 
+__device__ __forceinline__ int nm_divup_dev(int a, int b) { return (a + b - 1) / b; }
+
 // ||x||^2 of every row of A (nA rows) and B (nB rows) of every pair in one launch.
 __global__ __launch_bounds__(256) void norms_kernel(MatchBatch bt)
 {
@@ -98,7 +100,13 @@ __global__ __launch_bounds__(256) void norms_kernel(MatchBatch bt)
     if (i == 0 && c.fb_count) *c.fb_count = 0;       // first launch of a match call: resets the fallback list (no memset node)
     const float *X = A;
     float *out = na;
-    if (i >= nA) { i -= nA; X = B; out = nb; if (i >= nB) return; }
+    if (i >= nA) {
+        i -= nA; X = B; out = nb;
+        if (i >= nB) {        // the MFMA kernel stages whole 128-candidate tiles: rows past the end get an infinite norm
+            if (i < nm_divup_dev(nB, TILE_C) * TILE_C) nb[i] = __builtin_inff();
+            return;
+        }
+    }
     const float4 *row = reinterpret_cast<const float4 *>(X + (size_t)i * DIM);
     float acc = 0.f;
 #pragma unroll 8
@@ -163,6 +171,74 @@ __device__ __forceinline__ void top2_insert(Top2 &t, float d, int j)
 // double-buffered LDS image (row pitch KP). Dynamic LDS: 2 * TILE_C * KP floats.
 // MFMA orientation: rows (accumulator registers) = candidates, columns (lanes) = queries, so every lane scans its own
 // query's candidates in increasing index order and the running best/second-best never crosses lanes in the loop.
+//
+// What the instruction stream is built around (measured on MI355X, profiles/r02_mfma_*_microbench.txt): the fp32 MFMA
+// shares the SIMD's vector datapath with the VALU -- every VALU instruction of either wave of a SIMD takes ~4-5 cycles
+// away from the MFMAs (a bare 32x32x2 loop runs 154 TFLOP/s at 2.39 GHz; 2 VALU per MFMA cut it to 121) -- and an LDS
+// operand read that is waited for right after its issue stalls the wave for the LDS latency every 4 MFMAs. So:
+//   * staging uses raw buffer loads (the SRD's range check zero-fills rows >= nB: no compares, no address arithmetic
+//     beyond one per-lane offset; the tile advances through the scalar offset) and the norms array is padded with +inf;
+//   * the candidate fragments of k-group t+1 are requested before the MFMAs of k-group t;
+//   * selection stays branch-free at 4 VALU instructions per value (Top3). A threshold test per value (one v_cmp +
+//     wave vote + scalar branch, inserting only values below the running third best) was measured SLOWER (315 vs 298 us):
+//     a segment restarts its triple every ~2 300 candidates, so ~30 % of the values still take the insertion and the 32
+//     branches per group cost more than they save; staggering the two waves of a SIMD by half a tile changed nothing.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// fold the 2 x 16 accumulator values of one 64-candidate group into the running triple (see Top3 above)
+__device__ __forceinline__ void select_half(const f32x16 &acc0, const f32x16 &acc1, Top3 &best, int tag)
+{
+    int g1 = KEY_INF, g2 = KEY_INF, g3 = KEY_INF;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) key_insert3(g1, g2, g3, (__float_as_int(acc0[e]) & ~((1 << KEY_SLOT_BITS) - 1)) | e);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) key_insert3(g1, g2, g3, (__float_as_int(acc1[e]) & ~((1 << KEY_SLOT_BITS) - 1)) | (16 + e));
+    if (__any(g1 < best.k3)) {
+        top3_merge(best, g1, tag);
+        top3_merge(best, g2, tag);
+        top3_merge(best, g3, tag);
+    }
+}
+
+// 2 x (32 candidates x 32 queries x 128 + 1 k-pairs): acc[g] = |b_j|^2 + |a_i|^2 - 2 a_i.b_j for candidates
+// 64 half + 32 g + (row of the accumulator layout). rowp = this lane's candidate row of group 0 at its k offset 4 h.
+// The MFMAs are hand-placed (inline asm): the two accumulator chains alternate, and the "memory" clobbers keep the
+// fragment reads of k-group t+1 (ordinary loads, counted and waited for by the compiler at their first use) above the
+// MFMAs of k-group t. hipcc's own schedule of the equivalent builtins waits for every read right after issuing it and
+// runs the chains one after the other.
+#define NM_MFMA "v_mfma_f32_32x32x2_f32 "
+__device__ __forceinline__ void mfma_half(f32x16 &acc0, f32x16 &acc1, const float *rowp, const float *normp,
+                                          const float4 (&qf)[16], float nq)
+{
+    const float *r0 = rowp, *r1 = rowp + 32 * KP;
+    float4 c0 = *reinterpret_cast<const float4 *>(r0), c1 = *reinterpret_cast<const float4 *>(r1);
+    const float cn0 = normp[0], cn1 = normp[32 * KP];  // column 128 + h: (nb_j, 1) for h = (0, 1)
+    // augmented k-pair: (nb_j * 1) + (1 * na_i), accumulators start from the inline constant 0
+    asm volatile(NM_MFMA "%0, %2, %4, 0\n\t" NM_MFMA "%1, %3, %4, 0"
+                 : "=&v"(acc0), "=&v"(acc1) : "v"(cn0), "v"(cn1), "v"(nq) : "memory");
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        float4 n0 = c0, n1 = c1;
+        if (t + 1 < 16) {                               // next k-group's fragments fly during this group's 8 MFMAs
+            n0 = *reinterpret_cast<const float4 *>(r0 + 8 * (t + 1));
+            n1 = *reinterpret_cast<const float4 *>(r1 + 8 * (t + 1));
+        }
+        asm volatile(NM_MFMA "%0, %2, %10, %0\n\t" NM_MFMA "%1, %6, %10, %1\n\t"
+                     NM_MFMA "%0, %3, %11, %0\n\t" NM_MFMA "%1, %7, %11, %1\n\t"
+                     NM_MFMA "%0, %4, %12, %0\n\t" NM_MFMA "%1, %8, %12, %1\n\t"
+                     NM_MFMA "%0, %5, %13, %0\n\t" NM_MFMA "%1, %9, %13, %1"
+                     : "+v"(acc0), "+v"(acc1)
+                     : "v"(c0.x), "v"(c0.y), "v"(c0.z), "v"(c0.w), "v"(c1.x), "v"(c1.y), "v"(c1.z), "v"(c1.w),
+                       "v"(qf[t].x), "v"(qf[t].y), "v"(qf[t].z), "v"(qf[t].w)
+                     : "memory");
+        c0 = n0; c1 = n1;
+    }
+    // an MFMA's result may be read by a non-MFMA instruction only 18 wait states after its issue (16-pass XDL op):
+    // the compiler does not see inside the asm statements, so the padding is explicit
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc0), "+v"(acc1));
+}
+#undef NM_MFMA
+
 __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restrict__ A, int nA,
                                                            const float *__restrict__ B, int nB,
                                                            const float *__restrict__ na, const float *__restrict__ nb,
@@ -178,25 +254,23 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
     long u = (long)wg * plan.base + min(wg, plan.rem);
     const long u_end = u + plan.base + (wg < plan.rem ? 1 : 0);
 
-    float4 st[8];
+    // range-checked views: rows >= nB / nA read as zeros (the host refuses sets of 2^22 rows or more)
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, nB * (DIM * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, nA * (DIM * 4), 0x00020000);
+    const int voff = (srow * DIM + scol) * 4;
+
+    u32x4 st[8];
     float stn = 0.f;
     auto stage_load = [&](int tile) {                     // candidates tile*128 .. +127 -> registers
         const int jb = tile * TILE_C;
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int j = jb + srow + 16 * it;
-            st[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < nB) st[it] = *reinterpret_cast<const float4 *>(B + (size_t)j * DIM + scol);
-        }
-        if (tid < TILE_C) stn = (jb + tid < nB) ? nb[jb + tid] : __builtin_inff();
+        for (int it = 0; it < 8; ++it) st[it] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voff, (jb + 16 * it) * (DIM * 4), 0);
+        if (tid < TILE_C) stn = nb[jb + tid];             // padded with +inf up to T * 128 by norms_kernel
     };
     auto stage_write = [&](float *buf) {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = srow + 16 * it;
-            *reinterpret_cast<float4 *>(&buf[row * KP + scol]) = st[it];
-        }
-        if (tid < TILE_C) buf[tid * KP + DIM] = stn;
+        for (int it = 0; it < 8; ++it) *reinterpret_cast<u32x4 *>(&buf[(srow + 16 * it) * KP + scol]) = st[it];
+        if (tid < TILE_C) *reinterpret_cast<float2 *>(&buf[tid * KP + DIM]) = make_float2(stn, 1.0f);   // augmented k-pair
     };
 
     while (u < u_end) {
@@ -210,10 +284,8 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
         stage_load(t0);
 #pragma unroll 4
         for (int it = 0; it < QB / 16; ++it) {
-            const int row = srow + 16 * it;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i0 + row < nA) v = *reinterpret_cast<const float4 *>(A + (size_t)(i0 + row) * DIM + scol);
-            *reinterpret_cast<float4 *>(&lds[row * KP + scol]) = v;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff, (i0 + 16 * it) * (DIM * 4), 0);
+            *reinterpret_cast<u32x4 *>(&lds[(srow + 16 * it) * KP + scol]) = v;
         }
         __syncthreads();
         float4 qf[16];
@@ -234,50 +306,15 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
 
         // A wave multiplies its 32 queries with 64 candidates at a time (two 32 x 32 accumulators), then folds the 32
         // values each lane holds into its running triple. Within a lane the candidate index increases with (tile, half, g, e).
-        f32x16 acc[2];
+        f32x16 a0, a1;
         for (int n = 0; n < ntiles; ++n) {
-            float *buf = lds + (n & 1) * (TILE_C * KP);
+            const float *buf = lds + (n & 1) * (TILE_C * KP);
+            const float *rowp = buf + r * KP + 4 * h, *normp = buf + r * KP + DIM + h;
             if (n + 1 < ntiles) stage_load(t0 + n + 1);
-#pragma unroll 1
-            for (int half = 0; half < 2; ++half) {
-                const float *rowp[2];
-#pragma unroll
-                for (int g = 0; g < 2; ++g) rowp[g] = buf + (half * 64 + 32 * g + r) * KP;
-                // augmented k-pair: (nb_j * 1) + (1 * na_i), accumulators start from the inline constant 0
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
-                    const float nbv = rowp[g][DIM];
-                    const float cn = (h == 0) ? nbv : 1.0f;
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(cn, nq, acc[g], 0, 0, 0);
-                }
-#pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    float4 cf[2];
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) cf[g] = *reinterpret_cast<const float4 *>(rowp[g] + 8 * t + 4 * h);
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[g].x, qf[t].x, acc[g], 0, 0, 0);
-                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[g].y, qf[t].y, acc[g], 0, 0, 0);
-                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[g].z, qf[t].z, acc[g], 0, 0, 0);
-                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[g].w, qf[t].w, acc[g], 0, 0, 0);
-                    }
-                }
-                int g1 = KEY_INF, g2 = KEY_INF, g3 = KEY_INF;
-#pragma unroll
-                for (int g = 0; g < 2; ++g)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        key_insert3(g1, g2, g3, (__float_as_int(acc[g][e]) & ~((1 << KEY_SLOT_BITS) - 1)) | (g * 16 + e));
-                if (__any(g1 < best.k3)) {
-                    const int tag = 2 * n + half;
-                    top3_merge(best, g1, tag);
-                    top3_merge(best, g2, tag);
-                    top3_merge(best, g3, tag);
-                }
-            }
+            mfma_half(a0, a1, rowp, normp, qf, nq);
+            select_half(a0, a1, best, 2 * n);
+            mfma_half(a0, a1, rowp + 64 * KP, normp + 64 * KP, qf, nq);
+            select_half(a0, a1, best, 2 * n + 1);
             if (n + 1 < ntiles) stage_write(lds + ((n + 1) & 1) * (TILE_C * KP));
             __syncthreads();
         }
@@ -423,16 +460,24 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(MatchBatch bt)
         else if (ed[k] < m2) m2 = ed[k];
     }
     if (!have) return;
-    // Error of the MFMA formulation: 129 roundings of partial sums of magnitude <= na + nb, i.e. a random walk with
-    // sigma ~ sqrt(129/12) * 2^-23 * 0.7 (na + nb) = 2.7e-7 (na + nb); nb <= (sqrt(na) + sqrt(d))^2 <= 2 na + 2 d for any
-    // candidate at distance d. margin = 2.4e-6 (3 na + 2 d) is ~9 sigma (the all-aligned worst case is 3x larger still
-    // and has probability < 2^-129). A candidate within the margin of min2 (or a tie of min1 hiding among them) sends
-    // the query to the exact fallback.
+    // Proof obligation ("matcher theorem"): every candidate j that was NOT recomputed must have a
+    // reference distance d_ref(j) > m2. With u = 2^-24, gamma_n = n u / (1 - n u):
+    //   * the MFMA value is a 130-step fma chain nb^ + na^ - 2 sum a_k b_k with 129 roundings, products exact:
+    //     |d~ - (na^ + nb^ - 2 a.b)| <= gamma_129 (na^ + nb^ + 2 sum |a_k b_k|) <= gamma_129 (sqrt na + sqrt nb)^2 (1 + gamma_128)
+    //   * the norms are 128-step fma chains of squares: |na^ - na| <= gamma_128 na, the same for nb
+    //     => |d~(j) - d(j)| <= 2 gamma_129 (sqrt na + sqrt nb_j)^2 =: E_j
+    //   * the reference chain sum fma(t,t,acc), t = fl(a_k - b_k), gives d_ref >= d (1 - gamma_130)
+    //   * a key reports d~ with its low 5 mantissa bits replaced: |value - d~| < 2^-18 |d~|
+    // Suppose d_ref(j) <= m2. Then d(j) <= M := m2 (1 + gamma_131), sqrt nb_j <= sqrt na + sqrt M, so
+    // value(j) <= (M + 2 gamma_129 (2 sqrt na + sqrt M)^2) (1 + 2^-18) =: bound, and rest <= value(j) <= bound.
+    // Hence rest > bound proves the row; otherwise the row is re-scanned exactly. Deterministic for every input
+    // (2 gamma_129 = 1.5378e-5; the constants below carry the slop of evaluating the bound itself in fp32).
     const float nai = na[i];
-    // The selection keys drop 5 mantissa bits: a reported value undershoots its distance by < 2^-18 relative (3.9e-6).
-    float margin = 2.4e-6f * (3.0f * nai + 2.0f * __builtin_fminf(m2, 4.0f * nai + 4.0f * m1));
-    margin += 4.0e-6f * (m2 + margin);
-    if (rest <= m2 + margin && rest < __builtin_inff()) {
+    const float sq = 2.0f * __builtin_sqrtf(nai) + __builtin_sqrtf(m2);
+    const float bound = (m2 * 1.00001f + 1.56e-5f * (sq * sq)) * 1.00001f;      // 1 + 2^-17 = 1.0000076
+    const float margin = bound - m2;
+    (void)margin;
+    if (rest <= bound && rest < __builtin_inff()) {
         const int pos = atomicAdd(fb_count, 1);
         fb_list[pos] = i;
         return;
@@ -676,7 +721,7 @@ static MatchWs carve(void *workspace, int nA, int nB, const MatchPlan &p)
     MatchWs w;
     char *base = static_cast<char *>(workspace);
     w.na = reinterpret_cast<float *>(base); base += align256((size_t)nA * 4);
-    w.nb = reinterpret_cast<float *>(base); base += align256((size_t)nB * 4);
+    w.nb = reinterpret_cast<float *>(base); base += align256(((size_t)nB + TILE_C) * 4);      // + the +inf padding of a tile
     w.fb_count = reinterpret_cast<int *>(base); base += 256;
     w.fb_list = reinterpret_cast<int *>(base); base += align256((size_t)nA * 4);
     // partial / partial3 are dead once match_finalize_kernel has run: the fallback reuses the space from `partial` on
@@ -690,7 +735,7 @@ static size_t pair_workspace_bytes(int nA, int nB)
 {
     if (nA < 0) nA = 0;
     if (nB < 0) nB = 0;
-    return align256((size_t)nA * 4) + align256((size_t)nB * 4) + align256((size_t)nA * MAX_CHUNKS * sizeof(float4)) +
+    return align256((size_t)nA * 4) + align256(((size_t)nB + TILE_C) * 4) + align256((size_t)nA * MAX_CHUNKS * sizeof(float4)) +
            align256((size_t)nA * MAX_CHUNKS * sizeof(float)) + 256 + align256((size_t)nA * 4) + 256;
 }
 
@@ -722,7 +767,8 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
         c.A = j.A; c.B = j.B; c.nA = j.nA; c.nB = j.nB; c.na = w.na; c.nb = w.nb; c.partial = w.partial;
         c.partial3 = w.partial3; c.fb_count = w.fb_count; c.fb_list = w.fb_list; c.S = plans[q].S; c.mode = j.mode;
         c.index_offset = j.index_offset; c.result = j.result; c.min1 = j.min1; c.min2 = j.min2; c.idx1 = j.idx1;
-        max_rows = max(max_rows, j.nA + j.nB);
+        if (j.nA >= (1 << 22) || j.nB >= (1 << 22)) return (int)hipErrorInvalidValue;   // 32-bit byte ranges of the SRDs
+        max_rows = max(max_rows, j.nA + nm_divup(j.nB, TILE_C) * TILE_C);
         max_a = max(max_a, j.nA);
     }
     if (bt.n == 0) return 0;

@@ -8,6 +8,28 @@
 
 using nmfp::fma32;
 
+int nm_cu_count()
+{
+    static int cache[64];                       // 0 = not read yet; benign race: every thread computes the same value
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 256; }
+    if (cache[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+            (void)hipGetLastError();
+            n = 256;
+        }
+        cache[dev] = n;
+    }
+    return cache[dev];
+}
+
+int nm_xcd_count()
+{
+    const int x = nm_cu_count() / 32;
+    return x < 1 ? 1 : (x > 8 ? 8 : x);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Fused separable Gaussian. A workgroup (256 threads = 4 waves) walks over 64 x TH output tiles:
 //   fetch    global -> VGPRs: the (TH+2R) x (64+2RA) input tile of the NEXT tile is requested (float4, all loads in
@@ -24,7 +46,7 @@ template <int R, int TH, bool WRITE_BUF, bool WRITE_DOG, bool WRITE_GRAD, bool V
 __global__ __launch_bounds__(TH * 8) void conv_sep_kernel(float *__restrict__ result, const float *__restrict__ image,
                                                       float *__restrict__ buffer, float *__restrict__ dog,
                                                       float2 *__restrict__ grad, int width, int height,
-                                                      const float *__restrict__ taps, int tiles_x, int ntiles)
+                                                      const float *__restrict__ taps, int tiles_x, int ntiles, int nxcd)
 {
     constexpr int TW = 64;
     constexpr int RA = (R + 3) & ~3;              // halo rounded up to 4 columns: 16-byte aligned row segments
@@ -46,8 +68,7 @@ __global__ __launch_bounds__(TH * 8) void conv_sep_kernel(float *__restrict__ re
     for (int i = 0; i < NT; ++i) w[i] = taps[i];
 
     // tile schedule: XCD-contiguous bands
-    const int nxcd = 8;
-    const int xcd = blockIdx.x % nxcd, slot = blockIdx.x / nxcd, per_xcd = gridDim.x / nxcd;   // gridDim.x % 8 == 0
+    const int xcd = blockIdx.x % nxcd, slot = blockIdx.x / nxcd, per_xcd = gridDim.x / nxcd;   // gridDim.x % nxcd == 0
     const int band = (ntiles + nxcd - 1) / nxcd;
     const int t_begin = xcd * band, t_end = min(t_begin + band, ntiles);
 
@@ -302,7 +323,7 @@ __device__ __forceinline__ bool grad_pair(v2f xm, v2f xp, v2f ym, v2f yp, v2f &g
 template <int R, bool WRITE_DOG, bool WRITE_GRAD>
 __global__ __launch_bounds__(256) void conv_pk_kernel(NmConvBatch batch, int width, int height,
                                                      const float *__restrict__ taps, int tiles_x, int ntiles,
-                                                     int blocks_per_frame)
+                                                     int blocks_per_frame, int nxcd)
 {
     constexpr int TW = 64, TH = 32;
     constexpr int RA = (R + 3) & ~3;
@@ -322,8 +343,7 @@ __global__ __launch_bounds__(256) void conv_pk_kernel(NmConvBatch batch, int wid
     __shared__ __attribute__((aligned(16))) float s_mid[ROWS * MID_P];
 
     const int tid = threadIdx.x;
-    const int nxcd = 8;
-    const int frame = blockIdx.x / blocks_per_frame;              // blocks_per_frame % 8 == 0: blockIdx % 8 is the XCD
+    const int frame = blockIdx.x / blocks_per_frame;              // blocks_per_frame % nxcd == 0: blockIdx % nxcd is the XCD
     const int blk = blockIdx.x - frame * blocks_per_frame;
     const int xcd = blk % nxcd, slot = blk / nxcd;
     const int band = (ntiles + nxcd - 1) / nxcd;
@@ -535,12 +555,13 @@ static int launch_conv_rvt(float *result, const float *image, float *buffer, flo
     const int ntiles = tiles_x * tiles_y;
     // one tile per workgroup up to the chip's residency; grid is a multiple of 8 (XCDs). (Measured on MI355X: more
     // tiles per workgroup with register prefetch is slower than more resident workgroups.)
-    const int blocks = ((ntiles + 7) / 8) * 8;
+    const int nxcd = nm_xcd_count();
+    const int blocks = nm_divup(ntiles, nxcd) * nxcd;
     dim3 grid(blocks);
     float2 *g2 = reinterpret_cast<float2 *>(grad);
 #define NM_CONV_LAUNCH(BUF, DOG, GRAD)                                                                              \
     hipLaunchKernelGGL((conv_sep_kernel<R, TH, BUF, DOG, GRAD, VEC>), grid, dim3(TH * 8), 0, stream, result, image, \
-                       buffer, dog, g2, width, height, taps, tiles_x, ntiles)
+                       buffer, dog, g2, width, height, taps, tiles_x, ntiles, nxcd)
     if (buffer) {
         if (dog || grad || TH != 32) return (int)hipErrorInvalidValue;   // the API path never asks for the fused outputs
         if (TH == 32) NM_CONV_LAUNCH(true, false, false);
@@ -563,12 +584,13 @@ static int launch_conv_pk(const NmConvBatch &b, int width, int height, const flo
 {
     const int tiles_x = nm_divup(width, 64), tiles_y = nm_divup(height, 32);
     const int ntiles = tiles_x * tiles_y;
-    const int bpf = ((ntiles + 7) / 8) * 8;
+    const int nxcd = nm_xcd_count();
+    const int bpf = nm_divup(ntiles, nxcd) * nxcd;
     dim3 grid(bpf * b.n);
     const bool dog = b.dog[0] != nullptr, grad = b.grad[0] != nullptr;
 #define NM_PK_LAUNCH(DOG, GRAD)                                                                                     \
     hipLaunchKernelGGL((conv_pk_kernel<R, DOG, GRAD>), grid, dim3(256), 0, stream, b, width, height, taps, tiles_x, \
-                       ntiles, bpf)
+                       ntiles, bpf, nxcd)
     if (dog && grad) NM_PK_LAUNCH(true, true);
     else if (dog) NM_PK_LAUNCH(true, false);
     else NM_PK_LAUNCH(false, false);

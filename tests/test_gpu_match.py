@@ -252,3 +252,68 @@ def test_match_batch_equals_single_matches(nm, oracle, cuda):
     many = [tA[0]] * (nm.MATCH_MAX_BATCH + 1)
     with pytest.raises(nm.NmError):
         nm.sift_match_batch(many, many, [1] * len(many), [1] * len(many), [results[0]] * len(many))
+
+
+def test_match_adversarial_rounding(nm, oracle, cuda):
+    """Inputs built to drive the MFMA formulation |a|^2 + |b|^2 - 2 a.b to its worst-case rounding behaviour, where a
+    probabilistic error margin is not enough (matcher theorem): products that all round the same
+    way, massive cancellation, near-ties closer than the formulation can resolve. Whatever route a row takes (MFMA
+    candidates proven by the bound, or the exact fallback), (min1, index, min2) must equal the oracle's bit for bit."""
+    import torch
+    rng = np.random.default_rng(77)
+    ulp = np.float32(2.0 ** -23)
+    cases = {}
+    # 1. constant vectors: every one of the 128 products of a row pair is the same number and rounds the same way
+    ca = (1.0 + rng.integers(0, 4096, 600) * 2.0 ** -12).astype(np.float32)
+    cb = (1.0 + rng.integers(0, 4096, 900) * 2.0 ** -12).astype(np.float32)
+    cases["constant vectors"] = (np.repeat(ca[:, None], 128, 1), np.repeat(cb[:, None], 128, 1))
+    # 2. powers of two plus one ulp: the exact products end in ...01 x ...01 patterns that never round to even
+    ea = rng.integers(-3, 4, (500, 128)); eb = rng.integers(-3, 4, (700, 128))
+    cases["2^e (1 + ulp)"] = ((2.0 ** ea * (1.0 + ulp)).astype(np.float32), (2.0 ** eb * (1.0 + 3 * ulp)).astype(np.float32))
+    # 3. cancellation: norms ~1.3e8, distances ~1e-2 .. 1e2 -- the formulation's absolute error exceeds every distance
+    base = np.full((1, 128), 1000.0, np.float32)
+    cases["large offset, tiny distances"] = ((base + rng.standard_normal((400, 128)) * 0.05).astype(np.float32),
+                                             (base + rng.standard_normal((1100, 128)) * 0.05).astype(np.float32))
+    # 4. ties everywhere: all candidates identical, and a block of exact copies of the queries
+    A4 = H.synth.descriptors(5, 300); B4 = np.repeat(H.synth.descriptors(6, 1), 513, 0)
+    cases["all candidates equal"] = (A4, B4)
+    B5 = np.concatenate([A4[::-1], A4[::-1], H.synth.descriptors(9, 200)])       # every query twice in B: min2 == 0
+    cases["duplicated exact copies"] = (A4, B5)
+    # 5. one-ulp ladders: candidate j differs from the query in one coordinate by j ulps -> distances 0, tiny, tiny, ...
+    A6 = (H.synth.descriptors(7, 64) * 255).astype(np.float32)
+    B6 = np.repeat(A6, 9, 0)
+    for j in range(B6.shape[0]):
+        B6[j, (5 * j) % 128] = np.nextafter(B6[j, (5 * j) % 128], np.float32(1e9), dtype=np.float32) if j % 9 else B6[j, (5 * j) % 128]
+        for _ in range(j % 9 - 1 if j % 9 > 1 else 0):
+            B6[j, (5 * j) % 128] = np.nextafter(B6[j, (5 * j) % 128], np.float32(1e9), dtype=np.float32)
+    cases["one-ulp ladders"] = (A6, B6)
+    for name, (A, B) in cases.items():
+        A = np.ascontiguousarray(A, np.float32); B = np.ascontiguousarray(B, np.float32)
+        prior = np.full(len(A), -7, np.int32)
+        ref, _, (m1r, ixr, m2r) = oracle.sift_matches(A, B, 0.8, want_distance=False, prior=prior)
+        got, _ = _match(nm, cuda, A, B, prior=prior)
+        assert np.array_equal(got, ref), name
+        ws = nm.MatchWorkspace(len(A), len(B), cuda)
+        m1, ix, m2 = nm.sift_match_shard(_t(A, cuda), _t(B, cuda), 0, workspace=ws)
+        torch.cuda.synchronize()
+        assert np.array_equal(ix.cpu().numpy(), ixr), name
+        assert np.array_equal(m1.cpu().numpy().view(np.uint32), m1r.view(np.uint32)), name
+        assert np.array_equal(m2.cpu().numpy().view(np.uint32), m2r.view(np.uint32)), name
+        if name == "large offset, tiny distances":        # the bound must refuse to trust the MFMA pass here
+            assert nm.match_fallback_count(ws, len(A), len(B)) == len(A)
+
+
+def test_shard_with_empty_candidate_shard(nm, oracle, cuda):
+    """world > nB or uneven tiny sets: a rank's shard can be empty. Its triple must be neutral for the merge."""
+    import torch
+    A = H.synth.descriptors(1, 50)
+    B = H.synth.descriptors(2, 3)
+    ref, _, _ = oracle.sift_matches(A, B, 0.8, want_distance=False)
+    m1s, ixs, m2s = [], [], []
+    for b, e in [(0, 0), (0, 2), (2, 2), (2, 3)]:                       # shards 0 and 2 are empty
+        Bs = B[b:e] if e > b else np.zeros((1, 128), np.float32)
+        t = nm.sift_match_shard(_t(A, cuda), _t(Bs, cuda)[: e - b], b)
+        m1s.append(t[0]); ixs.append(t[1]); m2s.append(t[2])
+    res = nm.sift_match_merge(torch.stack(m1s), torch.stack(ixs), torch.stack(m2s), 0.8)
+    torch.cuda.synchronize()
+    assert np.array_equal(res.cpu().numpy(), ref)
