@@ -83,6 +83,13 @@ NM_API int nm_subtract_f32(const float *A, const float *B, float *C, int width, 
  * Deviation: the 1-pixel border, which the reference never writes, is written as (0,0).            */
 NM_API int nm_gradient_f32(const float *source, float *result, int width, int height, void *stream);
 
+/* The loops of compute_dog (sift/siftfunctions.cu:42-51) and compute_gradients (:53-63) as ONE launch each: arrays of n
+ * device plane pointers (host arrays), n <= 8 / n <= 3. Same arithmetic as nm_subtract_f32 / nm_gradient_f32. */
+NM_API int nm_subtract_batch_f32(int n, const float *const *A, const float *const *B, float *const *C, int width,
+                                 int height, void *stream);
+NM_API int nm_gradient_batch_f32(int n, const float *const *source, float *const *result, int width, int height,
+                                 void *stream);
+
 /* ---- keypoints ---- */
 /* find_keypoints, unmasked overload (kernels/keypoint.h:25-32, keypoint.cu:240-251). current/down/up are DoG
  * planes (were cudaTextureObject_t). `result` is the dense width*height float4 map, pre-filled with -1 by the
@@ -104,6 +111,18 @@ NM_API size_t nm_compact_workspace_bytes(int num_pixels);
 NM_API int nm_compact_keypoints(const float *dense, int num_pixels, float *out, int *d_count, void *workspace,
                                 void *stream);
 
+/* The three find_keypoints calls of compute_keypoints[_with_mask] (sift/siftfunctions.cu:65-134) in ONE launch: dog[0..4]
+ * are the octave's DoG planes, level l searches dog[l+1] between dog[l] and dog[l+2]; mask may be NULL. EVERY pixel of
+ * the first width*height float4 of result[0..2] is written (the accepted keypoint or (-1,-1,-1,-1)), so only the part
+ * of a map beyond width*height needs the reference's reset (siftfunctions.cu:120-121).                            */
+NM_API int nm_find_keypoints3_f32(const float *const dog[5], const float *mask, int mask_width, int mask_height,
+                                  int width, int height, float peak_threshold, float edge_threshold, float xper,
+                                  float sigma_0, int num_dogs, float *const result[3], void *stream);
+/* nm_compact_keypoints for three dense maps at once (three launches instead of nine); d_counts: 3 device ints. */
+NM_API size_t nm_compact3_workspace_bytes(int num_pixels);
+NM_API int nm_compact_keypoints3(const float *const dense[3], int num_pixels, float *const out[3], int *d_counts,
+                                 void *workspace, void *stream);
+
 /* ---- orientation + descriptor ---- */
 /* detect_orientations (kernels/orientation.h:19-24, orientation.cu:219-230). `result` float2 per keypoint,
  * pre-filled with (-1,-1) by the caller (pyramidata.cu:90).                                                     */
@@ -113,6 +132,17 @@ NM_API int nm_detect_orientations(const float *key_pts, const float *grad, int n
 NM_API int nm_compute_sift_descriptors(const float *key_pts, const float *orients, const float *grad, int num_pts,
                                        int octave_width, int octave_height, int num_dogs, float xper, float *desc,
                                        float *x, float *y, void *stream);
+
+/* detect_orientations / compute_sift_descriptors for the (up to three) level lists of one octave in ONE launch each: the
+ * loops of compute_orientations / compute_descriptors (sift/siftfunctions.cu:136-181). Host arrays of n_levels device
+ * pointers and counts. nm_detect_orientations_levels writes both components of every result (unset = -1): no pre-fill. */
+NM_API int nm_detect_orientations_levels(int n_levels, const float *const *key_pts, const int *num_pts, const float *grad,
+                                         int octave_width, int octave_height, float gauss_factor, float xper,
+                                         float *const *result, void *stream);
+NM_API int nm_compute_sift_descriptors_levels(int n_levels, const float *const *key_pts, const float *const *orients,
+                                              const int *num_pts, const float *grad, int octave_width, int octave_height,
+                                              int num_dogs, float xper, float *const *desc, float *const *x,
+                                              float *const *y, void *stream);
 
 /* ---- matcher ---- */
 /* transpose<float> (kernels/transpose.h:16-21, transpose.cu:33-40): odata[x*height+y] = idata[y*width+x]. */
@@ -243,6 +273,11 @@ NM_API int nm_sift_detect_describe(nm_sift_arena *arena, const float *gray, floa
 NM_API int nm_sift_detect_describe_batch(nm_sift_arena *const *arenas, int n, const float *const *gray,
                                          float *const *desc, float *const *x, float *const *y, float *const *kpts,
                                          float *const *orients, int *const *d_num_items, void *stream);
+/* Measurement aid: only the scale-space launches of nm_sift_detect_describe_batch (base blur + every octave's Gaussian
+ * levels, DoG planes, gradient planes and decimation), on `stream`, no detection. The planes it leaves in the arenas
+ * are those of the last octave. bench.py times this sequence for the whole-pyramid roofline (SURVEY.md 8(d):
+ * 108 B per octave-pixel + 36 B for the gradients).                                                              */
+NM_API int nm_sift_scale_space_batch(nm_sift_arena *const *arenas, int n, const float *const *gray, void *stream);
 /* Pointers into the arena for stage-level inspection (tests, profiling): Gaussian level l (0..5) and DoG d (0..4)
  * planes of the LAST processed octave geometry are overwritten per octave, so these are meaningful only after
  * nm_sift_octave_pyramid().                                                                                      */

@@ -13,6 +13,13 @@ extern "C" {
  * negative value on a C++ exception. */
 __attribute__((visibility("default"))) int nm_client_detect_describe(const float *gray, int width, int height,
                                                                     int capacity, float *desc, float *x, float *y);
+/* Wall-clock microseconds per frame pair of the reference-style client loop (2 x detect+describe with the per-octave
+ * API + compute_sift_matches), `reps` pairs after one warm-up, objects created once. gray0/gray1: DEVICE planes.
+ * with_distance: pass the reference's mandatory N x M distance buffer (1) or NULL (0, extension). n_out (3 ints, host,
+ * may be NULL): keypoints of frame 0, of frame 1, matches found. Negative on error. */
+__attribute__((visibility("default"))) double nm_client_pair_loop(const float *gray0, const float *gray1, int width,
+                                                                 int height, int capacity, int reps, int with_distance,
+                                                                 int *n_out);
 /* A: nA*128, B: nB*128 (host). distance: nA*nB (host) or NULL. result: nA ints, pre-filled by the caller. */
 __attribute__((visibility("default"))) int nm_client_match(const float *A, int nA, const float *B, int nB,
                                                           float *distance, int *result, float ambiguity);

@@ -30,6 +30,13 @@ _SIGNATURES = {
     "nm_gradient_f32": (_I, [_P, _P, _I, _I, _P]),
     "nm_find_keypoints_f32": (_I, [_P, _P, _P, _I, _I, _F, _F, _F, _F, _I, _I, _P, _P]),
     "nm_find_keypoints_masked_f32": (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _F, _F, _F, _F, _I, _I, _P, _P]),
+    "nm_subtract_batch_f32": (_I, [_I, _P, _P, _P, _I, _I, _P]),
+    "nm_gradient_batch_f32": (_I, [_I, _P, _P, _I, _I, _P]),
+    "nm_find_keypoints3_f32": (_I, [_P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _I, _P, _P]),
+    "nm_compact3_workspace_bytes": (_SZ, [_I]),
+    "nm_compact_keypoints3": (_I, [_P, _I, _P, _P, _P, _P]),
+    "nm_detect_orientations_levels": (_I, [_I, _P, _P, _P, _I, _I, _F, _F, _P, _P]),
+    "nm_compute_sift_descriptors_levels": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P]),
     "nm_compact_workspace_bytes": (_SZ, [_I]),
     "nm_compact_keypoints": (_I, [_P, _I, _P, _P, _P, _P]),
     "nm_detect_orientations": (_I, [_P, _P, _I, _I, _I, _F, _F, _P, _P]),
@@ -66,10 +73,12 @@ _SIGNATURES = {
     "nm_sift_arena_bytes": (_SZ, [_P]),
     "nm_sift_detect_describe": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nm_sift_detect_describe_batch": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "nm_sift_scale_space_batch": (_I, [_P, _I, _P, _P]),
     "nm_sift_arena_level": (_P, [_P, _I]), "nm_sift_arena_dog": (_P, [_P, _I]), "nm_sift_arena_grad": (_P, [_P]),
     "nm_sift_octave_pyramid": (_I, [_P, _I, _I, _P]),
     "nm_client_detect_describe": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "nm_client_match": (_I, [_P, _I, _P, _I, _P, _P, _F]),
+    "nm_client_pair_loop": (C.c_double, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "nm_client_ransac": (_I, [_I, _P, _P, _P, _P, _I, _F, _I, C.c_uint, _P]),
 }
 
@@ -525,6 +534,17 @@ def detect_describe_batch(arenas, grays):
         arr([_dev(a.desc) for a in arenas]), arr([_dev(a.x) for a in arenas]), arr([_dev(a.y) for a in arenas]),
         arr([_dev(a.kpts) for a in arenas]), arr([_dev(a.orients) for a in arenas]),
         arr([_dev(a.num_items) for a in arenas]), _stream()), "nm_sift_detect_describe_batch")
+
+
+def scale_space_batch(arenas, grays):
+    """Only the scale-space launches of detect_describe_batch (nm_sift_scale_space_batch), on the current stream."""
+    torch = _torch()
+    n = len(arenas)
+    if n != len(grays) or not 0 < n <= SIFT_MAX_BATCH:
+        raise NmError("batch of %d arenas / %d frames (max %d)" % (n, len(grays), SIFT_MAX_BATCH))
+    _check(lib().nm_sift_scale_space_batch((C.c_void_p * n)(*[a._h.value for a in arenas]), n,
+                                           (C.c_void_p * n)(*[_dev(g, torch.float32) for g in grays]), _stream()),
+           "nm_sift_scale_space_batch")
 
 
 class SiftArena:

@@ -266,6 +266,39 @@ __global__ __launch_bounds__(64) void descriptors_kernel(const float4 *__restric
                       yp + pt, part);
 }
 
+// ---- API kernels, up to 3 level lists of one octave per launch (compute_orientations / compute_descriptors) ----
+struct NmLevelLists {
+    const float4 *key_pts[3];
+    float2 *orients[3];
+    float *desc[3], *x[3], *y[3];
+    int num_pts[3];
+    int n_levels;
+};
+
+__global__ __launch_bounds__(256) void orientations_levels_kernel(NmLevelLists a, const float2 *__restrict__ grad, int ow,
+                                                                 int oh, float gauss_factor, float xper)
+{
+    __shared__ float s_part[4][ORI_LDS];
+    const int wave = threadIdx.x >> 6, l = blockIdx.y;
+    const int n = a.num_pts[l];
+    for (int pt = blockIdx.x * 4 + wave; pt < n; pt += gridDim.x * 4) {
+        float th0, th1;                           // unset components are -1, as the pre-fill of pyramidata.cu:90 leaves them
+        orient_wave(a.key_pts[l][pt], grad, ow, oh, gauss_factor, xper, th0, th1, s_part[wave]);
+        if ((threadIdx.x & 63) == 0) a.orients[l][pt] = make_float2(th0, th1);
+    }
+}
+
+__global__ __launch_bounds__(64) void descriptors_levels_kernel(NmLevelLists a, const float2 *__restrict__ grad, int ow,
+                                                               int oh, int num_dogs, float xper)
+{
+    __shared__ __attribute__((aligned(16))) float part[DESC_LDS];
+    const int l = blockIdx.y;
+    const int n = a.num_pts[l];
+    for (int pt = blockIdx.x; pt < n; pt += gridDim.x)
+        describe_wave(a.key_pts[l][pt], a.orients[l][pt].x, grad, ow, oh, num_dogs, xper, a.desc[l] + (size_t)pt * 128,
+                      a.x[l] + pt, a.y[l] + pt, part);
+}
+
 // ---- frame-driver kernels: all octaves of a frame in one launch, counts read from the device-side book ----
 __device__ __forceinline__ int octave_of(const NmFrameBook *book, int num_octaves, int i)
 {
@@ -330,6 +363,56 @@ int nm_detect_orientations(const float *key_pts, const float *grad, int num_pts,
     hipLaunchKernelGGL(orientations_kernel, dim3(blocks), dim3(256), 0, nm_stream(stream),
                        reinterpret_cast<const float4 *>(key_pts), reinterpret_cast<const float2 *>(grad), num_pts,
                        octave_width, octave_height, gauss_factor, xper, reinterpret_cast<float2 *>(result));
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+// detect_orientations for up to three level lists of one octave in one launch. Unlike nm_detect_orientations, both
+// components of every result are written (unset = -1), so the caller need not pre-fill (pyramidata.cu:90).
+int nm_detect_orientations_levels(int n_levels, const float *const *key_pts, const int *num_pts, const float *grad,
+                                  int octave_width, int octave_height, float gauss_factor, float xper,
+                                  float *const *result, void *stream)
+{
+    if (n_levels <= 0) return 0;
+    if (n_levels > 3 || !key_pts || !num_pts || !result) return (int)hipErrorInvalidValue;
+    NmLevelLists a{};
+    int most = 0;
+    a.n_levels = n_levels;
+    for (int l = 0; l < n_levels; ++l) {
+        a.key_pts[l] = reinterpret_cast<const float4 *>(key_pts[l]);
+        a.orients[l] = reinterpret_cast<float2 *>(result[l]);
+        a.num_pts[l] = num_pts[l];
+        most = max(most, num_pts[l]);
+    }
+    if (most <= 0) return 0;
+    hipLaunchKernelGGL(orientations_levels_kernel, dim3(min(nm_divup(most, 4), 4096), n_levels), dim3(256), 0,
+                       nm_stream(stream), a, reinterpret_cast<const float2 *>(grad), octave_width, octave_height,
+                       gauss_factor, xper);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+// compute_sift_descriptors for up to three level lists of one octave in one launch.
+int nm_compute_sift_descriptors_levels(int n_levels, const float *const *key_pts, const float *const *orients,
+                                       const int *num_pts, const float *grad, int octave_width, int octave_height,
+                                       int num_dogs, float xper, float *const *desc, float *const *x, float *const *y,
+                                       void *stream)
+{
+    if (n_levels <= 0) return 0;
+    if (n_levels > 3 || !key_pts || !orients || !num_pts || !desc || !x || !y) return (int)hipErrorInvalidValue;
+    NmLevelLists a{};
+    int most = 0;
+    a.n_levels = n_levels;
+    for (int l = 0; l < n_levels; ++l) {
+        a.key_pts[l] = reinterpret_cast<const float4 *>(key_pts[l]);
+        a.orients[l] = const_cast<float2 *>(reinterpret_cast<const float2 *>(orients[l]));
+        a.desc[l] = desc[l]; a.x[l] = x[l]; a.y[l] = y[l];
+        a.num_pts[l] = num_pts[l];
+        most = max(most, num_pts[l]);
+    }
+    if (most <= 0) return 0;
+    hipLaunchKernelGGL(descriptors_levels_kernel, dim3(min(most, 4096), n_levels), dim3(64), 0, nm_stream(stream), a,
+                       reinterpret_cast<const float2 *>(grad), octave_width, octave_height, num_dogs, xper);
     NM_LAUNCH_CHECK();
     return 0;
 }

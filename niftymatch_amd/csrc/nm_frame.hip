@@ -302,6 +302,30 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
     return rc;
 }
 
+// The scale-space chain of nm_sift_detect_describe_batch alone (base blur, then per octave the five fused Gaussian + DoG +
+// gradient launches with the decimation in the level-3 epilogue), exactly the launches the frame driver issues on the
+// caller's stream, without detection / description: what bench.py times for the whole-pyramid roofline.
+int nm_sift_scale_space_batch(nm_sift_arena *const *as, int n, const float *const *gray, void *stream)
+{
+    if (!as || n <= 0 || n > NM_MAX_BATCH || !gray) return (int)hipErrorInvalidValue;
+    int cur = -1;
+    NM_RETURN_IF(hipGetDevice(&cur));
+    for (int f = 0; f < n; ++f) {
+        if (!as[f] || !gray[f] || as[f]->device != cur) return (int)hipErrorInvalidValue;
+        if (as[f]->width != as[0]->width || as[f]->height != as[0]->height) return (int)hipErrorInvalidValue;
+    }
+    hipStream_t st = nm_stream(stream);
+    const SiftParams &P = as[0]->params;
+    const int W = as[0]->width, H = as[0]->height;
+    NmConvBatch base{};
+    base.n = n;
+    for (int f = 0; f < n; ++f) { base.result[f] = as[f]->level[0]; base.image[f] = gray[f]; }
+    int rc = nm_launch_convolve_batch(base, W, H, as[0]->taps_base, as[0]->base_radius, st);
+    for (int o = 0; !rc && o < P._num_octaves; ++o)
+        rc = octave_pyramid(as, n, o, W >> o, H >> o, false, o + 1 < P._num_octaves, st);
+    return rc;
+}
+
 int nm_sift_detect_describe(nm_sift_arena *a, const float *gray, float *desc, float *x, float *y, float *kpts,
                             float *orients, int *d_num_items, void *stream)
 {

@@ -179,6 +179,32 @@ __global__ __launch_bounds__(256) void scatter_valid_kernel(const float4 *__rest
     if (f) out[offsets[blockIdx.x] + r] = v;
 }
 
+struct NmCompact3 { const float4 *dense[3]; float4 *out[3]; int *counts; int *offsets; int *totals; int n, nb; };
+
+__global__ __launch_bounds__(256) void count_valid3_kernel(NmCompact3 c)
+{
+    __shared__ int s_wave[4];
+    const int l = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool f = (i < c.n) && (c.dense[l][i].w >= 0);
+    int total;
+    block_rank(f, total, s_wave);
+    if (threadIdx.x == 0) c.counts[l * c.nb + blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void scatter_valid3_kernel(NmCompact3 c)
+{
+    __shared__ int s_wave[4];
+    const int l = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float4 v = make_float4(-1, -1, -1, -1);
+    if (i < c.n) v = c.dense[l][i];
+    const bool f = (i < c.n) && (v.w >= 0);
+    int total;
+    const int r = block_rank(f, total, s_wave);
+    if (f) c.out[l][c.offsets[l * c.nb + blockIdx.x] + r] = v;
+}
+
 // Exclusive scan of n ints by ONE workgroup of 1024 threads; returns the total to every thread.
 __device__ int block_exclusive_scan_1024(const int *__restrict__ in, int *__restrict__ out, int n, int *s /* [1024+1] */)
 {
@@ -211,6 +237,15 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(const int *__restrict
     if (threadIdx.x == 0 && total_out) *total_out = total;
 }
 
+__global__ __launch_bounds__(1024) void scan_counts3_kernel(NmCompact3 c)
+{
+    __shared__ int s[1024];
+    for (int l = 0; l < 3; ++l) {
+        const int total = block_exclusive_scan_1024(c.counts + l * c.nb, c.offsets + l * c.nb, c.nb, s);
+        if (threadIdx.x == 0) c.totals[l] = total;
+    }
+}
+
 // ---- frame-driver kernels: detect 3 levels of one octave straight into per-unit staging, then scan + book-keeping,
 //      then gather into the output-ordered keypoint list ----
 // A unit is a 256-pixel segment of one image row (units in raster order: u = y * nseg + seg). One workgroup per unit,
@@ -232,6 +267,7 @@ __device__ __forceinline__ float min3f(float a, float b, float c) { return __bui
 
 constexpr int DET_ROWS = 4;      // image rows per workgroup: 6 rows are loaded for 4 tested (measured best of 4, 5, 6, 8)
 
+template <bool DENSE>
 __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
 {
     __shared__ int s_cnt[2][4][3];
@@ -288,7 +324,9 @@ __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
         const int cs = (j + 1) & 1;                                        // centre-row slot of row y
         if (j + 1 < DET_ROWS) fetch_row(y + 2, (j + 1) & 1);
         absorb_row(j & 1, s_dn, j & 1);
-        const bool interior = xin && x >= 1 && x <= ow - 2 && y >= 1 && y <= oh - 2;
+        bool interior = xin && x >= 1 && x <= ow - 2 && y >= 1 && y <= oh - 2;
+        if (DENSE && a.mask && interior)     // masked detection: the bilinear border fetch of the full-resolution mask must be 1
+            interior = mask_fetch(a.mask, a.mask_w, a.mask_h, ((float)x + 0.5f) * a.xper, ((float)y + 0.5f) * a.xper) >= 1.f;
         float m9[5], n9[5], m8[5], n8[5];
 #pragma unroll
         for (int p = 0; p < 5; ++p) {
@@ -309,6 +347,14 @@ __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
             if (f[level])
                 f[level] = refine(dog[level + 1], dog[level], dog[level + 2], x, y, ow, a.peak, a.edge, a.xper,
                                   a.sigma0, a.num_dogs, level, kp[level]);
+        }
+        if (DENSE) {                 // API path: the dense maps, every pixel (the caller never has to pre-fill this region)
+            if (xin && y < oh) {
+#pragma unroll
+                for (int level = 0; level < 3; ++level)
+                    reinterpret_cast<float4 *>(a.dense[level])[(size_t)y * ow + x] = kp[level];
+            }
+            continue;
         }
         // ordered compaction of the row segment (= one unit), 3 levels with one barrier
         int rank[3];
@@ -394,7 +440,7 @@ __global__ __launch_bounds__(256) void gather_stage_kernel(NmGatherArgs a)
 int nm_launch_detect_octave(const NmDetectArgs &d, const NmScanArgs &s, const NmGatherArgs &g, hipStream_t stream)
 {
     if (d.n_blocks <= 0 || d.n <= 0) return 0;
-    hipLaunchKernelGGL(detect_stage_kernel, dim3(d.nseg * nm_divup(d.oh, DET_ROWS), d.n), dim3(256), 0, stream, d);
+    hipLaunchKernelGGL(detect_stage_kernel<false>, dim3(d.nseg * nm_divup(d.oh, DET_ROWS), d.n), dim3(256), 0, stream, d);
     NM_LAUNCH_CHECK();
     hipLaunchKernelGGL(scan_book_kernel, dim3(s.n), dim3(1024), 0, stream, s);
     NM_LAUNCH_CHECK();
@@ -425,6 +471,57 @@ int nm_find_keypoints_f32(const float *current, const float *down, const float *
 {
     return nm_find_keypoints_masked_f32(current, nullptr, 0, 0, down, up, width, height, peak_threshold, edge_threshold,
                                         xper, sigma_0, num_dogs, dog, result, stream);
+}
+
+// find_keypoints for the three searched DoG levels of an octave in ONE launch (the loop of compute_keypoints,
+// sift/siftfunctions.cu:100-134). Every pixel of the first width*height entries of result[0..2] is written.
+int nm_find_keypoints3_f32(const float *const dog[5], const float *mask, int mask_width, int mask_height, int width,
+                           int height, float peak_threshold, float edge_threshold, float xper, float sigma_0, int num_dogs,
+                           float *const result[3], void *stream)
+{
+    if (width <= 0 || height <= 0) return 0;
+    if (!dog || !result) return (int)hipErrorInvalidValue;
+    NmDetectArgs d{};
+    d.n = 1; d.ow = width; d.oh = height; d.peak = peak_threshold; d.edge = edge_threshold; d.xper = xper;
+    d.sigma0 = sigma_0; d.num_dogs = num_dogs;
+    d.nseg = nm_divup(width, 256); d.n_blocks = height * d.nseg;
+    for (int i = 0; i < 5; ++i) { if (!dog[i]) return (int)hipErrorInvalidValue; d.dog[0][i] = dog[i]; }
+    for (int l = 0; l < 3; ++l) { if (!result[l]) return (int)hipErrorInvalidValue; d.dense[l] = result[l]; }
+    d.mask = mask; d.mask_w = mask_width; d.mask_h = mask_height;
+    hipLaunchKernelGGL(detect_stage_kernel<true>, dim3(d.nseg * nm_divup(height, DET_ROWS), 1), dim3(256), 0,
+                       nm_stream(stream), d);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+size_t nm_compact3_workspace_bytes(int num_pixels)
+{
+    const size_t nb = (size_t)nm_divup(num_pixels > 0 ? num_pixels : 1, 256);
+    return 6 * nb * sizeof(int);
+}
+
+// The stable compaction of gpu_collate_keypoints_for_level (sift/pyramidata.cu:84-88) for three dense maps at once:
+// three launches instead of nine. d_counts: 3 ints on the device.
+int nm_compact_keypoints3(const float *const dense[3], int num_pixels, float *const out[3], int *d_counts, void *workspace,
+                          void *stream)
+{
+    hipStream_t st = nm_stream(stream);
+    if (!dense || !out || !d_counts || !workspace) return (int)hipErrorInvalidValue;
+    if (num_pixels <= 0) return (int)hipMemsetAsync(d_counts, 0, 3 * sizeof(int), st);
+    NmCompact3 c{};
+    c.n = num_pixels; c.nb = nm_divup(num_pixels, 256);
+    for (int l = 0; l < 3; ++l) {
+        c.dense[l] = reinterpret_cast<const float4 *>(dense[l]);
+        c.out[l] = reinterpret_cast<float4 *>(out[l]);
+    }
+    c.counts = static_cast<int *>(workspace); c.offsets = c.counts + 3 * c.nb; c.totals = d_counts;
+    hipLaunchKernelGGL(count_valid3_kernel, dim3(c.nb, 3), dim3(256), 0, st, c);
+    NM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_counts3_kernel, dim3(1), dim3(1024), 0, st, c);
+    NM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scatter_valid3_kernel, dim3(c.nb, 3), dim3(256), 0, st, c);
+    NM_LAUNCH_CHECK();
+    return 0;
 }
 
 size_t nm_compact_workspace_bytes(int num_pixels)

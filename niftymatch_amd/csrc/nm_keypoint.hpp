@@ -14,6 +14,11 @@ struct NmDetectArgs {
     int *counts[NM_MAX_BATCH];      // 3 x n_blocks
     int n_blocks;          // oh * nseg units: a unit is one 256-pixel segment of one row, units in raster order
     int nseg;              // ceil(ow / 256)
+    // API path (nm_find_keypoints3_f32, one frame): every pixel of the three dense float4 maps is written (an accepted
+    // keypoint or -1) instead of the staging lists; optional full-resolution mask (keypoint.cu:204-224)
+    float *dense[3];
+    const float *mask;
+    int mask_w, mask_h;
 };
 
 struct NmScanArgs {

@@ -626,54 +626,90 @@ __global__ __launch_bounds__(256) void transpose_kernel(float *__restrict__ odat
     }
 }
 
-// Exact squared distances of a 64 (lane side) x 64 (register side) tile: every thread owns one lane-side vector and
-// 16 register-side vectors; k ascending, acc = fma(t, t, acc) with t = a_k - b_k (match.cu:36-42).
-// L: lane-side set (nL vectors), Rm: register-side set. Element (v,k) of a set is X[v*DIM+k], or X[k*n+v] when
-// transposed. out[(lane index)*ldl + (reg index)*ldr].
-template <bool L_TRANSPOSED>
-__global__ __launch_bounds__(256) void exact_distance_kernel(const float *__restrict__ L, int nL,
-                                                            const float *__restrict__ Rm, int nR,
-                                                            float *__restrict__ out, size_t ldl, size_t ldr,
-                                                            bool l_is_a)
+// Exact squared distances, the reference's own arithmetic (match.cu:36-42): for every (row vector x, column vector y)
+//   acc = 0;  for k = 0..127:  t = x_k - y_k;  acc = fma(t, t, acc)
+// (fl(x - y) = -fl(y - x) exactly, so which operand is the query does not matter). This is VALU work by nature -- the
+// difference has to be formed per pair, so it is not a contraction an MFMA could take -- and its floor is two VALU
+// operations per (pair, k): 2 * 128 * rows * cols / 78.6e12 lane-ops/s = 481 us at 12k x 12k. A workgroup owns a 128 x 128
+// tile of the output, a thread an 8 x 8 register tile; the operands stream through LDS k-major in chunks of 32 k (two
+// b128 reads per operand feed 128 VALU operations: 1 LDS read per 32 VALU instead of the 17 per 32 of the round-1 kernel).
+// X: row-side set (nX vectors), Y: column-side set. Element (v, k) is S[v * 128 + k], or S[k * n + v] when K_MAJOR.
+// out[row * ld + col].
+constexpr int XD_TILE = 128, XD_KC = 32, XD_PITCH = XD_TILE + 4;
+
+template <bool K_MAJOR>
+__device__ __forceinline__ void xd_stage(float *__restrict__ dst, const float *__restrict__ S, int n, int v0, int kc, int tid)
 {
-    __shared__ float sL[64 * 129];
-    __shared__ float sR[64 * 129];
+    if (K_MAJOR) {           // S[k][v]: rows of the LDS image are contiguous in memory
+#pragma unroll
+        for (int it = 0; it < (XD_KC * XD_TILE) / 256; ++it) {
+            const int e = tid + 256 * it;
+            const int k = e >> 7, v = e & 127;
+            dst[k * XD_PITCH + v] = (v0 + v < n) ? S[(size_t)(kc + k) * n + v0 + v] : 0.f;
+        }
+    } else {                 // S[v][k]: 8 lanes read the 32 k of one vector (128 contiguous bytes), scattered k-major into LDS
+#pragma unroll
+        for (int it = 0; it < (XD_KC * XD_TILE) / (256 * 4); ++it) {
+            const int e = tid + 256 * it;
+            const int v = e >> 3, k4 = (e & 7) * 4;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v0 + v < n) x = *reinterpret_cast<const float4 *>(S + (size_t)(v0 + v) * DIM + kc + k4);
+            dst[(k4 + 0) * XD_PITCH + v] = x.x; dst[(k4 + 1) * XD_PITCH + v] = x.y;
+            dst[(k4 + 2) * XD_PITCH + v] = x.z; dst[(k4 + 3) * XD_PITCH + v] = x.w;
+        }
+    }
+}
+
+template <bool X_KMAJOR, bool Y_KMAJOR>
+__global__ __launch_bounds__(256) void exact_distance_kernel(const float *__restrict__ X, int nX,
+                                                            const float *__restrict__ Y, int nY,
+                                                            float *__restrict__ out, size_t ld)
+{
+    __shared__ __attribute__((aligned(16))) float sX[XD_KC * XD_PITCH];
+    __shared__ __attribute__((aligned(16))) float sY[XD_KC * XD_PITCH];
     const int tid = threadIdx.x;
-    const int l0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
-    if (L_TRANSPOSED) {
-        for (int e = tid; e < 64 * DIM; e += 256) {
-            const int k = e >> 6, v = e & 63;
-            sL[v * 129 + k] = (l0 + v < nL) ? L[(size_t)k * nL + l0 + v] : 0.f;
-        }
-    } else {
-        for (int e = tid; e < 64 * DIM; e += 256) {
-            const int v = e >> 7, k = e & 127;
-            sL[v * 129 + k] = (l0 + v < nL) ? L[(size_t)(l0 + v) * DIM + k] : 0.f;
+    const int tx = tid & 15, ty = tid >> 4;                 // 16 x 16 threads, 8 x 8 outputs each
+    const int c0 = blockIdx.x * XD_TILE, r0 = blockIdx.y * XD_TILE;
+    float acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+    for (int kc = 0; kc < DIM; kc += XD_KC) {
+        __syncthreads();
+        xd_stage<X_KMAJOR>(sX, X, nX, r0, kc, tid);
+        xd_stage<Y_KMAJOR>(sY, Y, nY, c0, kc, tid);
+        __syncthreads();
+#pragma unroll 4
+        for (int k = 0; k < XD_KC; ++k) {
+            const float4 xa = *reinterpret_cast<const float4 *>(&sX[k * XD_PITCH + ty * 8]);
+            const float4 xb = *reinterpret_cast<const float4 *>(&sX[k * XD_PITCH + ty * 8 + 4]);
+            const float4 ya = *reinterpret_cast<const float4 *>(&sY[k * XD_PITCH + tx * 8]);
+            const float4 yb = *reinterpret_cast<const float4 *>(&sY[k * XD_PITCH + tx * 8 + 4]);
+            const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+            const float yv[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float t = xv[i] - yv[j];
+                    acc[i][j] = __builtin_fmaf(t, t, acc[i][j]);
+                }
         }
     }
-    for (int e = tid; e < 64 * DIM; e += 256) {
-        const int v = e >> 7, k = e & 127;
-        sR[v * 129 + k] = (r0 + v < nR) ? Rm[(size_t)(r0 + v) * DIM + k] : 0.f;
-    }
-    __syncthreads();
-    const int lv = tid & 63, rg = tid >> 6;
-    float acc[16];
+    const int col = c0 + tx * 8;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    for (int k = 0; k < DIM; ++k) {
-        const float x = sL[lv * 129 + k];
+    for (int i = 0; i < 8; ++i) {
+        const int row = r0 + ty * 8 + i;
+        if (row >= nX) continue;
+        float *o = out + (size_t)row * ld + col;
+        if (col + 7 < nY && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
+            *reinterpret_cast<float4 *>(o) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+            *reinterpret_cast<float4 *>(o + 4) = make_float4(acc[i][4], acc[i][5], acc[i][6], acc[i][7]);
+        } else {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float y = sR[(rg * 16 + q) * 129 + k];
-            const float t = l_is_a ? (x - y) : (y - x);
-            acc[q] = __builtin_fmaf(t, t, acc[q]);
-        }
-    }
-    if (l0 + lv < nL) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int rv = r0 + rg * 16 + q;
-            if (rv < nR) out[(size_t)(l0 + lv) * ldl + (size_t)rv * ldr] = acc[q];
+            for (int j = 0; j < 8; ++j)
+                if (col + j < nY) o[j] = acc[i][j];
         }
     }
 }
@@ -823,10 +859,10 @@ int nm_bf_distance_f32(const float *A, int size_A, const float *B, int size_B, i
 {
     if (sift_vector_size != DIM) return (int)hipErrorInvalidValue;
     if (size_A <= 0 || size_B <= 0) return 0;
-    // lanes along i (contiguous in the transposed output D[j*size_A + i])
-    dim3 grid(nm_divup(size_A, 64), nm_divup(size_B, 64));
-    hipLaunchKernelGGL(exact_distance_kernel<true>, grid, dim3(256), 0, nm_stream(stream), A, size_A, B, size_B, result,
-                       (size_t)1, (size_t)size_A, true);
+    // rows of the (transposed) output = candidates j, columns = queries i: result[j * size_A + i]; A arrives k-major
+    dim3 grid(nm_divup(size_A, XD_TILE), nm_divup(size_B, XD_TILE));
+    hipLaunchKernelGGL((exact_distance_kernel<false, true>), grid, dim3(256), 0, nm_stream(stream), B, size_B, A, size_A,
+                       result, (size_t)size_A);
     NM_LAUNCH_CHECK();
     return 0;
 }
@@ -888,10 +924,9 @@ int nm_sift_match_f32(const float *A, int nA, const float *B, int nB, float *dis
 {
     if (nA <= 0 || nB <= 0) return 0;
     hipStream_t st = nm_stream(stream);
-    if (distance) {                     // lanes along j (contiguous in distance[i*nB + j])
-        dim3 grid(nm_divup(nB, 64), nm_divup(nA, 64));
-        hipLaunchKernelGGL(exact_distance_kernel<false>, grid, dim3(256), 0, st, B, nB, A, nA, distance, (size_t)1,
-                           (size_t)nB, false);
+    if (distance) {                     // distance[i * nB + j]: rows = queries, columns = candidates
+        dim3 grid(nm_divup(nB, XD_TILE), nm_divup(nA, XD_TILE));
+        hipLaunchKernelGGL((exact_distance_kernel<false, false>), grid, dim3(256), 0, st, A, nA, B, nB, distance, (size_t)nB);
         NM_LAUNCH_CHECK();
     }
     return run_fused(A, nA, B, nB, 0, 0, ambiguity, result, nullptr, nullptr, nullptr, workspace, st);

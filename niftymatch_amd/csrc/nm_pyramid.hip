@@ -320,7 +320,7 @@ __device__ __forceinline__ bool grad_pair(v2f xm, v2f xp, v2f ym, v2f yp, v2f &g
 
 }  // namespace
 
-template <int R, bool WRITE_DOG, bool WRITE_GRAD>
+template <int R, bool WRITE_DOG, bool WRITE_GRAD, bool WRITE_BUF = false>
 __global__ __launch_bounds__(256) void conv_pk_kernel(NmConvBatch batch, int width, int height,
                                                      const float *__restrict__ taps, int tiles_x, int ntiles,
                                                      int blocks_per_frame, int nxcd)
@@ -411,6 +411,20 @@ __global__ __launch_bounds__(256) void conv_pk_kernel(NmConvBatch batch, int wid
             qa[1] = make_float4(o[4].x, o[5].x, o[6].x, o[7].x);
             qb[0] = make_float4(o[0].y, o[1].y, o[2].y, o[3].y);
             qb[1] = make_float4(o[4].y, o[5].y, o[6].y, o[7].y);
+            if (WRITE_BUF) {     // API path: the row pass of the tile's own rows is the caller's `buffer` (convolution.cu:141-159)
+                float *__restrict__ buffer = batch.down[frame];          // the API launcher passes `buffer` in this slot
+                const int gx = x0 + cg * 8;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int rr = 2 * p + half, gy = y0 - R + rr;
+                    if (rr >= R && rr < R + TH && gy < height && gx < width) {
+                        float4 *q = reinterpret_cast<float4 *>(buffer + (size_t)gy * width + gx);
+                        q[0] = half ? make_float4(o[0].y, o[1].y, o[2].y, o[3].y) : make_float4(o[0].x, o[1].x, o[2].x, o[3].x);
+                        if (gx + 4 < width)
+                            q[1] = half ? make_float4(o[4].y, o[5].y, o[6].y, o[7].y) : make_float4(o[4].x, o[5].x, o[6].x, o[7].x);
+                    }
+                }
+            }
         }
     }
     __syncthreads();
@@ -456,7 +470,7 @@ __global__ __launch_bounds__(256) void conv_pk_kernel(NmConvBatch batch, int wid
                 if (gy < height) {
                     const unsigned off = (unsigned)gy * row_bytes + (unsigned)gx * 4u;       // < 4 GiB: checked by the host
                     if (result) *reinterpret_cast<float2 *>(reinterpret_cast<char *>(result) + off) = make_float2(o[i].x, o[i].y);
-                    if (down && !(gy & 1)) {         // next octave's level 0 = every other pixel of every other row (gx is even)
+                    if (!WRITE_BUF && down && !(gy & 1)) {         // next octave's level 0 = every other pixel of every other row (gx is even)
                         const int dw = width >> 1, dx = gx >> 1, dy = gy >> 1;
                         if (dx < dw && dy < (height >> 1)) down[(size_t)dy * dw + dx] = o[i].x;
                     }
@@ -599,10 +613,29 @@ static int launch_conv_pk(const NmConvBatch &b, int width, int height, const flo
     return 0;
 }
 
+template <int R>
+static int launch_conv_pk_buf(float *result, const float *image, float *buffer, int width, int height, const float *taps,
+                              hipStream_t stream)
+{
+    NmConvBatch b{};
+    b.result[0] = result; b.image[0] = image; b.down[0] = buffer; b.n = 1;
+    const int tiles_x = nm_divup(width, 64), tiles_y = nm_divup(height, 32);
+    const int ntiles = tiles_x * tiles_y;
+    const int nxcd = nm_xcd_count();
+    const int bpf = nm_divup(ntiles, nxcd) * nxcd;
+    hipLaunchKernelGGL((conv_pk_kernel<R, false, false, true>), dim3(bpf), dim3(256), 0, stream, b, width, height, taps,
+                       tiles_x, ntiles, bpf, nxcd);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int R, bool VEC>
 static int launch_conv_rv(float *result, const float *image, float *buffer, float *dog, float *grad, int width,
                           int height, const float *taps, hipStream_t stream)
 {
+    if (VEC && buffer && !dog && !grad && result && (size_t)width * height * 4 < (1ull << 32) &&
+        ((reinterpret_cast<uintptr_t>(buffer) | reinterpret_cast<uintptr_t>(result)) & 15) == 0)
+        return launch_conv_pk_buf<R>(result, image, buffer, width, height, taps, stream);
     if (VEC && !buffer && !(grad && !dog) && (size_t)width * height * 4 < (1ull << 32)) {
         NmConvBatch b{};
         b.result[0] = result; b.image[0] = image; b.dog[0] = dog; b.grad[0] = grad; b.n = 1;
@@ -728,6 +761,16 @@ __global__ __launch_bounds__(256) void subtract_kernel(const float *__restrict__
     for (; i < n; i += stride) C[i] = A[i] - B[i];
 }
 
+struct NmSubBatch { const float *A[8]; const float *B[8]; float *C[8]; };
+__global__ __launch_bounds__(256) void subtract_batch_kernel(NmSubBatch b, size_t n)
+{
+    const float *__restrict__ A = b.A[blockIdx.y], *__restrict__ B = b.B[blockIdx.y];
+    float *__restrict__ C = b.C[blockIdx.y];
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) C[i] = A[i] - B[i];
+}
+
 // gradient: g = 0.5*sqrt(dx^2+dy^2), theta = mod_2pi(atan2(dy,dx) + 2pi) in (0, 2pi], 0 when g == 0; border = (0,0).
 __global__ __launch_bounds__(256) void gradient_kernel(NmGradBatch b, int width, int height)
 {
@@ -799,6 +842,33 @@ int nm_subtract_f32(const float *A, const float *B, float *C, int width, int hei
     hipLaunchKernelGGL(subtract_kernel, dim3(blocks), dim3(256), 0, nm_stream(stream), A, B, C, n);
     NM_LAUNCH_CHECK();
     return 0;
+}
+
+// compute_dog's loop (sift/siftfunctions.cu:42-51) as one launch: C[k] = A[k] - B[k] for n <= 8 planes.
+int nm_subtract_batch_f32(int n, const float *const *A, const float *const *B, float *const *C, int width, int height,
+                          void *stream)
+{
+    const size_t npx = (size_t)width * height;
+    if (n <= 0 || npx == 0) return 0;
+    if (n > 8 || !A || !B || !C) return (int)hipErrorInvalidValue;
+    NmSubBatch b{};
+    for (int k = 0; k < n; ++k) { b.A[k] = A[k]; b.B[k] = B[k]; b.C[k] = C[k]; }
+    int blocks = (int)((npx + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(subtract_batch_kernel, dim3(blocks, n), dim3(256), 0, nm_stream(stream), b, npx);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+// compute_gradients' loop (sift/siftfunctions.cu:53-63) as one launch: n <= 3 planes.
+int nm_gradient_batch_f32(int n, const float *const *source, float *const *result, int width, int height, void *stream)
+{
+    if (n <= 0) return 0;
+    if (n > 3 || !source || !result) return (int)hipErrorInvalidValue;
+    NmGradBatch b{};
+    b.n = n;
+    for (int k = 0; k < n; ++k) { b.src[k] = source[k]; b.dst[k] = result[k]; }
+    return nm_launch_gradient_batch(b, width, height, nm_stream(stream));
 }
 
 int nm_gradient_f32(const float *source, float *result, int width, int height, void *stream)

@@ -23,20 +23,20 @@ class device_vector {
     static_assert(sizeof(T) % 4 == 0, "device_vector<T>: T must be a multiple of 4 bytes");
 
 public:
-    device_vector() : _p(nullptr), _n(0) {}
-    explicit device_vector(size_t n) : _p(nullptr), _n(0) { allocate(n); zero(); }
-    device_vector(size_t n, const T &value) : _p(nullptr), _n(0) { allocate(n); fill(value); }
-    explicit device_vector(const std::vector<T> &host) : _p(nullptr), _n(0)
+    device_vector() : _p(nullptr), _n(0), _cap(0) {}
+    explicit device_vector(size_t n) : _p(nullptr), _n(0), _cap(0) { allocate(n); zero(); }
+    device_vector(size_t n, const T &value) : _p(nullptr), _n(0), _cap(0) { allocate(n); fill(value); }
+    explicit device_vector(const std::vector<T> &host) : _p(nullptr), _n(0), _cap(0)
     {
         allocate(host.size());
         if (_n) nm_check((int)hipMemcpy(_p, host.data(), _n * sizeof(T), hipMemcpyHostToDevice), "device_vector H2D");
     }
-    device_vector(const device_vector &o) : _p(nullptr), _n(0) { copy_from(o); }
-    device_vector(device_vector &&o) noexcept : _p(o._p), _n(o._n) { o._p = nullptr; o._n = 0; }
+    device_vector(const device_vector &o) : _p(nullptr), _n(0), _cap(0) { copy_from(o); }
+    device_vector(device_vector &&o) noexcept : _p(o._p), _n(o._n), _cap(o._cap) { o._p = nullptr; o._n = 0; o._cap = 0; }
     device_vector &operator=(const device_vector &o) { if (this != &o) copy_from(o); return *this; }
     device_vector &operator=(device_vector &&o) noexcept
     {
-        if (this != &o) { release(); _p = o._p; _n = o._n; o._p = nullptr; o._n = 0; }
+        if (this != &o) { release(); _p = o._p; _n = o._n; _cap = o._cap; o._p = nullptr; o._n = 0; o._cap = 0; }
         return *this;
     }
     ~device_vector() { release(); }
@@ -52,6 +52,19 @@ public:
     void clear() { release(); }
     void assign(size_t n, const T &value) { release(); allocate(n); fill(value); }
     void resize(size_t n) { if (n != _n) { release(); allocate(n); zero(); } }
+    size_t capacity() const { return _cap; }
+    //! size() becomes n WITHOUT touching the device: the allocation is kept while it is large enough (grow-only, with
+    //! headroom), the contents are unspecified. For buffers a kernel fills completely right afterwards -- no
+    //! hipMalloc / hipFree / fill on the per-octave path (the reference re-creates _orientations[level] per level,
+    //! sift/pyramidata.cu:90).
+    void resize_uninitialized(size_t n)
+    {
+        if (n > _cap) {
+            release();
+            allocate(n + n / 2 + 64);
+        }
+        _n = n;
+    }
 
     void fill(const T &value)
     {
@@ -79,6 +92,7 @@ private:
     void allocate(size_t n)
     {
         _n = n;
+        _cap = n;
         _p = nullptr;
         if (n) nm_check((int)hipMalloc(reinterpret_cast<void **>(&_p), n * sizeof(T)), "device_vector alloc");
     }
@@ -91,6 +105,7 @@ private:
         if (_p) (void)hipFree(_p);
         _p = nullptr;
         _n = 0;
+        _cap = 0;
     }
     void copy_from(const device_vector &o)
     {
@@ -99,7 +114,7 @@ private:
         if (_n) nm_check((int)hipMemcpy(_p, o._p, _n * sizeof(T), hipMemcpyDeviceToDevice), "device_vector D2D");
     }
     T *_p;
-    size_t _n;
+    size_t _n, _cap;
 };
 
 }  // namespace nm

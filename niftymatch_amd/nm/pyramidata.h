@@ -15,9 +15,9 @@
 
 class PyramidData {
 public:
-    PyramidData() : _base_radius(0), _num_octaves(0), _num_dogs(0), _num_kernels(0) {}
+    PyramidData() : _base_radius(0), _num_octaves(0), _num_dogs(0), _num_kernels(0) { for (auto &d : _dirty) d = 0; }
     PyramidData(const SiftParams &params);
-    ~PyramidData() {}
+    ~PyramidData();
 
     void initialize(const SiftParams &params);
     void clear();
@@ -41,11 +41,20 @@ public:
     int _num_dogs;
     int _num_kernels;
 
+    //! Extension used by compute_keypoints / compute_orientations: the three levels of an octave collated by one
+    //! batched compaction and ONE device-to-host copy of the three counts (the reference's copy_if synchronises once
+    //! per level). counts[l] = valid entries among the first \c num_pixels of _key_pts[l]; _collated_kpts[l] is filled.
+    //! Waits for \c stream. _orientations is not touched.
+    void gpu_collate_keypoints_for_octave(int num_pixels, int counts[3], hipStream_t stream = 0);
+    //! compute_keypoints bookkeeping: _key_pts[l][i] may differ from -1 only for i < _dirty[l].
+    size_t _dirty[19];
+
 private:
     void generate_kernels(const SiftParams &params);
     void create_kernel_for_sigma(float sigma, nm::device_vector<float> &result, int &radius);
-    nm::device_vector<int> _count;        // device-side counter + scratch of the compaction
+    nm::device_vector<int> _count;        // device-side counters + scratch of the compaction
     nm::device_vector<int> _compact_ws;
+    int *_host_counts = nullptr;          // pinned, 4 ints
 };
 
 #endif

@@ -17,6 +17,10 @@ struct SiftData {
     int *_match_indexes_ptr;
     int _num_items;
     int _capacity;
+    //! Extension: scratch of compute_sift_matches(A = this, ...), kept between calls and only ever grown, so that a match
+    //! call neither allocates nor synchronises (the reference allocates two device_vectors per call,
+    //! sift/siftfunctions.cu:21,28).
+    nm::device_vector<int> _match_workspace;
 
     SiftData() : _x_ptr(nullptr), _y_ptr(nullptr), _match_indexes_ptr(nullptr), _num_items(0), _capacity(0) {}
     SiftData(int capacity);      //!< throws std::runtime_error for capacity <= 0

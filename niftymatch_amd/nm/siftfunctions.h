@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include "cudatex2D.h"
 #include "pyramidata.h"
 #include "siftdata.h"
 #include "siftparams.h"
@@ -24,6 +25,11 @@ void compute_keypoints(PyramidData &pydata, const SiftParams &params, const int 
 void compute_keypoints_with_mask(PyramidData &pydata, SiftParams &params, const float *mask, const int mask_width,
                                  const int mask_height, const int octave, const int octave_width,
                                  const int octave_height, hipStream_t stream = 0);
+
+//! The reference's own argument list (sift/siftfunctions.h:70-73): \c mask is the texture view of the full-resolution
+//! float mask (NmTexture takes the place of cudaTextureObject_t, see cudatex2D.h).
+void compute_keypoints_with_mask(PyramidData &pydata, SiftParams &params, NmTexture mask, const int octave,
+                                 const int octave_width, const int octave_height, hipStream_t stream = 0);
 
 void compute_orientations(PyramidData &pydata, const SiftParams &params, const int octave, const int octave_width,
                           const int octave_height, hipStream_t stream = 0);

@@ -1,6 +1,8 @@
 // kernels_api.cpp -- C++ launchers of the `kernels` library: the reference's L2 signatures on top of the C ABI.
 // Error convention: a failing launch prints file:line + the HIP error and exit()s, as helper_cuda.h's
 // getLastCudaError does in the reference (e.g. kernels/convolution.cu:152,158, kernels/match.cu:134).
+#include <string>
+
 #include "../../../include/nm_abi.h"
 #include "../bgra_2_gray.h"
 #include "../cast.h"
@@ -67,6 +69,32 @@ void find_keypoints(const float *current, const float *mask, const int mask_widt
                                           peak_threshold, edge_threshold, xper, sigma_0, num_dogs, dog,
                                           reinterpret_cast<float *>(result), stream),
              "Keypoint detection launch failed");
+}
+
+static const float *plane_of(const NmTexture &t, int width, int height, const char *what)
+{
+    if (t.format != NM_TEXEL_F32 || !t.data) RUNTIME_EXCEPTION(std::string("find_keypoints: ") + what + " must be a float texture");
+    if (width > 0 && (t.width != width || t.height != height))
+        RUNTIME_EXCEPTION(std::string("find_keypoints: ") + what + " does not have the octave's geometry");
+    return static_cast<const float *>(t.data);
+}
+
+void find_keypoints(NmTexture current, NmTexture down, NmTexture up, const int width, const int height,
+                    const float peak_threshold, const float edge_threshold, const float xper, const float sigma_0,
+                    const int num_dogs, const int dog, float4 *result, hipStream_t stream)
+{
+    find_keypoints(plane_of(current, width, height, "current"), plane_of(down, width, height, "down"),
+                   plane_of(up, width, height, "up"), width, height, peak_threshold, edge_threshold, xper, sigma_0, num_dogs,
+                   dog, result, stream);
+}
+
+void find_keypoints(NmTexture current, NmTexture mask, NmTexture down, NmTexture up, const int width, const int height,
+                    const float peak_threshold, const float edge_threshold, const float xper, const float sigma_0,
+                    const int num_dogs, const int dog, float4 *result, hipStream_t stream)
+{
+    find_keypoints(plane_of(current, width, height, "current"), plane_of(mask, 0, 0, "mask"), mask.width, mask.height,
+                   plane_of(down, width, height, "down"), plane_of(up, width, height, "up"), width, height, peak_threshold,
+                   edge_threshold, xper, sigma_0, num_dogs, dog, result, stream);
 }
 
 void detect_orientations(const float4 *key_pts, const float2 *grad, const int num_pts, const int octave_width,

@@ -2,6 +2,7 @@
 // written against NiftyMatch owns, using only the public headers.
 #include "../../../include/nm_client.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <exception>
@@ -13,6 +14,30 @@
 #include "../ransac.h"
 #include "../siftfunctions.h"
 
+// The frame loop a NiftyMatch application owns: every call below is a function of the reference's public
+// headers with the reference's argument list. `gray` is on the device; `out` is reset first.
+static void client_frame(const SiftParams &params, PyramidData &py, const float *gray, SiftData &out, hipStream_t stream)
+{
+    const int width = params._width, height = params._height;
+    out._num_items = 0;
+    convolve<float>(py._octave[0].data(), gray, py._buffer.data(), width, height, py._base_kernel.data(), py._base_radius,
+                    stream);
+    for (int o = 0; o < params._num_octaves; ++o) {
+        const int ow = width >> o, oh = height >> o;
+        if (o > 0)   // level 3 has twice the base sigma: it seeds the next octave
+            downsample_by_2<float>(py._octave[0].data(), ow, oh, py._octave[3].data(), width >> (o - 1), height >> (o - 1),
+                                   stream);
+        for (int i = 1; i < py._num_octaves; ++i)
+            convolve<float>(py._octave[i].data(), py._octave[i - 1].data(), py._buffer.data(), ow, oh,
+                            py._kernels[i - 1].data(), py._kernel_radii[i - 1], stream);
+        compute_dog(py, ow, oh, stream);
+        compute_gradients(py, params, ow, oh, stream);
+        compute_keypoints(py, params, o, ow, oh, stream);
+        compute_orientations(py, params, o, ow, oh, stream);
+        compute_descriptors(py, params, o, ow, oh, out, stream);
+    }
+}
+
 extern "C" int nm_client_detect_describe(const float *gray, int width, int height, int capacity, float *desc, float *x,
                                          float *y)
 {
@@ -22,23 +47,7 @@ extern "C" int nm_client_detect_describe(const float *gray, int width, int heigh
         SiftData out(capacity);
         const size_t npix = (size_t)width * height;
         nm::device_vector<float> d_gray(std::vector<float>(gray, gray + npix));
-
-        convolve<float>(py._octave[0].data(), d_gray.data(), py._buffer.data(), width, height, py._base_kernel.data(),
-                        py._base_radius);
-        for (int o = 0; o < params._num_octaves; ++o) {
-            const int ow = width >> o, oh = height >> o;
-            if (o > 0)   // level 3 has twice the base sigma: it seeds the next octave
-                downsample_by_2<float>(py._octave[0].data(), ow, oh, py._octave[3].data(), width >> (o - 1),
-                                       height >> (o - 1));
-            for (int i = 1; i < py._num_octaves; ++i)
-                convolve<float>(py._octave[i].data(), py._octave[i - 1].data(), py._buffer.data(), ow, oh,
-                                py._kernels[i - 1].data(), py._kernel_radii[i - 1]);
-            compute_dog(py, ow, oh);
-            compute_gradients(py, params, ow, oh);
-            compute_keypoints(py, params, o, ow, oh);
-            compute_orientations(py, params, o, ow, oh);
-            compute_descriptors(py, params, o, ow, oh, out);
-        }
+        client_frame(params, py, d_gray.data(), out, 0);
         const int n = out._num_items;
         if (n > 0) {
             std::vector<float> h = out._desc.to_host();
@@ -50,6 +59,45 @@ extern "C" int nm_client_detect_describe(const float *gray, int width, int heigh
     } catch (const std::exception &e) {
         std::cerr << e.what() << std::endl;
         return -1;
+    }
+}
+
+// Throughput of the drop-in path as an application would drive it: `reps` times { detect+describe both frames with the
+// reference's per-octave client loop, compute_sift_matches(A, B, distance) }. Objects are created once, as a real client
+// does. gray0/gray1 are DEVICE planes. with_distance != 0 passes a caller-allocated N x M `distance` (the reference's
+// mandatory argument); 0 passes NULL (the extension). Returns the wall-clock microseconds per pair (host clock around
+// the loop, device drained), or a negative value on error; n_out receives the two keypoint counts and the match count.
+extern "C" double nm_client_pair_loop(const float *gray0, const float *gray1, int width, int height, int capacity, int reps,
+                                      int with_distance, int *n_out)
+{
+    try {
+        SiftParams params(width, height);
+        PyramidData py(params);
+        SiftData a(capacity), b(capacity);
+        nm::device_vector<float> dist(with_distance ? (size_t)capacity * capacity : 0);
+        hipStream_t st = nullptr;
+        auto pair = [&]() {
+            client_frame(params, py, gray0, a, st);
+            client_frame(params, py, gray1, b, st);
+            compute_sift_matches(&a, &b, with_distance ? dist.data() : nullptr, 0.8f, st);
+        };
+        pair();                                                       // warm-up (workspace growth, code loading)
+        if (hipDeviceSynchronize() != hipSuccess) return -1.0;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < reps; ++r) pair();
+        if (hipDeviceSynchronize() != hipSuccess) return -1.0;
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+        if (n_out) {
+            n_out[0] = a._num_items; n_out[1] = b._num_items;
+            std::vector<int> m = a._match_indexes.to_host();
+            int cnt = 0;
+            for (int i = 0; i < a._num_items; ++i) cnt += m[i] >= 0;
+            n_out[2] = cnt;
+        }
+        return us;
+    } catch (const std::exception &e) {
+        std::cerr << e.what() << std::endl;
+        return -1.0;
     }
 }
 

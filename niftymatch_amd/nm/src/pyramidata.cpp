@@ -6,7 +6,13 @@
 
 PyramidData::PyramidData(const SiftParams &params) : _base_radius(0), _num_octaves(0), _num_dogs(0), _num_kernels(0)
 {
+    for (auto &d : _dirty) d = 0;
     initialize(params);
+}
+
+PyramidData::~PyramidData()
+{
+    if (_host_counts) (void)hipHostFree(_host_counts);
 }
 
 void PyramidData::initialize(const SiftParams &params)
@@ -26,8 +32,12 @@ void PyramidData::initialize(const SiftParams &params)
     }
     _grad = nm::device_vector<float2>(num_pixels * _num_dogs, make_float2(0, 0));
     _buffer = nm::device_vector<float>(num_pixels);
-    _count = nm::device_vector<int>(1);
-    _compact_ws = nm::device_vector<int>(nm_compact_workspace_bytes((int)num_pixels) / sizeof(int) + 1);
+    _count = nm::device_vector<int>(4);
+    _compact_ws = nm::device_vector<int>(nm_compact3_workspace_bytes((int)num_pixels) / sizeof(int) + 1);
+    for (auto &d : _dirty) d = 0;                      // every dense map is all -1 now
+    if (!_host_counts)
+        nm_check((int)hipHostMalloc(reinterpret_cast<void **>(&_host_counts), 4 * sizeof(int), hipHostMallocDefault),
+                 "pinned counter allocation");
     generate_kernels(params);
 }
 
@@ -56,7 +66,27 @@ void PyramidData::gpu_collate_keypoints_for_level(int level, int num_pixels)
              "Keypoint collation failed");
     int new_size = 0;   // the reference's copy_if returns a host iterator: same implicit synchronisation point
     nm_check((int)hipMemcpy(&new_size, _count.data(), sizeof(int), hipMemcpyDeviceToHost), "Keypoint count D2H");
-    _orientations[level] = nm::device_vector<float2>((size_t)new_size, make_float2(-1, -1));
+    _orientations[level].resize_uninitialized((size_t)new_size);     // (-1,-1) per keypoint, without re-allocating
+    if (new_size > 0) {
+        nm_check(nm_fill_u32(_orientations[level].data(), (size_t)new_size * 2, 0xBF800000u, nullptr), "orientation reset");
+        nm_check((int)hipStreamSynchronize(nullptr), "orientation reset");
+    }
+}
+
+void PyramidData::gpu_collate_keypoints_for_octave(int num_pixels, int counts[3], hipStream_t stream)
+{
+    const float *dense[3];
+    float *out[3];
+    for (int l = 0; l < 3; ++l) {
+        dense[l] = reinterpret_cast<const float *>(_key_pts[l].data());
+        out[l] = reinterpret_cast<float *>(_collated_kpts[l].data());
+    }
+    nm_check(nm_compact_keypoints3(dense, num_pixels, out, _count.data(), _compact_ws.data(), stream),
+             "Keypoint collation failed");
+    nm_check((int)hipMemcpyAsync(_host_counts, _count.data(), 3 * sizeof(int), hipMemcpyDeviceToHost, stream),
+             "Keypoint count D2H");
+    nm_check((int)hipStreamSynchronize(stream), "Keypoint count D2H");
+    for (int l = 0; l < 3; ++l) counts[l] = _host_counts[l];
 }
 
 void PyramidData::generate_kernels(const SiftParams &params)

@@ -14,23 +14,34 @@
 
 // The reference transposes A, builds the transposed matrix, transposes it back and scans rows (siftfunctions.cu:21-39).
 // Here one fused MFMA pass finds the candidates and the exact pass decides; `distance` is filled only when asked for.
+// Asynchronous on `stream`: the scratch lives in A (grow-only), nothing is allocated or synchronised per call.
 void compute_sift_matches(SiftData *A, SiftData *B, float *distance, float ambiguity, hipStream_t stream)
 {
     const int A_size = A->_num_items;
     const int B_size = B->_num_items;
     if (A_size <= 0 || B_size <= 0) return;
-    nm::device_vector<int> ws(nm_sift_match_workspace_bytes(A_size, B_size) / sizeof(int) + 1);
+    const size_t need = nm_sift_match_workspace_bytes(A_size, B_size) / sizeof(int) + 1;
+    if (A->_match_workspace.size() < need) {
+        // sized for the container's capacity so that later calls with more keypoints do not grow it again
+        const int cap_a = A->_capacity > A_size ? A->_capacity : A_size, cap_b = B->_capacity > B_size ? B->_capacity : B_size;
+        nm_check((int)hipStreamSynchronize(stream), "SIFT matching failed");      // an earlier match may still use the old one
+        A->_match_workspace = nm::device_vector<int>();
+        A->_match_workspace.resize_uninitialized(nm_sift_match_workspace_bytes(cap_a, cap_b) / sizeof(int) + 1);
+    }
     nm_check(nm_sift_match_f32(A->_desc.data(), A_size, B->_desc.data(), B_size, distance, A->_match_indexes.data(),
-                               ambiguity, ws.data(), stream),
+                               ambiguity, A->_match_workspace.data(), stream),
              "SIFT matching failed");
-    nm_check((int)hipStreamSynchronize(stream), "SIFT matching failed");   // ws is released on return
 }
 
 void compute_dog(PyramidData &pydata, const int octave_width, const int octave_height, hipStream_t stream)
 {
-    for (int i = 0; i < pydata._num_dogs; ++i)
-        subtract<float>(pydata._octave[i + 1].data(), pydata._octave[i].data(), pydata._dog[i].data(), octave_width,
-                        octave_height, stream);
+    const float *a[19], *b[19];
+    float *c[19];
+    const int n = pydata._num_dogs;
+    for (int i = 0; i < n; ++i) { a[i] = pydata._octave[i + 1].data(); b[i] = pydata._octave[i].data(); c[i] = pydata._dog[i].data(); }
+    for (int i = 0; i < n; i += 8)         // one launch per 8 planes (5 in the SIFT configuration)
+        nm_check(nm_subtract_batch_f32(n - i < 8 ? n - i : 8, a + i, b + i, c + i, octave_width, octave_height, stream),
+                 "Subtract launch failed");
 }
 
 void compute_gradients(PyramidData &pydata, const SiftParams &params, const int octave_width, const int octave_height,
@@ -38,18 +49,46 @@ void compute_gradients(PyramidData &pydata, const SiftParams &params, const int 
 {
     float2 *g = pydata._grad.data();
     const size_t offset = (size_t)octave_width * octave_height;
-    for (int i = params._level_min + 1; i <= params._level_max - 2; ++i)
-        gradient<float>(pydata._octave[i + 1].data(), g + i * offset, octave_width, octave_height, stream);
+    const float *src[19];
+    float *dst[19];
+    int n = 0;
+    for (int i = params._level_min + 1; i <= params._level_max - 2; ++i, ++n) {
+        src[n] = pydata._octave[i + 1].data();
+        dst[n] = reinterpret_cast<float *>(g + i * offset);
+    }
+    for (int i = 0; i < n; i += 3)
+        nm_check(nm_gradient_batch_f32(n - i < 3 ? n - i : 3, src + i, dst + i, octave_width, octave_height, stream),
+                 "Set gradient launch failed");
 }
 
 static void keypoints_impl(PyramidData &pydata, const SiftParams &params, const float *mask, int mask_w, int mask_h,
                            const int octave, const int ow, const int oh, hipStream_t stream)
 {
     const float xper = std::pow(2.0, octave);
-    for (int i = 1; i < pydata._num_dogs - 1; ++i) {
-        // the whole full-resolution map is reset, as in the reference (siftfunctions.cu:120-121)
+    const size_t region = (size_t)ow * oh;
+    if (pydata._num_dogs == 5 && params._num_dog_levels == 3) {
+        // The reference resets the whole full-resolution maps and lets the kernel write the keypoints (siftfunctions.cu:
+        // 120-125). Here the fused kernel writes EVERY pixel of the octave's region (keypoint or -1), so only what an
+        // earlier, larger octave may have left beyond the region is reset: same final contents, ~6x fewer bytes.
+        for (int l = 0; l < 3; ++l) {
+            if (pydata._dirty[l] > region)
+                nm_check(nm_fill_u32(pydata._key_pts[l].data() + region, (pydata._dirty[l] - region) * 4, 0xBF800000u, stream),
+                         "Keypoint map reset failed");
+            pydata._dirty[l] = region < pydata._key_pts[l].size() ? region : pydata._key_pts[l].size();
+        }
+        const float *dog[5];
+        float *res[3];
+        for (int i = 0; i < 5; ++i) dog[i] = pydata._dog[i].data();
+        for (int l = 0; l < 3; ++l) res[l] = reinterpret_cast<float *>(pydata._key_pts[l].data());
+        nm_check(nm_find_keypoints3_f32(dog, mask, mask_w, mask_h, ow, oh, params._peak_threshold, params._edge_threshold,
+                                        xper, params._sigma_0, params._num_dog_levels, res, stream),
+                 "Keypoint detection launch failed");
+        return;
+    }
+    for (int i = 1; i < pydata._num_dogs - 1; ++i) {    // any other level structure: level by level, as the reference
         nm_check(nm_fill_u32(pydata._key_pts[i - 1].data(), pydata._key_pts[i - 1].size() * 4, 0xBF800000u, stream),
                  "Keypoint map reset failed");
+        pydata._dirty[i - 1] = region;
         if (mask)
             find_keypoints(pydata._dog[i].data(), mask, mask_w, mask_h, pydata._dog[i - 1].data(),
                            pydata._dog[i + 1].data(), ow, oh, params._peak_threshold, params._edge_threshold, xper,
@@ -74,11 +113,38 @@ void compute_keypoints_with_mask(PyramidData &pydata, SiftParams &params, const 
     keypoints_impl(pydata, params, mask, mask_width, mask_height, octave, octave_width, octave_height, stream);
 }
 
+void compute_keypoints_with_mask(PyramidData &pydata, SiftParams &params, NmTexture mask, const int octave,
+                                 const int octave_width, const int octave_height, hipStream_t stream)
+{
+    if (mask.format != NM_TEXEL_F32) RUNTIME_EXCEPTION("compute_keypoints_with_mask: the mask texture must hold floats");
+    keypoints_impl(pydata, params, static_cast<const float *>(mask.data), mask.width, mask.height, octave, octave_width,
+                   octave_height, stream);
+}
+
 void compute_orientations(PyramidData &pydata, const SiftParams &params, const int octave, const int octave_width,
                           const int octave_height, hipStream_t stream)
 {
     const float xper = std::pow(2.0, octave);
     const int num_pixels_for_octave = octave_width * octave_height;
+    if (params._num_dog_levels == 3) {
+        // one batched collation and ONE host synchronisation for the octave (the reference synchronises per level)
+        int counts[3];
+        pydata.gpu_collate_keypoints_for_octave(num_pixels_for_octave, counts, stream);
+        const float *kp[3];
+        float *res[3];
+        int n[3], levels = 0;
+        for (int i = 0; i < 3; ++i) {
+            pydata._orientations[i].resize_uninitialized((size_t)counts[i]);
+            if (counts[i] == 0) break;                     // an empty level ends the octave (siftfunctions.cu:145)
+            kp[levels] = reinterpret_cast<const float *>(pydata._collated_kpts[i].data());
+            res[levels] = reinterpret_cast<float *>(pydata._orientations[i].data());
+            n[levels++] = counts[i];
+        }
+        nm_check(nm_detect_orientations_levels(levels, kp, n, reinterpret_cast<const float *>(pydata._grad.data()),
+                                               octave_width, octave_height, 1.5f, xper, res, stream),
+                 "Orientation histogram launch failed");
+        return;
+    }
     if (stream) nm_check((int)hipStreamSynchronize(stream), "stream sync");   // collation runs on the NULL stream
     for (int i = 0; i < params._num_dog_levels; ++i) {
         pydata.gpu_collate_keypoints_for_level(i, num_pixels_for_octave);
@@ -92,18 +158,34 @@ void compute_descriptors(PyramidData &pydata, const SiftParams &params, const in
                          const int octave_height, SiftData &data, hipStream_t stream)
 {
     const float xper = std::pow(2.0, octave);
+    const float *kp[3], *ori[3];
+    float *desc[3], *xs[3], *ys[3];
+    int n[3], levels = 0;
     for (int i = 0; i < params._num_dog_levels; ++i) {
-        if (pydata._orientations[i].size() == 0) return;       // siftfunctions.cu:160
+        if (pydata._orientations[i].size() == 0) break;       // siftfunctions.cu:160
         int num_pts = (int)pydata._orientations[i].size();
         const int capacity = (int)(data._desc.size() / SIFT_VECTOR_SIZE);
         if (num_pts + data._num_items > capacity) num_pts = capacity - data._num_items;
         if (num_pts > 0) {
-            compute_sift_descriptors(pydata._collated_kpts[i].data(), pydata._orientations[i].data(),
-                                     pydata._grad.data(), num_pts, octave_width, octave_height,
-                                     params._num_dog_levels, xper,
-                                     data._desc.data() + (size_t)data._num_items * SIFT_VECTOR_SIZE,
-                                     data._x.data() + data._num_items, data._y.data() + data._num_items, stream);
+            kp[levels] = reinterpret_cast<const float *>(pydata._collated_kpts[i].data());
+            ori[levels] = reinterpret_cast<const float *>(pydata._orientations[i].data());
+            desc[levels] = data._desc.data() + (size_t)data._num_items * SIFT_VECTOR_SIZE;
+            xs[levels] = data._x.data() + data._num_items;
+            ys[levels] = data._y.data() + data._num_items;
+            n[levels++] = num_pts;
             data._num_items += num_pts;
         }
+        if (levels == 3 || i + 1 == params._num_dog_levels) {
+            nm_check(nm_compute_sift_descriptors_levels(levels, kp, ori, n, reinterpret_cast<const float *>(pydata._grad.data()),
+                                                        octave_width, octave_height, params._num_dog_levels, xper, desc,
+                                                        xs, ys, stream),
+                     "SIFT descriptor detection launch failed");
+            levels = 0;
+        }
     }
+    if (levels > 0)
+        nm_check(nm_compute_sift_descriptors_levels(levels, kp, ori, n, reinterpret_cast<const float *>(pydata._grad.data()),
+                                                    octave_width, octave_height, params._num_dog_levels, xper, desc, xs,
+                                                    ys, stream),
+                 "SIFT descriptor detection launch failed");
 }

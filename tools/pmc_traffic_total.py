@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Sum of HBM-side bytes over ALL dispatches whose kernel name contains a substring, from two rocprofv3 --pmc passes
+(FETCH_SIZE, WRITE_SIZE in KiB per dispatch; gfx950: FETCH_SIZE counts half of a wide streaming read, doubled here --
+MI355X_MICROARCH.md, HBM section).   usage: pmc_traffic_total.py <fetch_dir> <write_dir> <substring> <divide_by>"""
+import csv
+import glob
+import sys
+
+
+def total(path, name, sub):
+    t, n = 0.0, 0
+    for f in glob.glob(path + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == name and sub in r["Kernel_Name"]:
+                t += float(r["Counter_Value"]); n += 1
+    return t, n
+
+
+sub, div = sys.argv[3], float(sys.argv[4])
+f, nf = total(sys.argv[1], "FETCH_SIZE", sub)
+w, nw = total(sys.argv[2], "WRITE_SIZE", sub)
+print("kernels matching %r: %d / %d dispatches; FETCH_SIZE raw %.1f MiB, WRITE_SIZE %.1f MiB; HBM bytes (2F+W) = %.1f MB "
+      "total = %.2f MB per unit (divided by %g)" % (sub, nf, nw, f / 1024, w / 1024, (2 * f + w) * 1024 / 1e6,
+                                                    (2 * f + w) * 1024 / 1e6 / div, div))
