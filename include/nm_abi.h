@@ -188,6 +188,23 @@ NM_API int nm_sift_match_shard_f32(const float *A, int nA, const float *B_shard,
 NM_API int nm_sift_match_merge_f32(const float *min1, const int *idx1, const float *min2, int n_shards, int nA,
                                    int *result, float ambiguity, void *stream);
 
+/* The whole sharded match as ONE call per rank (native counterpart of niftymatch_amd/parallel.py::match_sharded): every
+ * rank holds all of A and rows [index_offset, index_offset + nB_shard) of B; the call computes the shard triples, issues
+ * ONE ncclAllGather of 3 * nA int32 per rank (12 B per row: latency-bound, far below the per-link xGMI bandwidth) on
+ * `stream`, and merges the n_ranks triples in ascending rank order so that the lowest global index wins ties
+ * (match.cu:94-105). nccl_comm is the caller's ncclComm_t (RCCL), passed as void* to keep this header free of rccl.h;
+ * ncclAllGather is resolved from the running process, libnm_hip.so does not link librccl. n_ranks = 1 needs no
+ * communicator. Shards must be passed in rank order: rank g's index_offset = rows of B held by ranks < g.
+ * workspace: nm_sift_match_allgather_workspace_bytes(nA, nB_shard, n_ranks) bytes. No reference counterpart (single-GPU). */
+/* The merge step alone, on the buffer the all-gather produces: rank g's block is (min1[nA], idx1[nA], min2[nA]) as int32
+ * bit patterns at packed + g * 3 * nA. Ranks in ascending order = ascending global candidate index (Q14). */
+NM_API int nm_sift_match_merge_packed_f32(const int *packed, int n_shards, int nA, int *result, float ambiguity,
+                                          void *stream);
+NM_API size_t nm_sift_match_allgather_workspace_bytes(int nA, int nB_shard, int n_ranks);
+NM_API int nm_sift_match_allgather_f32(const float *A, int nA, const float *B_shard, int nB_shard, int index_offset,
+                                       int n_ranks, int *result, float ambiguity, void *workspace, void *nccl_comm,
+                                       void *stream);
+
 /* ---- "next" rows of SURVEY.md 8(f): the element-wise stages either side of the path ---- */
 /* cuda_grayscale<float> (kernels/bgra_2_gray.h:14-18, bgra_2_gray.cu:9-31): 0.07 B + 0.72 G + 0.21 R. bgra = uchar4. */
 NM_API int nm_grayscale_f32(const unsigned char *bgra, float *output, int width, int height, void *stream);

@@ -53,6 +53,9 @@ _SIGNATURES = {
     "nm_sift_match_fallback_count": (_I, [_P, _I, _I, _P, _P]),
     "nm_sift_match_shard_f32": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
     "nm_sift_match_merge_f32": (_I, [_P, _P, _P, _I, _I, _P, _F, _P]),
+    "nm_sift_match_merge_packed_f32": (_I, [_P, _I, _I, _P, _F, _P]),
+    "nm_sift_match_allgather_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "nm_sift_match_allgather_f32": (_I, [_P, _I, _P, _I, _I, _I, _P, _F, _P, _P, _P]),
     "nm_grayscale_f32": (_I, [_P, _P, _I, _I, _P]),
     "nm_extract_channel_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "nm_put_channel_f32": (_I, [_P, _P, _I, _I, _I, _P]),

@@ -84,6 +84,15 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("example build failed:\n%s\n%s" % (r.stdout, r.stderr))
+    # native multi-GPU example (RCCL): examples/allpairs_rccl.cpp -> lib/allpairs_rccl
+    example = os.path.join(ROOT, "..", "examples", "allpairs_rccl.cpp")
+    exe = os.path.join(LIBDIR, "allpairs_rccl")
+    if os.path.exists(example) and (force or not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(example), os.path.getmtime(LIB))):
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-O2", "-std=c++17", "-I", os.path.join(ROOT, "..", "include"), example,
+               "-L", LIBDIR, "-lnm_hip", "-lrccl", "-lpthread", "-Wl,-rpath,$ORIGIN", "-o", exe]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("example build failed:\n%s\n%s" % (r.stdout, r.stderr))
     if verbose:
         print("built", LIB)
     return LIB

@@ -15,6 +15,8 @@
 //   4. match_fallback_kernel (+ match_fallback_merge_kernel), which scan all candidates exactly (a fraction of a
 //                          percent of the queries), 64 candidate slices per listed query.
 // API building blocks (transpose / bf_distance / get_sift_matches) keep the reference's layouts and are exact.
+#include <dlfcn.h>
+
 #include "nm_common.hpp"
 #include "../../include/nm_abi.h"
 
@@ -71,6 +73,7 @@ static MatchPlan make_plan(int nA, int nB)
 struct MatchPair {
     const float *A, *B;
     float *na, *nb;
+    float *nbmax;              // max of the candidate norms (one float), for the finalize bound
     float4 *partial;
     float *partial3;
     int *fb_count, *fb_list;
@@ -116,6 +119,23 @@ __global__ __launch_bounds__(256) void norms_kernel(MatchBatch bt)
         acc = __builtin_fmaf(v.z, v.z, acc); acc = __builtin_fmaf(v.w, v.w, acc);
     }
     out[i] = acc;
+}
+
+// max_j ||b_j||^2 of every pair (one workgroup per pair): tightens the error bound of match_finalize_kernel.
+__global__ __launch_bounds__(1024) void nbmax_kernel(MatchBatch bt)
+{
+    __shared__ float s[16];
+    const MatchPair &c = bt.p[blockIdx.x];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < c.nB; i += 1024) m = __builtin_fmaxf(m, c.nb[i]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) m = __builtin_fmaxf(m, s[w]);
+        *c.nbmax = m;
+    }
 }
 
 // Running best / second best / third best of one lane's query, as integer KEYS. The MFMA pipe and the VALU do not overlap
@@ -468,12 +488,14 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(MatchBatch bt)
     //     => |d~(j) - d(j)| <= 2 gamma_129 (sqrt na + sqrt nb_j)^2 =: E_j
     //   * the reference chain sum fma(t,t,acc), t = fl(a_k - b_k), gives d_ref >= d (1 - gamma_130)
     //   * a key reports d~ with its low 5 mantissa bits replaced: |value - d~| < 2^-18 |d~|
-    // Suppose d_ref(j) <= m2. Then d(j) <= M := m2 (1 + gamma_131), sqrt nb_j <= sqrt na + sqrt M, so
-    // value(j) <= (M + 2 gamma_129 (2 sqrt na + sqrt M)^2) (1 + 2^-18) =: bound, and rest <= value(j) <= bound.
+    // Suppose d_ref(j) <= m2. Then d(j) <= M := m2 (1 + gamma_131), and sqrt nb_j <= min(sqrt na + sqrt M, sqrt nb_max)
+    // (triangle inequality; nb_max = the largest candidate norm, nbmax_kernel), so with s := min(2 sqrt na + sqrt M,
+    // sqrt na + sqrt nb_max):  value(j) <= (M + 2 gamma_129 s^2) (1 + 2^-18) =: bound, and rest <= value(j) <= bound.
     // Hence rest > bound proves the row; otherwise the row is re-scanned exactly. Deterministic for every input
     // (2 gamma_129 = 1.5378e-5; the constants below carry the slop of evaluating the bound itself in fp32).
     const float nai = na[i];
-    const float sq = 2.0f * __builtin_sqrtf(nai) + __builtin_sqrtf(m2);
+    const float sq = __builtin_fminf(2.0f * __builtin_sqrtf(nai) + __builtin_sqrtf(m2),
+                                     __builtin_sqrtf(nai) + __builtin_sqrtf(*c.nbmax));
     const float bound = (m2 * 1.00001f + 1.56e-5f * (sq * sq)) * 1.00001f;      // 1 + 2^-17 = 1.0000076
     const float margin = bound - m2;
     (void)margin;
@@ -485,12 +507,49 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(MatchBatch bt)
     emit_match(i, m1, idx, m2, mode, index_offset, ambiguity, result, min1_out, idx_out, min2_out);
 }
 
-// Exact fallback for the queries the finalize pass could not prove. A listed query is scanned exactly (the reference's own
-// arithmetic: one thread owns one candidate's 128-step fma chain) by FB_SPLIT workgroups, each over a contiguous slice of
-// the candidates -- typically 0-2 queries are listed, and one workgroup per query would leave the chip idle for ~100 us.
-// Slice results (min1, lowest index, multiset second minimum) go to `part`; match_fallback_merge_kernel combines them in
-// ascending slice order.
+// Exact squared distances, the reference's own arithmetic (match.cu:36-42): for every (row vector x, column vector y)
+//   acc = 0;  for k = 0..127:  t = x_k - y_k;  acc = fma(t, t, acc)
+// (fl(x - y) = -fl(y - x) exactly, so which operand is the query does not matter). This is VALU work by nature -- the
+// difference has to be formed per pair, so it is not a contraction an MFMA could take -- and its floor is two VALU
+// operations per (pair, k): 2 * 128 * rows * cols / 78.6e12 lane-ops/s = 481 us at 12k x 12k. A workgroup owns a 128 x 128
+// tile of the output, a thread an 8 x 8 register tile; the operands stream through LDS k-major in chunks of 32 k (two
+// b128 reads per operand feed 128 VALU operations: 1 LDS read per 32 VALU instead of the 17 per 32 of the round-1 kernel).
+// X: row-side set (nX vectors), Y: column-side set. Element (v, k) is S[v * 128 + k], or S[k * n + v] when K_MAJOR.
+// out[row * ld + col].
+constexpr int XD_TILE = 128, XD_KC = 32, XD_PITCH = XD_TILE + 4;
+
+template <bool K_MAJOR>
+__device__ __forceinline__ void xd_stage(float *__restrict__ dst, const float *__restrict__ S, int n, int v0, int kc, int tid)
+{
+    if (K_MAJOR) {           // S[k][v]: rows of the LDS image are contiguous in memory
+#pragma unroll
+        for (int it = 0; it < (XD_KC * XD_TILE) / 256; ++it) {
+            const int e = tid + 256 * it;
+            const int k = e >> 7, v = e & 127;
+            dst[k * XD_PITCH + v] = (v0 + v < n) ? S[(size_t)(kc + k) * n + v0 + v] : 0.f;
+        }
+    } else {                 // S[v][k]: 8 lanes read the 32 k of one vector (128 contiguous bytes), scattered k-major into LDS
+#pragma unroll
+        for (int it = 0; it < (XD_KC * XD_TILE) / (256 * 4); ++it) {
+            const int e = tid + 256 * it;
+            const int v = e >> 3, k4 = (e & 7) * 4;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v0 + v < n) x = *reinterpret_cast<const float4 *>(S + (size_t)(v0 + v) * DIM + kc + k4);
+            dst[(k4 + 0) * XD_PITCH + v] = x.x; dst[(k4 + 1) * XD_PITCH + v] = x.y;
+            dst[(k4 + 2) * XD_PITCH + v] = x.z; dst[(k4 + 3) * XD_PITCH + v] = x.w;
+        }
+    }
+}
+
+// Exact fallback for the queries the finalize pass could not prove: the listed rows are re-scanned against ALL candidates
+// with the reference's arithmetic, as a tiled exact-distance computation (128 listed rows x 128 candidates per step, 8 x 8
+// register tiles as in exact_distance_kernel) that keeps only the running (min1, lowest index, second minimum) of every
+// row. A workgroup owns one 128-row chunk of the list and one of FB_SPLIT contiguous candidate slices; slice results go to
+// `part` and match_fallback_merge_kernel combines them in ascending slice order. A candidate row is read once per chunk,
+// not once per listed row (the round-1 kernel scanned row by row: 9 ms for the 1.5 % of rows listed at 100k x 100k).
 constexpr int FB_SPLIT = 64;
+constexpr int FB_CHUNKS = 16;          // chunk loops in flight (gridDim.y); a workgroup strides over the chunks
+constexpr int FB_ROWWISE_MAX = 24;     // up to this many listed rows: one pass per row instead of 128-row tiles
 
 __device__ __forceinline__ void top2_merge(float &m1, int &i1, float &m2, float o1, int oi, float o2)
 {
@@ -507,51 +566,125 @@ __global__ __launch_bounds__(256) void match_fallback_kernel(MatchBatch bt)
     const MatchPair &c = bt.p[blockIdx.z];
     const float *__restrict__ A = c.A, *__restrict__ B = c.B;
     const int nB = c.nB;
-    const int *__restrict__ fb_count = c.fb_count, *__restrict__ fb_list = c.fb_list;
+    const int *__restrict__ fb_list = c.fb_list;
     float4 *__restrict__ part = c.partial;
-    __shared__ float s_m1[4], s_m2[4];
-    __shared__ int s_i1[4];
-    const int count = *fb_count;
-    const int slice = (nB + FB_SPLIT - 1) / FB_SPLIT;
+    __shared__ __attribute__((aligned(16))) float sX[XD_KC * XD_PITCH];
+    __shared__ __attribute__((aligned(16))) float sY[XD_KC * XD_PITCH];
+    const int count = *c.fb_count;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int slice = nm_divup_dev(nB, FB_SPLIT);
     const int j0 = blockIdx.x * slice, j1 = min(j0 + slice, nB);
-    for (int e = blockIdx.y; e < count; e += gridDim.y) {
-        const int i = fb_list[e];
-        __syncthreads();
-        float m1 = __builtin_inff(), m2 = __builtin_inff(); int i1 = 0x7fffffff;
-        if (j0 + (int)threadIdx.x < j1) {                      // uniform per wave except the last one of the slice
-            float4 x[DIM / 4];                                 // the query row lives in registers
+    if (count <= FB_ROWWISE_MAX) {
+        // a handful of rows (the usual case: 0-10 of 12k on SIFT descriptors): a 128-row tile would be almost empty, so
+        // each listed row is scanned by its own pass, one thread per candidate with the query row in registers
+        float *s_m1 = sX, *s_m2 = sX + 4;
+        int *s_i1 = reinterpret_cast<int *>(sX + 8);
+        for (int e = blockIdx.y; e < count; e += gridDim.y) {
+            const int i = fb_list[e];
+            __syncthreads();
+            float m1 = __builtin_inff(), m2 = __builtin_inff(); int i1 = 0x7fffffff;
+            if (j0 + tid < j1) {                                   // uniform per wave except the last one of the slice
+                float4 x[DIM / 4];
 #pragma unroll
-            for (int k = 0; k < DIM / 4; ++k) x[k] = reinterpret_cast<const float4 *>(A + (size_t)i * DIM)[k];
-            for (int j = j0 + threadIdx.x; j < j1; j += 256) {
-                const float4 *b = reinterpret_cast<const float4 *>(B + (size_t)j * DIM);
-                float4 y[DIM / 4];
+                for (int k = 0; k < DIM / 4; ++k) x[k] = reinterpret_cast<const float4 *>(A + (size_t)i * DIM)[k];
+                for (int j = j0 + tid; j < j1; j += 256) {
+                    const float4 *b = reinterpret_cast<const float4 *>(B + (size_t)j * DIM);
+                    float4 y[DIM / 4];
 #pragma unroll
-                for (int k = 0; k < DIM / 4; ++k) y[k] = b[k];
-                float acc = 0.0f;
+                    for (int k = 0; k < DIM / 4; ++k) y[k] = b[k];
+                    float acc = 0.0f;
 #pragma unroll
-                for (int k = 0; k < DIM / 4; ++k) {
-                    float tt;
-                    tt = x[k].x - y[k].x; acc = __builtin_fmaf(tt, tt, acc);
-                    tt = x[k].y - y[k].y; acc = __builtin_fmaf(tt, tt, acc);
-                    tt = x[k].z - y[k].z; acc = __builtin_fmaf(tt, tt, acc);
-                    tt = x[k].w - y[k].w; acc = __builtin_fmaf(tt, tt, acc);
+                    for (int k = 0; k < DIM / 4; ++k) {
+                        float tt;
+                        tt = x[k].x - y[k].x; acc = __builtin_fmaf(tt, tt, acc);
+                        tt = x[k].y - y[k].y; acc = __builtin_fmaf(tt, tt, acc);
+                        tt = x[k].z - y[k].z; acc = __builtin_fmaf(tt, tt, acc);
+                        tt = x[k].w - y[k].w; acc = __builtin_fmaf(tt, tt, acc);
+                    }
+                    if (acc < m1) { m2 = m1; m1 = acc; i1 = j; }
+                    else if (acc < m2) m2 = acc;
                 }
-                if (acc < m1) { m2 = m1; m1 = acc; i1 = j; }
-                else if (acc < m2) m2 = acc;
+            }
+#pragma unroll
+            for (int sft = 1; sft < 64; sft <<= 1) {
+                const float o1 = __shfl_xor(m1, sft), o2 = __shfl_xor(m2, sft);
+                const int oi = __shfl_xor(i1, sft);
+                top2_merge(m1, i1, m2, o1, oi, o2);
+            }
+            const int wave = tid >> 6;
+            if ((tid & 63) == 0) { s_m1[wave] = m1; s_m2[wave] = m2; s_i1[wave] = i1; }
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < 4; ++w) top2_merge(m1, i1, m2, s_m1[w], s_i1[w], s_m2[w]);
+                part[(size_t)e * FB_SPLIT + blockIdx.x] = make_float4(m1, __int_as_float(i1), m2, 0.f);
             }
         }
+        return;
+    }
+    for (int e0 = blockIdx.y * XD_TILE; e0 < count; e0 += gridDim.y * XD_TILE) {
+        float m1[8], m2[8]; int i1[8];
 #pragma unroll
-        for (int sft = 1; sft < 64; sft <<= 1) {
-            const float o1 = __shfl_xor(m1, sft), o2 = __shfl_xor(m2, sft);
-            const int oi = __shfl_xor(i1, sft);
-            top2_merge(m1, i1, m2, o1, oi, o2);
+        for (int i = 0; i < 8; ++i) { m1[i] = __builtin_inff(); m2[i] = __builtin_inff(); i1[i] = 0x7fffffff; }
+        for (int c0 = j0; c0 < j1; c0 += XD_TILE) {
+            float acc[8][8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+            for (int kc = 0; kc < DIM; kc += XD_KC) {
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < (XD_KC * XD_TILE) / (256 * 4); ++it) {       // listed query rows, gathered
+                    const int e = tid + 256 * it;
+                    const int v = e >> 3, k4 = (e & 7) * 4;
+                    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (e0 + v < count) x = *reinterpret_cast<const float4 *>(A + (size_t)fb_list[e0 + v] * DIM + kc + k4);
+                    sX[(k4 + 0) * XD_PITCH + v] = x.x; sX[(k4 + 1) * XD_PITCH + v] = x.y;
+                    sX[(k4 + 2) * XD_PITCH + v] = x.z; sX[(k4 + 3) * XD_PITCH + v] = x.w;
+                }
+                xd_stage<false>(sY, B, j1, c0, kc, tid);
+                __syncthreads();
+#pragma unroll 4
+                for (int k = 0; k < XD_KC; ++k) {
+                    const float4 xa = *reinterpret_cast<const float4 *>(&sX[k * XD_PITCH + ty * 8]);
+                    const float4 xb = *reinterpret_cast<const float4 *>(&sX[k * XD_PITCH + ty * 8 + 4]);
+                    const float4 ya = *reinterpret_cast<const float4 *>(&sY[k * XD_PITCH + tx * 8]);
+                    const float4 yb = *reinterpret_cast<const float4 *>(&sY[k * XD_PITCH + tx * 8 + 4]);
+                    const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+                    const float yv[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float t = xv[i] - yv[j];
+                            acc[i][j] = __builtin_fmaf(t, t, acc[i][j]);
+                        }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {                       // ascending candidate index within the thread
+                const int col = c0 + tx * 8 + j;
+                if (col < j1) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float d = acc[i][j];
+                        if (d < m1[i]) { m2[i] = m1[i]; m1[i] = d; i1[i] = col; }
+                        else if (d < m2[i]) m2[i] = d;
+                    }
+                }
+            }
         }
-        const int wave = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) { s_m1[wave] = m1; s_m2[wave] = m2; s_i1[wave] = i1; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int w = 1; w < 4; ++w) top2_merge(m1, i1, m2, s_m1[w], s_i1[w], s_m2[w]);
-            part[(size_t)e * FB_SPLIT + blockIdx.x] = make_float4(m1, __int_as_float(i1), m2, 0.f);
+        // the 16 threads that share a row: butterfly over tx (lanes of one wave), index breaks ties
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int sft = 1; sft < 16; sft <<= 1) {
+                const float o1 = __shfl_xor(m1[i], sft), o2 = __shfl_xor(m2[i], sft);
+                const int oi = __shfl_xor(i1[i], sft);
+                top2_merge(m1[i], i1[i], m2[i], o1, oi, o2);
+            }
+            const int e = e0 + ty * 8 + i;
+            if (tx == 0 && e < count) part[(size_t)e * FB_SPLIT + blockIdx.x] = make_float4(m1[i], __int_as_float(i1[i]), m2[i], 0.f);
         }
     }
 }
@@ -607,6 +740,28 @@ __global__ __launch_bounds__(256) void shard_neutral_kernel(float *__restrict__ 
     min1[i] = __builtin_inff(); idx1[i] = -1; min2[i] = MIN2_INIT;
 }
 
+// The same merge on the buffer an all-gather of per-rank (min1[nA], idx1[nA], min2[nA]) blocks produces: element c of row i
+// of rank g sits at packed[(g * 3 + c) * nA + i].
+__global__ __launch_bounds__(256) void match_merge_packed_kernel(const int *__restrict__ packed, int n_shards, int nA,
+                                                                float ambiguity, int *__restrict__ result)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nA) return;
+    float m1 = __int_as_float(packed[i]), m2 = __int_as_float(packed[2 * (size_t)nA + i]);
+    int idx = packed[(size_t)nA + i];
+    for (int g = 1; g < n_shards; ++g) {
+        const int *p = packed + (size_t)g * 3 * nA;
+        const float a1 = __int_as_float(p[i]), a2 = __int_as_float(p[2 * (size_t)nA + i]);
+        const int ai = p[(size_t)nA + i];
+        if (a1 < m1) { m2 = (m1 < a2) ? m1 : a2; m1 = a1; idx = ai; }
+        else { const float c = (a1 < m2) ? a1 : m2; m2 = c; }
+    }
+    if (m2 > 0) {
+        const float q = m1 / m2;
+        result[i] = (q < ambiguity) ? idx : -1;
+    }
+}
+
 // ---- exact API building blocks ----
 __global__ __launch_bounds__(256) void transpose_kernel(float *__restrict__ odata, const float *__restrict__ idata,
                                                        int width, int height)
@@ -623,40 +778,6 @@ __global__ __launch_bounds__(256) void transpose_kernel(float *__restrict__ odat
     for (int k = 0; k < 32; k += 8) {
         const int y = blockIdx.x * 32 + ty + k;                   // output row = input column
         if (x < height && y < width) odata[(size_t)y * height + x] = tile[tx][ty + k];
-    }
-}
-
-// Exact squared distances, the reference's own arithmetic (match.cu:36-42): for every (row vector x, column vector y)
-//   acc = 0;  for k = 0..127:  t = x_k - y_k;  acc = fma(t, t, acc)
-// (fl(x - y) = -fl(y - x) exactly, so which operand is the query does not matter). This is VALU work by nature -- the
-// difference has to be formed per pair, so it is not a contraction an MFMA could take -- and its floor is two VALU
-// operations per (pair, k): 2 * 128 * rows * cols / 78.6e12 lane-ops/s = 481 us at 12k x 12k. A workgroup owns a 128 x 128
-// tile of the output, a thread an 8 x 8 register tile; the operands stream through LDS k-major in chunks of 32 k (two
-// b128 reads per operand feed 128 VALU operations: 1 LDS read per 32 VALU instead of the 17 per 32 of the round-1 kernel).
-// X: row-side set (nX vectors), Y: column-side set. Element (v, k) is S[v * 128 + k], or S[k * n + v] when K_MAJOR.
-// out[row * ld + col].
-constexpr int XD_TILE = 128, XD_KC = 32, XD_PITCH = XD_TILE + 4;
-
-template <bool K_MAJOR>
-__device__ __forceinline__ void xd_stage(float *__restrict__ dst, const float *__restrict__ S, int n, int v0, int kc, int tid)
-{
-    if (K_MAJOR) {           // S[k][v]: rows of the LDS image are contiguous in memory
-#pragma unroll
-        for (int it = 0; it < (XD_KC * XD_TILE) / 256; ++it) {
-            const int e = tid + 256 * it;
-            const int k = e >> 7, v = e & 127;
-            dst[k * XD_PITCH + v] = (v0 + v < n) ? S[(size_t)(kc + k) * n + v0 + v] : 0.f;
-        }
-    } else {                 // S[v][k]: 8 lanes read the 32 k of one vector (128 contiguous bytes), scattered k-major into LDS
-#pragma unroll
-        for (int it = 0; it < (XD_KC * XD_TILE) / (256 * 4); ++it) {
-            const int e = tid + 256 * it;
-            const int v = e >> 3, k4 = (e & 7) * 4;
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (v0 + v < n) x = *reinterpret_cast<const float4 *>(S + (size_t)(v0 + v) * DIM + kc + k4);
-            dst[(k4 + 0) * XD_PITCH + v] = x.x; dst[(k4 + 1) * XD_PITCH + v] = x.y;
-            dst[(k4 + 2) * XD_PITCH + v] = x.z; dst[(k4 + 3) * XD_PITCH + v] = x.w;
-        }
     }
 }
 
@@ -801,7 +922,7 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
         const MatchWs w = carve(j.workspace, j.nA, j.nB, plans[q]);
         MatchPair &c = bt.p[q];
         c.A = j.A; c.B = j.B; c.nA = j.nA; c.nB = j.nB; c.na = w.na; c.nb = w.nb; c.partial = w.partial;
-        c.partial3 = w.partial3; c.fb_count = w.fb_count; c.fb_list = w.fb_list; c.S = plans[q].S; c.mode = j.mode;
+        c.partial3 = w.partial3; c.fb_count = w.fb_count; c.fb_list = w.fb_list; c.nbmax = reinterpret_cast<float *>(w.fb_count + 16); c.S = plans[q].S; c.mode = j.mode;
         c.index_offset = j.index_offset; c.result = j.result; c.min1 = j.min1; c.min2 = j.min2; c.idx1 = j.idx1;
         if (j.nA >= (1 << 22) || j.nB >= (1 << 22)) return (int)hipErrorInvalidValue;   // 32-bit byte ranges of the SRDs
         max_rows = max(max_rows, j.nA + nm_divup(j.nB, TILE_C) * TILE_C);
@@ -809,6 +930,8 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
     }
     if (bt.n == 0) return 0;
     hipLaunchKernelGGL(norms_kernel, dim3(nm_divup(max_rows, 256), bt.n), dim3(256), 0, st, bt);
+    NM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nbmax_kernel, dim3(bt.n), dim3(1024), 0, st, bt);
     NM_LAUNCH_CHECK();
     const size_t lds_bytes = (size_t)2 * TILE_C * KP * sizeof(float);
     // per call: the attribute is per device, and a process may drive several (cheap host-side call, not a stream op)
@@ -827,7 +950,7 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
     static_assert(FB_SPLIT <= MAX_CHUNKS, "fallback slices reuse the partial area");
     // few rows are ever listed (0-2 of 12k on SIFT data): a small grid drains fastest when the list is empty, and its
     // workgroups loop over the entries when it is not
-    hipLaunchKernelGGL(match_fallback_kernel, dim3(FB_SPLIT, 8, bt.n), dim3(256), 0, st, bt);
+    hipLaunchKernelGGL(match_fallback_kernel, dim3(FB_SPLIT, FB_CHUNKS, bt.n), dim3(256), 0, st, bt);
     NM_LAUNCH_CHECK();
     hipLaunchKernelGGL(match_fallback_merge_kernel, dim3(8, bt.n), dim3(256), 0, st, bt);
     NM_LAUNCH_CHECK();
@@ -943,6 +1066,64 @@ int nm_sift_match_shard_f32(const float *A, int nA, const float *B_shard, int nB
     }
     return run_fused(A, nA, B_shard, nB_shard, 1, index_offset, 0.f, nullptr, min1, idx1, min2, workspace,
                      nm_stream(stream));
+}
+
+// ---- native multi-GPU entry: shard -> ONE ncclAllGather of 12 B per row per rank -> merge ----
+// RCCL is resolved at run time from the process (the caller created the communicator, so its RCCL is loaded already;
+// torch ships its own copy): libnm_hip.so has no link-time dependency on librccl.
+typedef int (*NmAllGatherFn)(const void *, void *, size_t, int, void *, hipStream_t);
+static NmAllGatherFn nm_resolve_allgather()
+{
+    static NmAllGatherFn fn = [] {
+        void *sym = dlsym(RTLD_DEFAULT, "ncclAllGather");
+        if (!sym) {
+            void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (h) sym = dlsym(h, "ncclAllGather");
+        }
+        return reinterpret_cast<NmAllGatherFn>(sym);
+    }();
+    return fn;
+}
+
+int nm_sift_match_merge_packed_f32(const int *packed, int n_shards, int nA, int *result, float ambiguity, void *stream)
+{
+    if (nA <= 0 || n_shards <= 0) return 0;
+    if (!packed || !result) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(match_merge_packed_kernel, dim3(nm_divup(nA, 256)), dim3(256), 0, nm_stream(stream), packed, n_shards,
+                       nA, ambiguity, result);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+size_t nm_sift_match_allgather_workspace_bytes(int nA, int nB_shard, int n_ranks)
+{
+    if (nA < 0) nA = 0;
+    if (n_ranks < 1) n_ranks = 1;
+    return pair_workspace_bytes(nA, nB_shard) + align256((size_t)3 * nA * 4) + align256((size_t)n_ranks * 3 * nA * 4);
+}
+
+int nm_sift_match_allgather_f32(const float *A, int nA, const float *B_shard, int nB_shard, int index_offset, int n_ranks,
+                                int *result, float ambiguity, void *workspace, void *nccl_comm, void *stream)
+{
+    if (nA <= 0) return 0;
+    if (!A || !result || !workspace || n_ranks < 1 || (n_ranks > 1 && !nccl_comm)) return (int)hipErrorInvalidValue;
+    hipStream_t st = nm_stream(stream);
+    char *base = static_cast<char *>(workspace) + pair_workspace_bytes(nA, nB_shard);
+    int *mine = reinterpret_cast<int *>(base);
+    int *gathered = reinterpret_cast<int *>(base + align256((size_t)3 * nA * 4));
+    int rc = nm_sift_match_shard_f32(A, nA, B_shard, nB_shard, index_offset, reinterpret_cast<float *>(mine), mine + nA,
+                                     reinterpret_cast<float *>(mine + 2 * (size_t)nA), workspace, stream);
+    if (rc) return rc;
+    const int *merged_from = mine;
+    if (n_ranks > 1) {
+        const NmAllGatherFn allgather = nm_resolve_allgather();
+        if (!allgather) return (int)hipErrorNotSupported;                 // no RCCL in this process
+        const int nrc = allgather(mine, gathered, (size_t)3 * nA, /* ncclInt32 */ 2, nccl_comm, st);
+        if (nrc != 0) return (int)hipErrorUnknown;
+        merged_from = gathered;
+    }
+    return nm_sift_match_merge_packed_f32(merged_from, n_ranks, nA, result, ambiguity, stream);
 }
 
 int nm_sift_match_merge_f32(const float *min1, const int *idx1, const float *min2, int n_shards, int nA, int *result,

@@ -152,3 +152,17 @@ def test_abi_headers_are_plain_c(tmp_path, nm):
                            str(src), "-o", str(exe), "-L", libdir, "-lnm_hip", "-Wl,-rpath," + libdir])
     out = subprocess.check_output([str(exe)]).decode().split()
     assert out == ["48", "95", "256", "4"]
+
+
+def test_native_multi_gpu_entry_is_exported_and_sized(nm):
+    """The native sharded-match entry (shard -> ncclAllGather -> merge) is part of the C ABI, resolves RCCL lazily (the
+    library loads on a box without a GPU and without librccl in the process) and sizes its workspace monotonically."""
+    lib = nm.lib()
+    for name in ("nm_sift_match_allgather_f32", "nm_sift_match_allgather_workspace_bytes", "nm_sift_match_merge_packed_f32"):
+        assert hasattr(lib, name)
+    w1 = lib.nm_sift_match_allgather_workspace_bytes(100000, 12500, 1)
+    w8 = lib.nm_sift_match_allgather_workspace_bytes(100000, 12500, 8)
+    assert w8 - w1 >= 7 * 3 * 100000 * 4 - 1024 and w1 >= lib.nm_sift_match_workspace_bytes(100000, 12500) + 3 * 100000 * 4
+    import subprocess
+    out = subprocess.run(["readelf", "-d", nm.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rccl" not in out, "libnm_hip.so must not depend on librccl at link time"

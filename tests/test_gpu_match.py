@@ -317,3 +317,38 @@ def test_shard_with_empty_candidate_shard(nm, oracle, cuda):
     res = nm.sift_match_merge(torch.stack(m1s), torch.stack(ixs), torch.stack(m2s), 0.8)
     torch.cuda.synchronize()
     assert np.array_equal(res.cpu().numpy(), ref)
+
+
+def test_native_allgather_entry_and_packed_merge(nm, oracle, cuda):
+    """nm_sift_match_allgather_f32 (native multi-GPU entry). One rank: shard + merge without a communicator must equal
+    the unsharded match. Several ranks are emulated by laying the per-rank (min1, idx, min2) blocks out exactly as
+    ncclAllGather would (rank-major) and running the merge step on it: ascending rank order = lowest global index wins
+    a cross-shard tie (Q14, match.cu:94-105)."""
+    import torch
+    A = H.synth.descriptors(1, 1500)
+    B = H.synth.descriptors(2, 2100)
+    B[100] = B[1900]                                     # cross-shard duplicate: the lower global index must win
+    A[7] = B[1900] + np.float32(1e-3)
+    ref, _, _ = oracle.sift_matches(A, B, 1.5, want_distance=False)      # ambiguity 1.5: the tie (ratio 1) is reported
+    tA, tB = _t(A, cuda), _t(B, cuda)
+    lib = nm.lib()
+    res = torch.full((1500,), -1, dtype=torch.int32, device=cuda)
+    ws = torch.empty(lib.nm_sift_match_allgather_workspace_bytes(1500, 2100, 1), dtype=torch.uint8, device=cuda)
+    assert lib.nm_sift_match_allgather_f32(tA.data_ptr(), 1500, tB.data_ptr(), 2100, 0, 1, res.data_ptr(), 1.5,
+                                           ws.data_ptr(), None, None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(res.cpu().numpy(), ref) and ref[7] == 100
+    # more than one rank without a communicator is refused, not silently wrong
+    assert lib.nm_sift_match_allgather_f32(tA.data_ptr(), 1500, tB.data_ptr(), 2100, 0, 2, res.data_ptr(), 1.5,
+                                           ws.data_ptr(), None, None) != 0
+    bounds = [0, 700, 700, 1400, 2100]                   # four "ranks", the second one with an empty shard
+    blocks = []
+    for g in range(4):
+        b, e = bounds[g], bounds[g + 1]
+        m1, ix, m2 = nm.sift_match_shard(tA, tB[b:e], b)
+        blocks.append(torch.stack([m1.view(torch.int32), ix, m2.view(torch.int32)]))
+    packed = torch.stack(blocks).contiguous()            # (rank, 3, nA) = the all-gather's receive buffer
+    res2 = torch.full((1500,), -1, dtype=torch.int32, device=cuda)
+    assert lib.nm_sift_match_merge_packed_f32(packed.data_ptr(), 4, 1500, res2.data_ptr(), 1.5, None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(res2.cpu().numpy(), ref)
