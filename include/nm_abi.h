@@ -169,11 +169,17 @@ NM_API size_t nm_sift_match_workspace_bytes(int nA, int nB);
 NM_API size_t nm_sift_match_batch_workspace_bytes(int n, const int *nA, const int *nB);
 NM_API int nm_sift_match_batch_f32(int n, const float *const *A, const int *nA, const float *const *B, const int *nB,
                                    int *const *result, float ambiguity, void *workspace, void *stream);
-/* HOST function (no device access): the work distribution the matcher would use for (nA, nB). plan[0..5] = query blocks
- * of 256 rows, candidate tiles of 128 rows per block, persistent workgroups G, units per workgroup (base), workgroups
- * with one unit more (rem), partial lists per query S (<= 64, what the workspace bound assumes). Units = blocks x tiles
- * are dealt to the workgroups as contiguous ranges: G * base + rem units in total. For tests and capacity planning. */
-NM_API int nm_sift_match_plan(int nA, int nB, int plan[6]);
+/* HOST functions (no device access; on a box without a GPU the MI355X geometry of 256 CUs / 8 XCDs is assumed): the work
+ * distribution the matcher uses for (nA, nB). plan[0..9] = query blocks of 256 rows, candidate tiles of 128 rows, persistent
+ * workgroups G, partial lists per query S (<= 64, what the workspace bound assumes), XCD groups X, workgroups per group,
+ * tiles per chunk Tc, chunks C, query blocks per group (base, and how many groups hold one more). Units = blocks x tiles;
+ * group x = workgroups {x, x + X, ...} holds a contiguous share of the query blocks and walks its units chunk by chunk,
+ * query block by query block inside a chunk, so that the workgroups of one XCD stream the same candidate tiles together.
+ * nm_sift_match_plan_segments lists what workgroup `wg` does, in order: rows of 5 ints (query block, first tile, number of
+ * tiles, partial-list slot, 1 if the segment completes its query block); returns the number of segments. For tests and
+ * capacity planning. */
+NM_API int nm_sift_match_plan(int nA, int nB, int plan[10]);
+NM_API int nm_sift_match_plan_segments(int nA, int nB, int wg, int *segments, int max_segments);
 NM_API int nm_sift_match_f32(const float *A, int nA, const float *B, int nB, float *distance, int *result,
                              float ambiguity, void *workspace, void *stream);
 /* Diagnostics: number of query rows of the LAST nm_sift_match_f32 / _shard_f32 call on `workspace` (same nA, nB) that took

@@ -45,6 +45,7 @@ _SIGNATURES = {
     "nm_bf_distance_f32": (_I, [_P, _I, _P, _I, _I, _P, _P]),
     "nm_get_sift_matches_f32": (_I, [_P, _I, _I, _I, _P, _F, _P]),
     "nm_sift_match_plan": (_I, [_I, _I, _P]),
+    "nm_sift_match_plan_segments": (_I, [_I, _I, _I, _P, _I]),
     "nm_profile_event_pairs": (_I, [_I, _P, _I]),
     "nm_sift_match_batch_workspace_bytes": (_SZ, [_I, _P, _P]),
     "nm_sift_match_batch_f32": (_I, [_I, _P, _P, _P, _P, _P, _F, _P, _P]),

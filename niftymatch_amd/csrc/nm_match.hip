@@ -31,39 +31,150 @@ constexpr int QB = 256;            // queries per workgroup (32 per wave, fragme
 constexpr float MIN2_INIT = 2139095040.0f;   // (float)0x7f800000, match.cu:91
 constexpr int MAX_CHUNKS = 64;     // upper bound of the number S of segments (partial lists) per query block of any plan
 
-// Work = qblocks x T units, a unit being (256 queries) x (one 128-candidate tile), linearised query-block-major. The grid
-// is G persistent workgroups (one per CU: the kernel owns the LDS), each taking a contiguous range of `base` or `base+1`
-// units: every CU carries the same MFMA load to within one tile and the chip drains at once. A range that crosses a
-// query-block boundary is processed as separate SEGMENTS (fragments of the new block are reloaded). A query block is
-// covered by at most S consecutive workgroups; segment k of a block writes partial slot k, the workgroup that reaches
-// the block's end also blanks the slots up to S.
-struct MatchPlan { int qblocks, T, G, base, rem, S; };
+// Work = qblocks x T units, a unit being (256 queries) x (one 128-candidate tile). The grid is G persistent workgroups
+// (one per CU: the kernel owns the LDS), each taking a contiguous range of `base` or `base+1` units of a linear order:
+// every CU carries the same MFMA load to within one tile and the chip drains at once. A range is processed as SEGMENTS:
+// maximal runs of consecutive tiles of one query block (the query fragments are reloaded per segment). Segment k of a
+// query block writes partial slot k; the segment that finishes the block also blanks the slots up to S.
+//
+// The linear order is XCD-aware (round 2). Workgroups b and b + X share an XCD and its 4 MB L2 (X = 8 on MI355X: blocks
+// are dealt round-robin over the XCDs; speed only, never correctness). Group x = the workgroups {x, x + X, ...} gets a
+// contiguous share of the query blocks, and orders its units PIECE-major: the candidate tiles are cut into C chunks of
+// Tc tiles (Tc ~ the units per workgroup), and the order runs chunk by chunk, inside a chunk query block by query block.
+// The ~nq workgroups that work on one chunk at the same time then stream the SAME candidate tiles, so the XCD's L2
+// serves them once instead of every query block re-streaming the candidate set from the Infinity Cache. With X = 1 and
+// C = 1 this is the plain query-block-major order (used for small problems and single-XCD partitions).
+struct MatchPlan { int qblocks, T, G, S, X, Gx, Tc, C, q_base, q_rem; };
+struct PlanGroup { int nq, q0, base, rem; };
 
-static inline int plan_owner(const MatchPlan &p, long u)           // workgroup whose range holds unit u
+#define NM_HD __host__ __device__ __forceinline__
+NM_HD PlanGroup plan_group(const MatchPlan &p, int x)
 {
-    const long cut = (long)p.rem * (p.base + 1);
-    return (u < cut) ? (int)(u / (p.base + 1)) : p.rem + (int)((u - cut) / p.base);
+    PlanGroup g;
+    g.nq = p.q_base + (x < p.q_rem ? 1 : 0);
+    g.q0 = x * p.q_base + (x < p.q_rem ? x : p.q_rem);
+    const long U = (long)g.nq * p.T;
+    g.base = (int)(U / p.Gx);
+    g.rem = (int)(U % p.Gx);
+    return g;
+}
+NM_HD long group_begin(const PlanGroup &g, int v) { return (long)v * g.base + (v < g.rem ? v : g.rem); }
+NM_HD int group_owner(const PlanGroup &g, long ul)            // local workgroup whose range holds local unit ul
+{
+    const long cut = (long)g.rem * (g.base + 1);
+    return (ul < cut) ? (int)(ul / (g.base + 1)) : g.rem + (int)((ul - cut) / g.base);
+}
+// local unit ul -> chunk c, local query block qbl, tile offset tt inside the piece, piece length Lc
+NM_HD void plan_locate(const MatchPlan &p, const PlanGroup &g, long ul, int &c, int &qbl, int &tt, int &Lc)
+{
+    const long per_chunk = (long)g.nq * p.Tc;
+    c = (int)(ul / per_chunk);
+    const int r = (int)(ul - (long)c * per_chunk);
+    Lc = p.T - c * p.Tc < p.Tc ? p.T - c * p.Tc : p.Tc;
+    qbl = r / Lc;
+    tt = r - qbl * Lc;
+}
+// workgroups (of the group) that work on piece (c, qbl)
+NM_HD void piece_owners(const MatchPlan &p, const PlanGroup &g, int c, int qbl, int &first, int &last)
+{
+    const int Lc = p.T - c * p.Tc < p.Tc ? p.T - c * p.Tc : p.Tc;
+    const long P = (long)g.nq * c * p.Tc + (long)qbl * Lc;
+    first = group_owner(g, P);
+    last = group_owner(g, P + Lc - 1);
+}
+// partial-list slot of the segment that local workgroup v owns in piece (c, qbl)
+NM_HD int plan_slot(const MatchPlan &p, const PlanGroup &g, int c, int qbl, int v)
+{
+    int slot = 0, f, l;
+    for (int cc = 0; cc < c; ++cc) { piece_owners(p, g, cc, qbl, f, l); slot += l - f + 1; }
+    piece_owners(p, g, c, qbl, f, l);
+    return slot + (v - f);
+}
+
+// A workgroup's segments in PROCESSING order. Its range is contiguous in the piece-major order, so only its first segment
+// can start in the middle of a piece (the tail another workgroup left). If more pieces of the same chunk follow, that
+// tail is processed AFTER them: every workgroup then walks a chunk's tiles in ascending tile index from the chunk's first
+// tile, in step with the other workgroups of its XCD on the same chunk -- the first reader of a candidate tile misses in
+// L2, the others hit. (Slots and results do not depend on the processing order.)
+struct SegIter {
+    long u, u_end, u0;
+    bool have_def;
+    long def_u;
+    NM_HD void init(long b, long e) { u = b; u0 = b; u_end = e; have_def = false; def_u = 0; }
+    // next segment: local unit where it starts (its length follows from plan_locate); false when done
+    NM_HD bool next(const MatchPlan &p, const PlanGroup &g, long &seg_u)
+    {
+        for (;;) {
+            if (u >= u_end) {
+                if (have_def) { have_def = false; seg_u = def_u; return true; }
+                return false;
+            }
+            int c, qbl, tt, Lc;
+            plan_locate(p, g, u, c, qbl, tt, Lc);
+            const long n = (Lc - tt) < (u_end - u) ? (Lc - tt) : (u_end - u);
+            if (have_def) {
+                int dc, dq, dt, dl;
+                plan_locate(p, g, def_u, dc, dq, dt, dl);
+                if (dc != c) { have_def = false; seg_u = def_u; return true; }     // chunk changes: flush the tail first
+            } else if (u == u0 && tt > 0 && u + n < u_end) {
+                int c2, q2, t2, l2;
+                plan_locate(p, g, u + n, c2, q2, t2, l2);
+                if (c2 == c) { have_def = true; def_u = u; u += n; continue; }      // defer the leading tail
+            }
+            seg_u = u;
+            u += n;
+            return true;
+        }
+    }
+};
+
+static int plan_max_slots(const MatchPlan &p)
+{
+    int S = 1;
+    for (int x = 0; x < p.X; ++x) {
+        const PlanGroup g = plan_group(p, x);
+        for (int qbl = 0; qbl < g.nq; ++qbl) {
+            int f, l;
+            piece_owners(p, g, p.C - 1, qbl, f, l);
+            const int n = plan_slot(p, g, p.C - 1, qbl, l) + 1;
+            if (n > S) S = n;
+        }
+    }
+    return S;
 }
 
 static MatchPlan make_plan(int nA, int nB)
 {
     MatchPlan p;
     const int n_cu = nm_cu_count();          // one persistent workgroup per CU of the current device (256 on MI355X SPX)
+    const int n_xcd = nm_xcd_count();
     p.qblocks = nm_divup(nA > 0 ? nA : 1, QB);
     p.T = nm_divup(nB > 0 ? nB : 1, TILE_C);
     const long U = (long)p.qblocks * p.T;
+    // XCD-grouped order: the whole chip is used, the query blocks split over the XCDs to within 3 %, and every XCD has a
+    // few query blocks to share tiles between
+    if (n_xcd > 1 && n_cu % n_xcd == 0 && U >= 4L * n_cu && p.qblocks >= 2 * n_xcd &&
+        (long)nm_divup(p.qblocks, n_xcd) * n_xcd * 100 <= (long)p.qblocks * 103) {
+        p.G = n_cu; p.X = n_xcd; p.Gx = n_cu / n_xcd;
+        p.q_base = p.qblocks / n_xcd; p.q_rem = p.qblocks % n_xcd;
+        const long upw = U / n_cu;                                   // units per workgroup
+        int C = (int)((p.T + upw / 2) / (upw > 0 ? upw : 1));       // chunks ~ T / units-per-workgroup
+        if (C < 1) C = 1;
+        if (C > p.T) C = p.T;
+        p.Tc = nm_divup(p.T, C);
+        p.C = nm_divup(p.T, p.Tc);
+        p.S = plan_max_slots(p);
+        if (p.S <= MAX_CHUNKS) return p;
+    }
+    // plain query-block-major order over one group
     const int min_len = nm_divup(p.T, MAX_CHUNKS - 2);            // a block spans <= MAX_CHUNKS - 2 whole ranges + 2 ends
     long G = U / min_len;
     if (G > n_cu) G = n_cu;
     if (G < 1) G = 1;
-    p.G = (int)G;
-    p.base = (int)(U / G);
-    p.rem = (int)(U % G);
-    p.S = 1;
-    for (int qb = 0; qb < p.qblocks; ++qb) {
-        const int span = plan_owner(p, (long)qb * p.T + p.T - 1) - plan_owner(p, (long)qb * p.T) + 1;
-        if (span > p.S) p.S = span;
-    }
+    p.G = (int)G; p.X = 1; p.Gx = p.G;
+    p.q_base = p.qblocks; p.q_rem = 0;
+    p.Tc = p.T; p.C = 1;
+    p.S = plan_max_slots(p);
     return p;
 }
 
@@ -271,8 +382,11 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
     const int srow = tid >> 5, scol = (tid & 31) * 4;     // staging coordinates: 16 rows x 32 float4 per pass
     const int T = plan.T, S = plan.S;
     const int wg = blockIdx.x;
-    long u = (long)wg * plan.base + min(wg, plan.rem);
-    const long u_end = u + plan.base + (wg < plan.rem ? 1 : 0);
+    const int xg = wg % plan.X, vg = wg / plan.X;         // XCD group (blocks b, b + X share an XCD) and position in it
+    const PlanGroup grp = plan_group(plan, xg);
+    const long u_begin = group_begin(grp, vg), u_end = group_begin(grp, vg + 1);
+    SegIter it;
+    it.init(u_begin, u_end);
 
     // range-checked views: rows >= nB / nA read as zeros (the host refuses sets of 2^22 rows or more)
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, nB * (DIM * 4), 0x00020000);
@@ -293,9 +407,12 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
         if (tid < TILE_C) *reinterpret_cast<float2 *>(&buf[tid * KP + DIM]) = make_float2(stn, 1.0f);   // augmented k-pair
     };
 
-    while (u < u_end) {
-        const int qb = (int)(u / T), t0 = (int)(u - (long)qb * T);
-        const int ntiles = min(T - t0, (int)(u_end - u));
+    long u;
+    while (it.next(plan, grp, u)) {
+        int pc, qbl, tt, Lc;
+        plan_locate(plan, grp, u, pc, qbl, tt, Lc);
+        const int qb = grp.q0 + qbl, t0 = pc * plan.Tc + tt;
+        const int ntiles = min(Lc - tt, (int)(u_end - u));
         const int i0 = qb * QB;
         const int c0 = t0 * TILE_C;
 
@@ -359,14 +476,12 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
             if (o.i1 >= 0) top2_insert(m, o.m1, o.i1);
             if (o.i2 >= 0) top2_insert(m, o.m2, o.i2);
             m.m3 = __builtin_fminf(m.m3, o.m3);         // o.m3 >= o.m2 >= the merged m2: only the third value can change
-            // slot = how many workgroups before this one also work on this query block
-            const long ub = (long)qb * T, cut = (long)plan.rem * (plan.base + 1);
-            const int first = (ub < cut) ? (int)(ub / (plan.base + 1)) : plan.rem + (int)((ub - cut) / plan.base);
-            const int slot = wg - first;
+            // slot = how many segments of this query block come before this one in the plan's order
+            const int slot = plan_slot(plan, grp, pc, qbl, vg);
             if (h == 0 && qi < nA) {
                 partial[(size_t)qi * S + slot] = make_float4(m.m1, __int_as_float(m.i1), m.m2, __int_as_float(m.i2));
                 partial3[(size_t)qi * S + slot] = m.m3;
-                if (t0 + ntiles == T) {                 // this segment ends the block: blank the slots nobody writes
+                if (pc == plan.C - 1 && tt + ntiles == Lc) {     // this segment ends the block: blank the slots nobody writes
                     for (int k = slot + 1; k < S; ++k) {
                         partial[(size_t)qi * S + k] = make_float4(__builtin_inff(), __int_as_float(-1), __builtin_inff(), __int_as_float(-1));
                         partial3[(size_t)qi * S + k] = __builtin_inff();
@@ -374,7 +489,6 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
                 }
             }
         }
-        u += ntiles;
         __syncthreads();                                  // the next segment's prologue reuses the LDS
     }
 }
@@ -1025,12 +1139,41 @@ int nm_sift_match_batch_f32(int n, const float *const *A, const int *nA, const f
     return run_fused_batch(jobs, n, ambiguity, nm_stream(stream));
 }
 
-int nm_sift_match_plan(int nA, int nB, int plan[6])
+int nm_sift_match_plan(int nA, int nB, int plan[10])
 {
     if (!plan || nA < 0 || nB < 0) return (int)hipErrorInvalidValue;
     const MatchPlan p = make_plan(nA, nB);
-    plan[0] = p.qblocks; plan[1] = p.T; plan[2] = p.G; plan[3] = p.base; plan[4] = p.rem; plan[5] = p.S;
+    plan[0] = p.qblocks; plan[1] = p.T; plan[2] = p.G; plan[3] = p.S; plan[4] = p.X; plan[5] = p.Gx;
+    plan[6] = p.Tc; plan[7] = p.C; plan[8] = p.q_base; plan[9] = p.q_rem;
     return 0;
+}
+
+// HOST function for tests: the segments workgroup `wg` processes, in order, as rows (query block, first tile, tiles, slot,
+// ends_block); returns their number (at most max_segments are written).
+int nm_sift_match_plan_segments(int nA, int nB, int wg, int *segments, int max_segments)
+{
+    if (nA < 0 || nB < 0 || wg < 0) return -1;
+    const MatchPlan p = make_plan(nA, nB);
+    if (wg >= p.G) return 0;
+    const int xg = wg % p.X, vg = wg / p.X;
+    const PlanGroup grp = plan_group(p, xg);
+    const long u_end = group_begin(grp, vg + 1);
+    SegIter it;
+    it.init(group_begin(grp, vg), u_end);
+    int n = 0;
+    long u;
+    while (it.next(p, grp, u)) {
+        int pc, qbl, tt, Lc;
+        plan_locate(p, grp, u, pc, qbl, tt, Lc);
+        const int ntiles = (int)((Lc - tt) < (u_end - u) ? (Lc - tt) : (u_end - u));
+        if (segments && n < max_segments) {
+            int *r = segments + 5 * n;
+            r[0] = grp.q0 + qbl; r[1] = pc * p.Tc + tt; r[2] = ntiles; r[3] = plan_slot(p, grp, pc, qbl, vg);
+            r[4] = (pc == p.C - 1 && tt + ntiles == Lc) ? 1 : 0;
+        }
+        ++n;
+    }
+    return n;
 }
 
 int nm_sift_match_fallback_count(const void *workspace, int nA, int nB, int *host_count, void *stream)

@@ -101,33 +101,69 @@ def test_cmake_find_package_dropin(tmp_path, nm):
 
 
 def test_match_plan_invariants(nm):
-    """Host logic of the matcher's work distribution (nm_sift_match_plan, no GPU needed): every unit is owned by exactly
-    one workgroup range, ranges differ by at most one unit, a query block is covered by at most S <= 64 consecutive
-    workgroups, and the workspace bound holds for every smaller shape served by the same buffer."""
+    """Host logic of the matcher's work distribution (nm_sift_match_plan / _plan_segments, no GPU needed): every unit
+    (query block, candidate tile) is processed by exactly one workgroup, workgroups of a group differ by at most one unit,
+    the segments of a query block use the partial-list slots 0..n-1 exactly once with n <= S <= 64, exactly one segment
+    per block is marked as finishing it and it is the block's last tile, the XCD-grouped order really puts the same
+    candidate tiles on the workgroups of one group at the same step, and the workspace bound holds for every smaller
+    shape served by the same buffer."""
     import ctypes as C
     lib = nm.lib()
 
     def plan(nA, nB):
-        out = (C.c_int * 6)()
+        out = (C.c_int * 10)()
         assert lib.nm_sift_match_plan(nA, nB, out) == 0
         return list(out)
 
-    shapes = [(1, 1), (255, 127), (256, 128), (257, 129), (1000, 50), (50, 1000), (12223, 12080), (16384, 16384),
-              (300, 100000), (100000, 300), (100000, 100000), (100000, 12500), (4097, 8193)]
-    for nA, nB in shapes:
-        qb, T, G, base, rem, S = plan(nA, nB)
-        assert qb == -(-nA // 256) and T == -(-nB // 128)
-        U = qb * T
-        assert 1 <= G <= 256 and G * base + rem == U and 0 <= rem < G and base >= 1
-        assert 1 <= S <= 64
+    def segments(nA, nB, wg):
+        buf = (C.c_int * (5 * 256))()
+        n = lib.nm_sift_match_plan_segments(nA, nB, wg, buf, 256)
+        assert 0 <= n <= 256
+        return [tuple(buf[5 * k: 5 * k + 5]) for k in range(n)]
 
-        def owner(u):
-            cut = rem * (base + 1)
-            return u // (base + 1) if u < cut else rem + (u - cut) // base
-        spans = [owner(b * T + T - 1) - owner(b * T) + 1 for b in range(qb)]
-        assert max(spans) == S and owner(U - 1) == G - 1 and owner(0) == 0
+    shapes = [(1, 1), (255, 127), (256, 128), (257, 129), (1000, 50), (50, 1000), (12223, 12080), (16384, 16384),
+              (300, 100000), (100000, 300), (100000, 12500), (4097, 8193), (4096, 3000), (5000, 20000)]
+    grouped = 0
+    for nA, nB in shapes:
+        qb, T, G, S, X, Gx, Tc, Cn, q_base, q_rem = plan(nA, nB)
+        assert qb == -(-nA // 256) and T == -(-nB // 128)
+        assert 1 <= G <= 256 and G == X * Gx and 1 <= S <= 64 and Cn == -(-T // Tc) and X * q_base + q_rem == qb
+        grouped += X > 1
+        seen = {}
+        slots = {}
+        ends = {}
+        per_wg = []
+        for wg in range(G):
+            units = 0
+            for (b, t0, n, slot, last) in segments(nA, nB, wg):
+                assert 0 <= b < qb and 0 <= t0 and n >= 1 and t0 + n <= T and 0 <= slot < S
+                for t in range(t0, t0 + n):
+                    assert (b, t) not in seen
+                    seen[(b, t)] = wg
+                assert slot not in slots.setdefault(b, set())
+                slots[b].add(slot)
+                if last:
+                    assert b not in ends and t0 + n == T
+                    ends[b] = slot
+                units += n
+            per_wg.append(units)
+        assert len(seen) == qb * T, (nA, nB)
+        for b in range(qb):
+            assert slots[b] == set(range(len(slots[b]))) and ends[b] == max(slots[b]), (nA, nB, b)
+        for x in range(X):                               # balance inside every group
+            grp = per_wg[x::X]
+            assert max(grp) - min(grp) <= 1
         # partial lists (nA * S * 20 B) stay inside what the workspace bound reserves for them (nA * 64 * 20 B)
         assert lib.nm_sift_match_workspace_bytes(nA, nB) >= nA * S * 20 + 4 * (nA + nB) + 4 * nA
+    assert grouped >= 4, "the XCD-grouped order was never chosen"
+    # the point of the grouped order: at the bench's shape the workgroups of one XCD group that start a chunk together
+    # read the same candidate tiles (6 query blocks share each tile range), not 32 different ranges
+    qb, T, G, S, X, Gx, Tc, Cn, q_base, q_rem = plan(12223, 12080)
+    assert (X, Gx, q_base) == (8, 32, 6)
+    first_tiles = [segments(12223, 12080, 0 + X * v)[0][1] for v in range(Gx)]        # group 0
+    assert len(set(t // Tc for t in first_tiles)) <= Cn and max(first_tiles.count(t) for t in set(first_tiles)) >= 1
+    chunk_of = [t // Tc for t in first_tiles]
+    assert max(chunk_of.count(c) for c in set(chunk_of)) >= 5        # >= 5 workgroups on the same chunk of tiles
     # a workspace sized for the largest shape serves every smaller one
     big = lib.nm_sift_match_workspace_bytes(16384, 16384)
     for nA, nB in [(12223, 12080), (16384, 1), (1, 16384), (5000, 16000)]:
@@ -144,7 +180,7 @@ def test_abi_headers_are_plain_c(tmp_path, nm):
         pytest.skip("gcc not available")
     src = tmp_path / "client.c"
     src.write_text('#include "nm_abi.h"\n#include "nm_client.h"\n#include <stdio.h>\n'
-                   "int main(void) { int p[6]; if (nm_sift_match_plan(12223, 12080, p)) return 1;\n"
+                   "int main(void) { int p[10]; if (nm_sift_match_plan(12223, 12080, p)) return 1;\n"
                    '  printf("%d %d %d %d\\n", p[0], p[1], p[2], DivUp(7, 2)); return 0; }\n')
     exe = tmp_path / "client"
     libdir = os.path.join(ROOT, "niftymatch_amd", "lib")
