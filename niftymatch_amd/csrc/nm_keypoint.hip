@@ -270,7 +270,9 @@ constexpr int DET_ROWS = 4;      // image rows per workgroup: 6 rows are loaded 
 template <bool DENSE>
 __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
 {
-    __shared__ int s_cnt[2][4][3];
+    __shared__ unsigned char s_x[DET_ROWS][3][4][64];    // candidate lanes per (row, level, wave), in lane order
+    __shared__ int s_cnt[DET_ROWS * 12 + 1];              // sub-list lengths, then their exclusive scan (+ total)
+    __shared__ int s_acc[DET_ROWS * 3], s_last[DET_ROWS * 3], s_wtot[4], s_pref[257];
     const int frame = blockIdx.y;
     const float *const *dog = a.dog[frame];
     const int seg = blockIdx.x % a.nseg, yg = blockIdx.x / a.nseg;
@@ -335,52 +337,94 @@ __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
             m8[p] = max3f(rmax[p][s_up], rmax[p][s_dn], clr_max[p][cs]);
             n8[p] = min3f(rmin[p][s_up], rmin[p][s_dn], clr_min[p][cs]);
         }
-        bool f[3];
-        float4 kp[3];
 #pragma unroll
         for (int level = 0; level < 3; ++level) {
             const float cv = cmid[level + 1][cs];
             const bool is_max = cv > max3f(m9[level], m9[level + 2], m8[level + 1]);
             const bool is_min = cv < min3f(n9[level], n9[level + 2], n8[level + 1]);
-            f[level] = interior && ((cv <= thr && is_min) || (cv >= thr && is_max));
-            kp[level] = make_float4(-1.f, -1.f, -1.f, -1.f);
-            if (f[level])
-                f[level] = refine(dog[level + 1], dog[level], dog[level + 2], x, y, ow, a.peak, a.edge, a.xper,
-                                  a.sigma0, a.num_dogs, level, kp[level]);
+            const bool cand = interior && ((cv <= thr && is_min) || (cv >= thr && is_max));
+            // candidates are only LISTED here (per row, level and wave, in lane = column order); they are refined after the
+            // scan by consecutive lanes. Refining in place made whole waves run the ~150-instruction refinement for the
+            // one or two candidate lanes they hold, three times per row: most of the kernel's VALU work.
+            const unsigned long long m = __ballot(cand);
+            if (cand) s_x[j][level][wave][__popcll(m & ((1ull << lane) - 1ull))] = (unsigned char)lane;
+            if (lane == 0) s_cnt[(j * 3 + level) * 4 + wave] = __popcll(m);
+            if (DENSE && !cand && xin && y < oh)     // API path: every pixel of the dense maps is written exactly once
+                reinterpret_cast<float4 *>(a.dense[level])[(size_t)y * ow + x] = make_float4(-1.f, -1.f, -1.f, -1.f);
         }
-        if (DENSE) {                 // API path: the dense maps, every pixel (the caller never has to pre-fill this region)
-            if (xin && y < oh) {
+    }
+    __syncthreads();
+    // exclusive scan of the 48 sub-list lengths -> flattened candidate order (row, level, column): s_cnt[q] = first index
+    if (wave == 0) {
+        const int c = lane < DET_ROWS * 12 ? s_cnt[lane] : 0;
+        int incl = c;
 #pragma unroll
-                for (int level = 0; level < 3; ++level)
-                    reinterpret_cast<float4 *>(a.dense[level])[(size_t)y * ow + x] = kp[level];
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane < DET_ROWS * 12) s_cnt[lane] = incl - c;
+        if (lane == DET_ROWS * 12 - 1) s_cnt[DET_ROWS * 12] = incl;
+        if (lane < DET_ROWS * 3) s_acc[lane] = 0;
+    }
+    __syncthreads();
+    const int total = s_cnt[DET_ROWS * 12];
+    for (int b0 = 0; b0 < total; b0 += 256) {           // 256 candidates per pass (a 4 x 256 pixel unit usually holds < 100)
+        const int c = b0 + (int)threadIdx.x;
+        bool acc = false;
+        float4 kp = make_float4(-1.f, -1.f, -1.f, -1.f);
+        int g = 0, px = 0, py = 0, lvl = 0;
+        if (c < total) {
+            int lo = 0, hi = DET_ROWS * 12;               // largest q with s_cnt[q] <= c (empty sub-lists share their successor's start)
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_cnt[mid] <= c) lo = mid; else hi = mid;
             }
+            g = lo >> 2;                                  // (row, level) group
+            const int jr = g / 3, w = lo & 3;
+            lvl = g - 3 * jr;
+            px = seg * 256 + w * 64 + s_x[jr][lvl][w][c - s_cnt[lo]];
+            py = y0 + jr;
+            acc = refine(dog[lvl + 1], dog[lvl], dog[lvl + 2], px, py, ow, a.peak, a.edge, a.xper, a.sigma0, a.num_dogs, lvl, kp);
+        }
+        if (DENSE) {
+            if (c < total) reinterpret_cast<float4 *>(a.dense[lvl])[(size_t)py * ow + px] = kp;    // kp stays -1 when rejected
             continue;
         }
-        // ordered compaction of the row segment (= one unit), 3 levels with one barrier
-        int rank[3];
+        // ordered compaction of the accepted candidates inside their (row, level) group
+        const unsigned long long m = __ballot(acc);
+        const int in_wave = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wtot[wave] = __popcll(m);
+        __syncthreads();
+        int before = in_wave;
 #pragma unroll
-        for (int level = 0; level < 3; ++level) {
-            const unsigned long long m = __ballot(f[level]);
-            rank[level] = __popcll(m & ((1ull << lane) - 1ull));
-            if (lane == 0) s_cnt[j & 1][wave][level] = __popcll(m);
+        for (int w = 0; w < 4; ++w)
+            if (w < wave) before += s_wtot[w];
+        s_pref[threadIdx.x] = before;                     // accepted candidates of this pass before candidate c
+        if (threadIdx.x == 255) s_pref[256] = before + (acc ? 1 : 0);
+        __syncthreads();
+        if (c < total) {
+            const int gs = s_cnt[g * 4], ge = s_cnt[g * 4 + 4];       // the group's flattened range (s_cnt[48] = total)
+            const int base = max(gs, b0) - b0;
+            const int pos = s_acc[g] + before - s_pref[base];
+            if (acc) {
+                const int unit = py * a.nseg + seg;
+                float4 *st = reinterpret_cast<float4 *>(a.staging[frame]) + (size_t)lvl * a.stage_stride + (size_t)unit * 256;
+                st[pos] = kp;
+            }
+            if (c == min(ge, b0 + 256) - 1) s_last[g] = pos + (acc ? 1 : 0);     // accepted so far, this pass included
         }
         __syncthreads();
-        if (y < oh) {
-            const int unit = y * a.nseg + seg;
-#pragma unroll
-            for (int level = 0; level < 3; ++level) {
-                int off = 0, total = 0;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const int c = s_cnt[j & 1][w][level];
-                    if (w < wave) off += c;
-                    total += c;
-                }
-                float4 *st = reinterpret_cast<float4 *>(a.staging[frame]) + (size_t)level * a.stage_stride + (size_t)unit * 256;
-                if (f[level]) st[off + rank[level]] = kp[level];
-                if (threadIdx.x == 0) a.counts[frame][level * a.n_blocks + unit] = total;
-            }
+        if (threadIdx.x < DET_ROWS * 3) {
+            const int gs = s_cnt[threadIdx.x * 4], ge = s_cnt[threadIdx.x * 4 + 4];
+            if (ge > b0 && gs < b0 + 256 && ge > gs) s_acc[threadIdx.x] = s_last[threadIdx.x];
         }
+        __syncthreads();
+    }
+    if (!DENSE && threadIdx.x < DET_ROWS * 3) {           // per-unit counts of the three levels
+        const int jr = threadIdx.x / 3, lv = threadIdx.x - 3 * jr;
+        const int y = y0 + jr;
+        if (y < oh) a.counts[frame][lv * a.n_blocks + y * a.nseg + seg] = s_acc[threadIdx.x];
     }
 }
 
