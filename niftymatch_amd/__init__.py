@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnm_hip.so")
+LIB_PATH = os.environ.get("NM_HIP_LIB") or os.path.join(_HERE, "lib", "libnm_hip.so")     # NM_HIP_LIB: A/B diagnostics only
 _lib = None
 
 _F = C.c_float

@@ -451,15 +451,31 @@ __global__ __launch_bounds__(256) void conv_pk_kernel(NmConvBatch batch, int wid
         if (gx < width) {
             // input-level values around the 2 x 4 patch, from the interleaved tile: rows yy-1 .. yy+4, columns x-1 .. x+2
             const int cc = RA + 2 * xp;
-            auto in_at = [&](int rr, int c) -> float { return s_in[((rr >> 1) * IN_P2 + c) * 2 + (rr & 1)]; };
+            // One b128 read of the interleaved tile at an even column c returns (row 2p, c), (row 2p+1, c), (row 2p, c+1),
+            // (row 2p+1, c+1): the 6 x 4 patch comes from 3-4 row pairs x 3 aligned reads, conflict-free (a lane's address
+            // advances by 4 floats with xp), instead of 28 scalar reads that hit 8 banks 4 ways each.
+            constexpr int PAR = (R - 1) & 1;                  // parity of the first needed row (yg * NY is even)
+            constexpr int J0 = WRITE_GRAD ? 0 : 1, J1 = WRITE_GRAD ? NY + 1 : NY;      // rows j needed
+            constexpr int P0 = (PAR + J0) >> 1, P1 = (PAR + J1) >> 1;                  // row pairs relative to rp0
+            const int rp0 = (yg * NY + R - 1) >> 1;
+            float patch[2 * (P1 + 1)][4];                       // [row relative to 2 rp0][column x-1 .. x+2]
+#pragma unroll
+            for (int pp = P0; pp <= P1; ++pp) {
+                const float *base = &s_in[((rp0 + pp) * IN_P2 + cc) * 2];
+                const float4 m = *reinterpret_cast<const float4 *>(base);
+                patch[2 * pp][1] = m.x; patch[2 * pp + 1][1] = m.y; patch[2 * pp][2] = m.z; patch[2 * pp + 1][2] = m.w;
+                if (WRITE_GRAD) {
+                    const float4 l = *reinterpret_cast<const float4 *>(base - 4), rr4 = *reinterpret_cast<const float4 *>(base + 4);
+                    patch[2 * pp][0] = l.z; patch[2 * pp + 1][0] = l.w; patch[2 * pp][3] = rr4.x; patch[2 * pp + 1][3] = rr4.y;
+                }
+            }
             v2f mid[NY + 2], lft[NY + 2], rgt[NY + 2];      // columns (x, x+1), (x-1, x), (x+1, x+2) of each row
 #pragma unroll
             for (int j = 0; j < NY + 2; ++j) {
-                const int rr = yg * NY + R - 1 + j;
-                if (WRITE_GRAD || (j >= 1 && j <= NY)) mid[j] = (v2f){in_at(rr, cc), in_at(rr, cc + 1)};
+                if (WRITE_GRAD || (j >= 1 && j <= NY)) mid[j] = (v2f){patch[PAR + j][1], patch[PAR + j][2]};
                 if (WRITE_GRAD && j >= 1 && j <= NY) {
-                    lft[j] = (v2f){in_at(rr, cc - 1), in_at(rr, cc)};
-                    rgt[j] = (v2f){in_at(rr, cc + 1), in_at(rr, cc + 2)};
+                    lft[j] = (v2f){patch[PAR + j][0], patch[PAR + j][1]};
+                    rgt[j] = (v2f){patch[PAR + j][2], patch[PAR + j][3]};
                 }
             }
             const unsigned row_bytes = (unsigned)width * 4u;
