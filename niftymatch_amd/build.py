@@ -93,6 +93,17 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("example build failed:\n%s\n%s" % (r.stdout, r.stderr))
+    # diagnostic microbenchmarks (tools/micro/*.hip -> lib/<name>): what fp32 MFMA sustains on the device
+    micro = os.path.join(ROOT, "..", "tools", "micro")
+    if os.path.isdir(micro):
+        for f in sorted(os.listdir(micro)):
+            if not f.endswith(".hip"):
+                continue
+            src, exe = os.path.join(micro, f), os.path.join(LIBDIR, f[:-4])
+            if force or not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+                r = subprocess.run([HIPCC, "--offload-arch=" + ARCH, "-O3", src, "-o", exe], capture_output=True, text=True)
+                if r.returncode != 0:
+                    raise RuntimeError("microbenchmark build failed:\n%s\n%s" % (r.stdout, r.stderr))
     if verbose:
         print("built", LIB)
     return LIB
