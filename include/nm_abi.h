@@ -118,6 +118,15 @@ NM_API int nm_compact_keypoints(const float *dense, int num_pixels, float *out, 
 NM_API int nm_find_keypoints3_f32(const float *const dog[5], const float *mask, int mask_width, int mask_height,
                                   int width, int height, float peak_threshold, float edge_threshold, float xper,
                                   float sigma_0, int num_dogs, float *const result[3], void *stream);
+/* The frame driver's detection of one octave on caller-provided DoG planes: fused 3-level detection straight into ordered
+ * lists, no dense maps (what nm_sift_detect_describe does per octave). The orchestration rules of compute_orientations /
+ * compute_descriptors are applied: an empty level ends the octave (siftfunctions.cu:145,160), at most `capacity`
+ * keypoints in total (:165-169). out: capacity float4, the levels' raster-ordered lists back to back; d_counts: 3 device
+ * ints = keypoints kept per level. workspace: nm_find_keypoints3_compact_workspace_bytes(width, height) bytes.        */
+NM_API size_t nm_find_keypoints3_compact_workspace_bytes(int width, int height);
+NM_API int nm_find_keypoints3_compact_f32(const float *const dog[5], int width, int height, float peak_threshold,
+                                          float edge_threshold, float xper, float sigma_0, int num_dogs, int capacity,
+                                          float *out, int *d_counts, void *workspace, void *stream);
 /* nm_compact_keypoints for three dense maps at once (three launches instead of nine); d_counts: 3 device ints. */
 NM_API size_t nm_compact3_workspace_bytes(int num_pixels);
 NM_API int nm_compact_keypoints3(const float *const dense[3], int num_pixels, float *const out[3], int *d_counts,

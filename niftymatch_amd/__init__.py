@@ -33,6 +33,8 @@ _SIGNATURES = {
     "nm_subtract_batch_f32": (_I, [_I, _P, _P, _P, _I, _I, _P]),
     "nm_gradient_batch_f32": (_I, [_I, _P, _P, _I, _I, _P]),
     "nm_find_keypoints3_f32": (_I, [_P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _I, _P, _P]),
+    "nm_find_keypoints3_compact_workspace_bytes": (_SZ, [_I, _I]),
+    "nm_find_keypoints3_compact_f32": (_I, [_P, _I, _I, _F, _F, _F, _F, _I, _I, _P, _P, _P, _P]),
     "nm_compact3_workspace_bytes": (_SZ, [_I]),
     "nm_compact_keypoints3": (_I, [_P, _I, _P, _P, _P, _P]),
     "nm_detect_orientations_levels": (_I, [_I, _P, _P, _P, _I, _I, _F, _F, _P, _P]),

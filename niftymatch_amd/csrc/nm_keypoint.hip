@@ -493,7 +493,55 @@ int nm_launch_detect_octave(const NmDetectArgs &d, const NmScanArgs &s, const Nm
     return 0;
 }
 
+__global__ void book_counts_kernel(const NmFrameBook *book, int *counts)
+{
+    if (threadIdx.x < 3) counts[threadIdx.x] = book->lvl_n[0][threadIdx.x];
+}
+
 extern "C" {
+
+// The frame driver's detection of ONE octave on caller-provided DoG planes: fused 3-level detection straight into ordered
+// lists (no dense maps), with the orchestration rules of compute_orientations / compute_descriptors applied (an empty
+// level ends the octave, sift/siftfunctions.cu:145,160; at most `capacity` keypoints in total, :165-169). out: capacity
+// float4, the levels' raster-ordered lists back to back; d_counts: 3 device ints = keypoints kept per level.
+size_t nm_find_keypoints3_compact_workspace_bytes(int width, int height)
+{
+    const size_t nb = (size_t)(height > 0 ? height : 1) * nm_divup(width > 0 ? width : 1, 256);
+    return 3 * nb * 256 * 16 + 2 * 3 * nb * sizeof(int) + 1024;
+}
+
+int nm_find_keypoints3_compact_f32(const float *const dog[5], int width, int height, float peak_threshold,
+                                   float edge_threshold, float xper, float sigma_0, int num_dogs, int capacity, float *out,
+                                   int *d_counts, void *workspace, void *stream)
+{
+    if (width <= 0 || height <= 0 || capacity <= 0) return 0;
+    if (!dog || !out || !d_counts || !workspace) return (int)hipErrorInvalidValue;
+    hipStream_t st = nm_stream(stream);
+    const int nseg = nm_divup(width, 256), n_blocks = height * nseg;
+    char *base = static_cast<char *>(workspace);
+    NmFrameBook *book = reinterpret_cast<NmFrameBook *>(base);        // 1 KB reserved
+    float *staging = reinterpret_cast<float *>(base + 1024);
+    const size_t stage_stride = (size_t)n_blocks * 256;
+    int *counts = reinterpret_cast<int *>(base + 1024 + 3 * stage_stride * 16);
+    int *offsets = counts + 3 * (size_t)n_blocks;
+    static_assert(sizeof(NmFrameBook) <= 1024, "book fits its slot");
+    NmDetectArgs d{};
+    NmScanArgs s{};
+    NmGatherArgs g{};
+    d.n = s.n = g.n = 1;
+    d.ow = width; d.oh = height; d.peak = peak_threshold; d.edge = edge_threshold; d.xper = xper; d.sigma0 = sigma_0;
+    d.num_dogs = num_dogs; d.stage_stride = stage_stride; d.n_blocks = n_blocks; d.nseg = nseg;
+    for (int i = 0; i < 5; ++i) { if (!dog[i]) return (int)hipErrorInvalidValue; d.dog[0][i] = dog[i]; }
+    d.staging[0] = staging; d.counts[0] = counts;
+    s.counts[0] = counts; s.offsets[0] = offsets; s.book[0] = book; s.n_blocks = n_blocks; s.octave = 0; s.capacity = capacity;
+    g.staging[0] = staging; g.counts[0] = counts; g.offsets[0] = offsets; g.book[0] = book; g.kpts[0] = out;
+    g.stage_stride = stage_stride; g.n_blocks = n_blocks; g.octave = 0; g.capacity = capacity;
+    const int rc = nm_launch_detect_octave(d, s, g, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(book_counts_kernel, dim3(1), dim3(64), 0, st, book, d_counts);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
 
 int nm_find_keypoints_masked_f32(const float *current, const float *mask, int mask_width, int mask_height,
                                  const float *down, const float *up, int width, int height, float peak_threshold,

@@ -173,3 +173,60 @@ def test_cpp_api_match_with_and_without_distance(nm, oracle, cuda):
     res2 = np.full(700, -1, np.int32)
     assert nm.lib().nm_client_match(A.ctypes.data, 700, B.ctypes.data, 450, None, res2.ctypes.data, 0.8) == 0
     assert np.array_equal(res2, ref)
+
+
+@pytest.mark.parametrize("wh", [(520, 44), (256, 9), (1000, 12)])
+def test_dense_candidates_take_several_refinement_passes(nm, oracle, cuda, wh):
+    """detect_stage_kernel lists the candidates of a 4 x 256-pixel unit and refines them 256 at a time. Real scale spaces
+    put ~10 candidates into a unit; crafted DoG planes (noise in the searched planes, almost nothing in their neighbours:
+    22 % of the pixels are strict extrema) put 400-900 there, so the refinement runs 2-4 passes per unit with the accepted
+    counts carried between passes and the ordered compaction inside every (row, level) group crossing pass boundaries.
+    Both forms of the kernel against the oracle: the dense maps of the API and the compact ordered lists of the frame
+    driver (incl. the empty-level and capacity rules of the orchestration)."""
+    import torch
+    w, h = wh
+    rng = np.random.default_rng(w * 1000 + h)
+    big = lambda: (rng.uniform(-40, 40, (h, w))).astype(np.float32)
+    small = lambda: (rng.uniform(-1e-3, 1e-3, (h, w))).astype(np.float32)
+    dogs = [small(), big(), small(), big(), small()]
+    p = oracle.sift_params(1920, 1080)
+    dense_ref = [oracle.find_keypoints(dogs[l + 1], dogs[l], dogs[l + 2], p.peak_threshold, p.edge_threshold, 2.0, p.sigma_0, 3, l)
+                 for l in range(3)]
+    lists_ref = [oracle.compact_keypoints(d) for d in dense_ref]
+    def extrema(cur, dn, up):            # strict 26-neighbour extrema with the sign gating of keypoint.cu:195-196, interior only
+        c = cur[1:-1, 1:-1]
+        nb = [pl[1 + dy: pl.shape[0] - 1 + dy, 1 + dx: pl.shape[1] - 1 + dx] for pl in (cur, dn, up) for dy in (-1, 0, 1)
+              for dx in (-1, 0, 1) if not (pl is cur and dy == 0 and dx == 0)]
+        hi, lo = np.maximum.reduce(nb), np.minimum.reduce(nb)
+        return ((c >= 0) & (c > hi)) | ((c <= 0) & (c < lo))
+    cand = np.zeros((h - 2, w - 2), np.int32)
+    for l in range(3):
+        cand += extrema(dogs[l + 1], dogs[l], dogs[l + 2])
+    per_unit = max(int(cand[r0: r0 + 4, c0: c0 + 256].sum()) for r0 in range(0, h, 4) for c0 in range(0, w, 256))
+    assert per_unit > 300, "the planes are not dense enough to need several refinement passes (%d per unit)" % per_unit
+    tdog = [_t(d, cuda) for d in dogs]
+    arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    dense = [torch.full((h, w, 4), 5.0, dtype=torch.float32, device=cuda) for _ in range(3)]
+    assert nm.lib().nm_find_keypoints3_f32(arr(tdog), None, 0, 0, w, h, p.peak_threshold, p.edge_threshold, 2.0, p.sigma_0, 3,
+                                           arr(dense), None) == 0
+    torch.cuda.synchronize()
+    for l in range(3):
+        _eq(dense[l], dense_ref[l], "dense map level %d" % l)
+    for cap in (1 << 20, len(lists_ref[0]) + 7):                         # unclipped, and clipped inside level 1
+        cap = min(cap, 3 * w * h)
+        out = torch.full((cap, 4), -3.0, dtype=torch.float32, device=cuda)
+        cnt = torch.zeros(3, dtype=torch.int32, device=cuda)
+        ws = torch.empty(nm.lib().nm_find_keypoints3_compact_workspace_bytes(w, h), dtype=torch.uint8, device=cuda)
+        assert nm.lib().nm_find_keypoints3_compact_f32(arr(tdog), w, h, p.peak_threshold, p.edge_threshold, 2.0, p.sigma_0, 3,
+                                                       cap, out.data_ptr(), cnt.data_ptr(), ws.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        want, room, live = [], cap, True
+        for l in range(3):
+            n = len(lists_ref[l]) if live else 0
+            if n == 0:
+                live = False
+            n = min(n, room)
+            room -= n
+            want.append(lists_ref[l][:n])
+        assert cnt.cpu().tolist() == [len(x) for x in want]
+        _eq(out[: sum(len(x) for x in want)], np.concatenate(want), "compact ordered lists, capacity %d" % cap)
