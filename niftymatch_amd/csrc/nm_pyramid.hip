@@ -216,6 +216,15 @@ __device__ __forceinline__ v2f pk_fma(v2f a, float w, v2f c)
     return __builtin_elementwise_fma(a, ww, c);
 }
 
+// The same with the tap in a SCALAR register: op_sel_hi:[1,0,1] makes both halves of the packed FMA read the low dword of
+// the scalar pair, so a uniform weight needs no VGPR pair and no v_mov to build one (the kernel spent 24 % of its VALU
+// instructions on register moves, most of them broadcasting the 2R+1 taps into pairs for both passes).
+__device__ __forceinline__ v2f pk_fma_s(v2f a, unsigned long long wq, v2f c)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(c) : "v"(a), "s"(wq));
+    return c;
+}
+
 // RN(sqrt(s)) for s = 0 or 2^-96 <= s < 2^96 without the denormal-safe expansion; other inputs take the IEEE path.
 __device__ __forceinline__ float sqrt_rn_fast_core(float s)
 {
@@ -357,9 +366,9 @@ __global__ __launch_bounds__(256) void conv_pk_kernel(NmConvBatch batch, int wid
     float2 *__restrict__ grad = reinterpret_cast<float2 *>(batch.grad[frame]);
     float *__restrict__ down = batch.down[frame];
 
-    float w[2 * R + 1];
+    unsigned long long w[2 * R + 1];             // taps as scalar operands of v_pk_fma_f32 (low dword = the float)
 #pragma unroll
-    for (int i = 0; i <= 2 * R; ++i) w[i] = taps[i];
+    for (int i = 0; i <= 2 * R; ++i) w[i] = (unsigned long long)__float_as_uint(taps[i]);
 
     // phase 1: global -> LDS, two rows per thread, interleaved
     {
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(256) void conv_pk_kernel(NmConvBatch batch, int wid
 #pragma unroll
             for (int t = 0; t <= 2 * R; ++t) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) o[i] = pk_fma(win[D + i + t], w[2 * R - t], o[i]);
+                for (int i = 0; i < 8; ++i) o[i] = pk_fma_s(win[D + i + t], w[2 * R - t], o[i]);
             }
             float4 *qa = reinterpret_cast<float4 *>(&s_mid[(2 * p) * MID_P + cg * 8]);
             float4 *qb = reinterpret_cast<float4 *>(&s_mid[(2 * p + 1) * MID_P + cg * 8]);
@@ -444,7 +453,7 @@ __global__ __launch_bounds__(256) void conv_pk_kernel(NmConvBatch batch, int wid
 #pragma unroll
             for (int t = 0; t <= 2 * R; ++t) {
 #pragma unroll
-                for (int i = 0; i < NY; ++i) o[i] = pk_fma(win[i + t], w[2 * R - t], o[i]);
+                for (int i = 0; i < NY; ++i) o[i] = pk_fma_s(win[i + t], w[2 * R - t], o[i]);
             }
         }
         const int gx = x0 + 2 * xp;
