@@ -170,6 +170,12 @@ NM_API int nm_get_sift_matches_f32(const float *distance, int rows, int cols, in
  * (match.cu:107-116). Match decisions are made on distances recomputed exactly in the reference's summation
  * order; rows whose best two cannot be proven from the MFMA pass are re-scanned exactly. workspace: nm_sift_match_workspace_bytes(nA, nB) bytes of device scratch.                            */
 NM_API size_t nm_sift_match_workspace_bytes(int nA, int nB);
+/* Which MFMA screen the fused matcher runs before its exact finalize (process-wide; results are identical):
+ * 0 = fp32 (v_mfma_f32_32x32x2_f32 on the descriptors themselves), 1 = bf16x3 (v_mfma_f32_32x32x16_bf16 on operands
+ * split into two bf16 pieces: ~3x faster, a few more rows take the exact fallback). Default 1; the environment
+ * variable NM_MATCH_SCREEN=f32|bf16x3 sets the initial value. Extension: the reference has one (exact VALU) path. */
+NM_API int nm_sift_match_set_screen(int screen);
+NM_API int nm_sift_match_get_screen(void);
 /* n <= 16 independent matches in one call (arrays of n): the norms, finalize and fallback launches cover all pairs at
  * once (the pair is a grid dimension), only the MFMA kernel runs once per pair -- 4 + n stream operations instead of
  * 5 n. result[k] as in nm_sift_match_f32 (no distance matrices). workspace: nm_sift_match_batch_workspace_bytes bytes

@@ -52,6 +52,8 @@ _SIGNATURES = {
     "nm_sift_match_batch_workspace_bytes": (_SZ, [_I, _P, _P]),
     "nm_sift_match_batch_f32": (_I, [_I, _P, _P, _P, _P, _P, _F, _P, _P]),
     "nm_sift_match_workspace_bytes": (_SZ, [_I, _I]),
+    "nm_sift_match_set_screen": (_I, [_I]),
+    "nm_sift_match_get_screen": (_I, []),
     "nm_sift_match_f32": (_I, [_P, _I, _P, _I, _P, _P, _F, _P, _P]),
     "nm_sift_match_fallback_count": (_I, [_P, _I, _I, _P, _P]),
     "nm_sift_match_shard_f32": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
@@ -331,6 +333,19 @@ def sift_match_batch(As, Bs, nAs, nBs, results, ambiguity=0.8, workspace=None):
                                          arr([_dev(r, torch.int32) for r in results]), ambiguity, _dev(workspace.buf),
                                          _stream()), "nm_sift_match_batch_f32")
     return workspace
+
+
+MATCH_SCREENS = {"f32": 0, "bf16x3": 1}
+
+
+def set_match_screen(name):
+    """Select the MFMA screen of the fused matcher ("f32" or "bf16x3"; results are identical, see nm_abi.h)."""
+    _check(lib().nm_sift_match_set_screen(MATCH_SCREENS[name]), "nm_sift_match_set_screen")
+
+
+def get_match_screen():
+    v = lib().nm_sift_match_get_screen()
+    return [k for k, x in MATCH_SCREENS.items() if x == v][0]
 
 
 def match_fallback_count(workspace, nA, nB):

@@ -17,6 +17,10 @@
 // API building blocks (transpose / bf_distance / get_sift_matches) keep the reference's layouts and are exact.
 #include <dlfcn.h>
 
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+
 #include "nm_common.hpp"
 #include "../../include/nm_abi.h"
 
@@ -191,6 +195,8 @@ struct MatchPair {
     int *result;
     float *min1, *min2;
     int *idx1;
+    unsigned *As, *Bs;         // bf16x3 screen: split images of A (scaled by -2) and B, 512 B per row (hi | lo)
+    uint4 *nbslot;             // bf16x3 screen: the candidates' norm k-slots, padded to whole tiles
     int nA, nB, S, mode, index_offset;
 };
 constexpr int MATCH_MAX_BATCH = 16;
@@ -198,38 +204,82 @@ struct MatchBatch {
     MatchPair p[MATCH_MAX_BATCH];
     int n;
     float ambiguity;
+    float err_coeff;           // |screen value - exact d| <= err_coeff (sqrt na + sqrt nb)^2 for the screen in use
 };
 static_assert(sizeof(MatchBatch) <= 4096, "kernel arguments are limited to 4 KB");
 
 __device__ __forceinline__ int nm_divup_dev(int a, int b) { return (a + b - 1) / b; }
 
-// ||x||^2 of every row of A (nA rows) and B (nB rows) of every pair in one launch.
-__global__ __launch_bounds__(256) void norms_kernel(MatchBatch bt)
+// bf16 pieces. rne: round to nearest even (the guide's integer form; finite inputs). The split x = hi + lo + r has
+// |x - hi| <= 2^-8 |x| and |r| <= 2^-16 |x|  (bf16 carries 8 significant bits).
+__device__ __forceinline__ unsigned bf16_rne(float x)
+{
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void bf16_split(float x, unsigned &hi, unsigned &lo)
+{
+    hi = bf16_rne(x);
+    lo = bf16_rne(x - __uint_as_float(hi << 16));          // the difference is exact
+}
+// A non-negative float as the EXACT sum of three bf16 values (8 + 8 + 8 significant bits, by truncation).
+__device__ __forceinline__ void bf16_three(float n, unsigned &h, unsigned &m, unsigned &l)
+{
+    const unsigned uh = __float_as_uint(n) & 0xFFFF0000u;
+    const float r1 = n - __uint_as_float(uh);
+    const unsigned um = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(um);
+    h = uh >> 16; m = um >> 16; l = __float_as_uint(r2) >> 16;
+}
+constexpr unsigned BF16_ONE = 0x3F80u;
+constexpr unsigned BF16_BIG = 0x7F7Fu;      // largest finite bf16: the "norm" of the rows that pad the last tile
+
+// One wave per row of A (nA rows) and B (nB rows, then the padding of the last 128-candidate tile) of every pair:
+//   * ||x||^2 as RN32 of a binary64 sum of exact squares (error <= 2^-24 relative: the screens' bounds count on it);
+//     rows past nB get +inf (fp32 screen) -- the MFMA kernels stage whole tiles;
+//   * SPLIT (bf16x3 screen): the row's split image [128 x bf16 hi | 128 x bf16 lo] (A is scaled by -2 first: exact), and
+//     for candidates the 16-byte k-slot (nb_h, nb_m, nb_l, 1, 1, 1, 0, 0) that adds the norms inside the MFMA chain.
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void prep_kernel(MatchBatch bt)
 {
     const MatchPair &c = bt.p[blockIdx.y];
-    const float *__restrict__ A = c.A, *__restrict__ B = c.B;
-    float *__restrict__ na = c.na, *__restrict__ nb = c.nb;
-    const int nA = c.nA, nB = c.nB;
-    int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0 && c.fb_count) *c.fb_count = 0;       // first launch of a match call: resets the fallback list (no memset node)
-    const float *X = A;
-    float *out = na;
-    if (i >= nA) {
-        i -= nA; X = B; out = nb;
-        if (i >= nB) {        // the MFMA kernel stages whole 128-candidate tiles: rows past the end get an infinite norm
-            if (i < nm_divup_dev(nB, TILE_C) * TILE_C) nb[i] = __builtin_inff();
-            return;
+    const int nA = c.nA, nB = c.nB, lane = threadIdx.x & 63;
+    const int padded = nm_divup_dev(nB, TILE_C) * TILE_C;
+    int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i == 0 && lane == 0 && c.fb_count) *c.fb_count = 0;   // first launch of a match call: resets the fallback list
+    const bool isA = i < nA;
+    if (!isA) i -= nA;
+    if (!isA && i >= nB) {
+        if (i < padded && lane == 0) {
+            c.nb[i] = __builtin_inff();
+            if (SPLIT) c.nbslot[i] = make_uint4(BF16_BIG, BF16_ONE << 16, BF16_ONE | (BF16_ONE << 16), 0u);
+        }
+        return;
+    }
+    const float *X = isA ? c.A : c.B;
+    const float2 v = *reinterpret_cast<const float2 *>(X + (size_t)i * DIM + 2 * lane);
+    double acc = (double)v.x * (double)v.x + (double)v.y * (double)v.y;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    const float nrm = (float)acc;
+    if (SPLIT) {
+        const float sc = isA ? -2.0f : 1.0f;
+        unsigned h0, l0, h1, l1;
+        bf16_split(sc * v.x, h0, l0);
+        bf16_split(sc * v.y, h1, l1);
+        unsigned *row = (isA ? c.As : c.Bs) + (size_t)i * DIM;
+        row[lane] = h0 | (h1 << 16);
+        row[64 + lane] = l0 | (l1 << 16);
+    }
+    if (lane == 0) {
+        (isA ? c.na : c.nb)[i] = nrm;
+        if (SPLIT && !isA) {
+            unsigned h, m, l;
+            bf16_three(nrm, h, m, l);
+            c.nbslot[i] = (nrm < 3.0e38f) ? make_uint4(h | (m << 16), l | (BF16_ONE << 16), BF16_ONE | (BF16_ONE << 16), 0u)
+                                          : make_uint4(BF16_BIG, BF16_ONE << 16, BF16_ONE | (BF16_ONE << 16), 0u);
         }
     }
-    const float4 *row = reinterpret_cast<const float4 *>(X + (size_t)i * DIM);
-    float acc = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < DIM / 4; ++k) {
-        const float4 v = row[k];
-        acc = __builtin_fmaf(v.x, v.x, acc); acc = __builtin_fmaf(v.y, v.y, acc);
-        acc = __builtin_fmaf(v.z, v.z, acc); acc = __builtin_fmaf(v.w, v.w, acc);
-    }
-    out[i] = acc;
 }
 
 // max_j ||b_j||^2 of every pair (one workgroup per pair): tightens the error bound of match_finalize_kernel.
@@ -370,9 +420,49 @@ __device__ __forceinline__ void mfma_half(f32x16 &acc0, f32x16 &acc1, const floa
 }
 #undef NM_MFMA
 
+// The bf16x3 screen: the same two 32 x 32 accumulators from v_mfma_f32_32x32x16_bf16 on the SPLIT operands
+//   a = a_h + a_l + r_a,  b = b_h + b_l + r_b   (bf16 pieces, |r| <= 2^-16 |x|):   a.b ~ a_h.b_h + a_h.b_l + a_l.b_h
+// -- 3 x 8 instructions of 32 cycles per accumulator instead of 64 fp32 instructions of 64 cycles (5.3x fewer MFMA
+// cycles), plus one instruction whose k-slots carry the norms as exact sums of three bf16 each. rowp = this lane's
+// candidate row of group 0 at its k offset (8 h bf16 = 4 h dwords); a row is [hi: 64 dwords | lo: 64 dwords | slot: 4].
+// qf[s] / qf[8 + s] = the query's hi / lo pieces of k-step s (k = 16 s + 8 h ..+7), already scaled by -2.
+// The value differs from the exact distance by at most MatchBatch::err_coeff (sqrt na + sqrt nb)^2.
+#define NM_MFMA "v_mfma_f32_32x32x16_bf16 "
+__device__ __forceinline__ void mfma_half_bf16(f32x16 &acc0, f32x16 &acc1, const float *rowp, const float *slotp,
+                                               const u32x4 (&qf)[16], const u32x4 qslot)
+{
+    const float *r0 = rowp, *r1 = rowp + 32 * KP;
+    u32x4 h0 = *reinterpret_cast<const u32x4 *>(r0), l0 = *reinterpret_cast<const u32x4 *>(r0 + 64);
+    u32x4 h1 = *reinterpret_cast<const u32x4 *>(r1), l1 = *reinterpret_cast<const u32x4 *>(r1 + 64);
+    const u32x4 s0 = *reinterpret_cast<const u32x4 *>(slotp), s1 = *reinterpret_cast<const u32x4 *>(slotp + 32 * KP);
+    asm volatile(NM_MFMA "%0, %2, %4, 0\n\t" NM_MFMA "%1, %3, %4, 0"
+                 : "=&v"(acc0), "=&v"(acc1) : "v"(s0), "v"(s1), "v"(qslot) : "memory");
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        u32x4 nh0 = h0, nl0 = l0, nh1 = h1, nl1 = l1;
+        if (t + 1 < 8) {                                // next k-step's fragments fly during this step's 6 MFMAs
+            nh0 = *reinterpret_cast<const u32x4 *>(r0 + 8 * (t + 1)); nl0 = *reinterpret_cast<const u32x4 *>(r0 + 64 + 8 * (t + 1));
+            nh1 = *reinterpret_cast<const u32x4 *>(r1 + 8 * (t + 1)); nl1 = *reinterpret_cast<const u32x4 *>(r1 + 64 + 8 * (t + 1));
+        }
+        asm volatile(NM_MFMA "%0, %2, %6, %0\n\t" NM_MFMA "%1, %4, %6, %1\n\t"
+                     NM_MFMA "%0, %2, %7, %0\n\t" NM_MFMA "%1, %4, %7, %1\n\t"
+                     NM_MFMA "%0, %3, %6, %0\n\t" NM_MFMA "%1, %5, %6, %1"
+                     : "+v"(acc0), "+v"(acc1)
+                     : "v"(h0), "v"(l0), "v"(h1), "v"(l1), "v"(qf[t]), "v"(qf[8 + t])
+                     : "memory");
+        h0 = nh0; l0 = nl0; h1 = nh1; l1 = nl1;
+    }
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc0), "+v"(acc1));
+}
+#undef NM_MFMA
+
+// BF16 = false: A, B are the fp32 descriptor rows. BF16 = true: A, B are the split images written by prep_kernel<true>
+// (same 512-byte rows, so the staging is identical) and nbslot replaces nb.
+template <bool BF16>
 __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restrict__ A, int nA,
                                                            const float *__restrict__ B, int nB,
                                                            const float *__restrict__ na, const float *__restrict__ nb,
+                                                           const uint4 *__restrict__ nbslot,
                                                            MatchPlan plan, float4 *__restrict__ partial,
                                                            float *__restrict__ partial3)
 {
@@ -395,16 +485,23 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
 
     u32x4 st[8];
     float stn = 0.f;
+    uint4 sts = make_uint4(0u, 0u, 0u, 0u);
     auto stage_load = [&](int tile) {                     // candidates tile*128 .. +127 -> registers
         const int jb = tile * TILE_C;
 #pragma unroll
         for (int it = 0; it < 8; ++it) st[it] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voff, (jb + 16 * it) * (DIM * 4), 0);
-        if (tid < TILE_C) stn = nb[jb + tid];             // padded with +inf up to T * 128 by norms_kernel
+        if (tid < TILE_C) {                               // padded up to T * 128 by prep_kernel
+            if (BF16) sts = nbslot[jb + tid];
+            else stn = nb[jb + tid];
+        }
     };
     auto stage_write = [&](float *buf) {
 #pragma unroll
         for (int it = 0; it < 8; ++it) *reinterpret_cast<u32x4 *>(&buf[(srow + 16 * it) * KP + scol]) = st[it];
-        if (tid < TILE_C) *reinterpret_cast<float2 *>(&buf[tid * KP + DIM]) = make_float2(stn, 1.0f);   // augmented k-pair
+        if (tid < TILE_C) {                               // augmented k-pair / k-slot
+            if (BF16) *reinterpret_cast<uint4 *>(&buf[tid * KP + DIM]) = sts;
+            else *reinterpret_cast<float2 *>(&buf[tid * KP + DIM]) = make_float2(stn, 1.0f);
+        }
     };
 
     long u;
@@ -426,14 +523,25 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
         }
         __syncthreads();
         float4 qf[16];
+        u32x4 qw[16];
         const int qi = i0 + wave * 32 + r;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {      // the -2 of  |a|^2 + |b|^2 - 2 a.b  rides on the query fragments (once per segment)
-            const float4 v = *reinterpret_cast<const float4 *>(&lds[(wave * 32 + r) * KP + 8 * t + 4 * h]);
-            qf[t] = make_float4(-2.f * v.x, -2.f * v.y, -2.f * v.z, -2.f * v.w);
+            if (BF16) {                     // hi pieces of k-steps 0..7, then the lo pieces (prep_kernel applied the -2)
+                qw[t] = *reinterpret_cast<const u32x4 *>(&lds[(wave * 32 + r) * KP + 8 * t + 4 * h]);
+            } else {
+                const float4 v = *reinterpret_cast<const float4 *>(&lds[(wave * 32 + r) * KP + 8 * t + 4 * h]);
+                qf[t] = make_float4(-2.f * v.x, -2.f * v.y, -2.f * v.z, -2.f * v.w);
+            }
         }
         const float nav = (qi < nA) ? na[qi] : 0.f;
         const float nq = (h == 0) ? 1.0f : nav;
+        u32x4 qslot = {0u, 0u, 0u, 0u};     // k-slots (1, 1, 1, na_h, na_m, na_l, 0, 0) on the lanes that hold k = 0..7
+        if (BF16 && h == 0) {
+            unsigned nh, nm, nl;
+            bf16_three(nav, nh, nm, nl);
+            qslot = (u32x4){BF16_ONE | (BF16_ONE << 16), BF16_ONE | (nh << 16), nm | (nl << 16), 0u};
+        }
         __syncthreads();
         stage_write(lds);
         __syncthreads();
@@ -448,9 +556,11 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
             const float *buf = lds + (n & 1) * (TILE_C * KP);
             const float *rowp = buf + r * KP + 4 * h, *normp = buf + r * KP + DIM + h;
             if (n + 1 < ntiles) stage_load(t0 + n + 1);
-            mfma_half(a0, a1, rowp, normp, qf, nq);
+            if (BF16) mfma_half_bf16(a0, a1, rowp, buf + r * KP + DIM, qw, qslot);
+            else mfma_half(a0, a1, rowp, normp, qf, nq);
             select_half(a0, a1, best, 2 * n);
-            mfma_half(a0, a1, rowp + 64 * KP, normp + 64 * KP, qf, nq);
+            if (BF16) mfma_half_bf16(a0, a1, rowp + 64 * KP, buf + (64 + r) * KP + DIM, qw, qslot);
+            else mfma_half(a0, a1, rowp + 64 * KP, normp + 64 * KP, qf, nq);
             select_half(a0, a1, best, 2 * n + 1);
             if (n + 1 < ntiles) stage_write(lds + ((n + 1) & 1) * (TILE_C * KP));
             __syncthreads();
@@ -550,8 +660,9 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(MatchBatch bt)
     float rest = __builtin_inff();
 #pragma unroll
     for (int k = 0; k < 4; ++k) { cd[k] = __builtin_inff(); ci[k] = -1; }
+    const int nB = c.nB;
     auto insert = [&](float d, int j) {
-        if (j < 0) return;
+        if (j < 0 || j >= nB) return;                // absent, or a row of the last tile's padding (bf16x3: finite "norm")
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                // sorted insertion by (approx distance, index)
             const bool lt = (d < cd[k]) || (d == cd[k] && j < ci[k]);
@@ -610,7 +721,7 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(MatchBatch bt)
     const float nai = na[i];
     const float sq = __builtin_fminf(2.0f * __builtin_sqrtf(nai) + __builtin_sqrtf(m2),
                                      __builtin_sqrtf(nai) + __builtin_sqrtf(*c.nbmax));
-    const float bound = (m2 * 1.00001f + 1.56e-5f * (sq * sq)) * 1.00001f;      // 1 + 2^-17 = 1.0000076
+    const float bound = (m2 * 1.00001f + bt.err_coeff * (sq * sq)) * 1.00001f + 1e-30f;      // 1 + 2^-17 = 1.0000076
     const float margin = bound - m2;
     (void)margin;
     if (rest <= bound && rest < __builtin_inff()) {
@@ -983,7 +1094,25 @@ __global__ __launch_bounds__(256) void set_matches_kernel(int *__restrict__ resu
     }
 }
 
-struct MatchWs { float *na, *nb; float4 *partial; float *partial3; int *fb_count, *fb_list; };
+struct MatchWs { float *na, *nb; float4 *partial; float *partial3; int *fb_count, *fb_list; unsigned *As, *Bs; uint4 *nbslot; };
+
+// Which MFMA screen match_top2 runs: 0 = fp32 (v_mfma_f32_32x32x2_f32, K = 128 exact products), 1 = bf16x3 (split
+// operands on v_mfma_f32_32x32x16_bf16). Both feed the same exact finalize / fallback, so the results are identical;
+// the bf16x3 screen is ~3x faster and sends a few more rows to the exact fallback. NM_MATCH_SCREEN=f32|bf16x3 or
+// nm_sift_match_set_screen() select it (process-wide).
+static std::atomic<int> g_screen{-1};
+static int match_screen()
+{
+    int v = g_screen.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("NM_MATCH_SCREEN");
+        v = (e && (!strcmp(e, "f32") || !strcmp(e, "0"))) ? 0 : 1;
+        g_screen.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+// |screen value - exact squared distance| <= coeff (sqrt na + sqrt nb)^2  
+static float screen_err_coeff(int screen) { return screen ? 2.75e-5f : 1.56e-5f; }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -997,8 +1126,11 @@ static MatchWs carve(void *workspace, int nA, int nB, const MatchPlan &p)
     w.fb_list = reinterpret_cast<int *>(base); base += align256((size_t)nA * 4);
     // partial / partial3 are dead once match_finalize_kernel has run: the fallback reuses the space from `partial` on
     // for its FB_SPLIT slice results per listed query (<= nA * MAX_CHUNKS float4, covered by the workspace bound)
-    w.partial = reinterpret_cast<float4 *>(base); base += align256((size_t)nA * p.S * sizeof(float4));
-    w.partial3 = reinterpret_cast<float *>(base);
+    w.partial = reinterpret_cast<float4 *>(base); base += align256((size_t)nA * MAX_CHUNKS * sizeof(float4));
+    w.partial3 = reinterpret_cast<float *>(base); base += align256((size_t)nA * MAX_CHUNKS * sizeof(float));
+    w.As = reinterpret_cast<unsigned *>(base); base += align256((size_t)nA * DIM * 4);
+    w.Bs = reinterpret_cast<unsigned *>(base); base += align256((size_t)nB * DIM * 4);
+    w.nbslot = reinterpret_cast<uint4 *>(base);
     return w;
 }
 
@@ -1007,7 +1139,8 @@ static size_t pair_workspace_bytes(int nA, int nB)
     if (nA < 0) nA = 0;
     if (nB < 0) nB = 0;
     return align256((size_t)nA * 4) + align256(((size_t)nB + TILE_C) * 4) + align256((size_t)nA * MAX_CHUNKS * sizeof(float4)) +
-           align256((size_t)nA * MAX_CHUNKS * sizeof(float)) + 256 + align256((size_t)nA * 4) + 256;
+           align256((size_t)nA * MAX_CHUNKS * sizeof(float)) + 256 + align256((size_t)nA * 4) + 256 +
+           align256((size_t)nA * DIM * 4) + align256((size_t)nB * DIM * 4) + align256(((size_t)nB + TILE_C) * sizeof(uint4));
 }
 
 struct MatchJob {                 // host-side description of one pair of a (possibly batched) call
@@ -1026,7 +1159,9 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
     if (n > MATCH_MAX_BATCH) return (int)hipErrorInvalidValue;
     MatchBatch bt{};
     MatchPlan plans[MATCH_MAX_BATCH];
+    const int screen = match_screen();
     bt.ambiguity = ambiguity;
+    bt.err_coeff = screen_err_coeff(screen);
     int max_rows = 0, max_a = 0;
     for (int k = 0; k < n; ++k) {
         const MatchJob &j = jobs[k];
@@ -1038,24 +1173,32 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
         c.A = j.A; c.B = j.B; c.nA = j.nA; c.nB = j.nB; c.na = w.na; c.nb = w.nb; c.partial = w.partial;
         c.partial3 = w.partial3; c.fb_count = w.fb_count; c.fb_list = w.fb_list; c.nbmax = reinterpret_cast<float *>(w.fb_count + 16); c.S = plans[q].S; c.mode = j.mode;
         c.index_offset = j.index_offset; c.result = j.result; c.min1 = j.min1; c.min2 = j.min2; c.idx1 = j.idx1;
+        c.As = w.As; c.Bs = w.Bs; c.nbslot = w.nbslot;
         if (j.nA >= (1 << 22) || j.nB >= (1 << 22)) return (int)hipErrorInvalidValue;   // 32-bit byte ranges of the SRDs
         max_rows = max(max_rows, j.nA + nm_divup(j.nB, TILE_C) * TILE_C);
         max_a = max(max_a, j.nA);
     }
     if (bt.n == 0) return 0;
-    hipLaunchKernelGGL(norms_kernel, dim3(nm_divup(max_rows, 256), bt.n), dim3(256), 0, st, bt);
+    if (screen) hipLaunchKernelGGL(prep_kernel<true>, dim3(nm_divup(max_rows, 4), bt.n), dim3(256), 0, st, bt);
+    else hipLaunchKernelGGL(prep_kernel<false>, dim3(nm_divup(max_rows, 4), bt.n), dim3(256), 0, st, bt);
     NM_LAUNCH_CHECK();
     hipLaunchKernelGGL(nbmax_kernel, dim3(bt.n), dim3(1024), 0, st, bt);
     NM_LAUNCH_CHECK();
     const size_t lds_bytes = (size_t)2 * TILE_C * KP * sizeof(float);
     // per call: the attribute is per device, and a process may drive several (cheap host-side call, not a stream op)
-    NM_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_kernel),
+    NM_RETURN_IF(hipFuncSetAttribute(screen ? reinterpret_cast<const void *>(match_top2_kernel<true>)
+                                            : reinterpret_cast<const void *>(match_top2_kernel<false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     for (int q = 0; q < bt.n; ++q) {
         const MatchPair &c = bt.p[q];
         nm_prof_begin(NM_PROF_MATCH_TOP2, st);
-        hipLaunchKernelGGL(match_top2_kernel, dim3(plans[q].G), dim3(512), lds_bytes, st, c.A, c.nA, c.B, c.nB, c.na, c.nb,
-                           plans[q], c.partial, c.partial3);
+        if (screen)
+            hipLaunchKernelGGL(match_top2_kernel<true>, dim3(plans[q].G), dim3(512), lds_bytes, st,
+                               reinterpret_cast<const float *>(c.As), c.nA, reinterpret_cast<const float *>(c.Bs), c.nB,
+                               c.na, c.nb, c.nbslot, plans[q], c.partial, c.partial3);
+        else
+            hipLaunchKernelGGL(match_top2_kernel<false>, dim3(plans[q].G), dim3(512), lds_bytes, st, c.A, c.nA, c.B, c.nB,
+                               c.na, c.nb, c.nbslot, plans[q], c.partial, c.partial3);
         nm_prof_end(NM_PROF_MATCH_TOP2, st);
         NM_LAUNCH_CHECK();
     }
@@ -1117,6 +1260,14 @@ int nm_get_sift_matches_f32(const float *distance, int rows, int cols, int buffe
 // Upper bound for every call with nA' <= nA and nB' <= nB on the same workspace (the grid plan, hence the number of
 // candidate chunks S <= MAX_CHUNKS, depends on the actual sizes).
 size_t nm_sift_match_workspace_bytes(int nA, int nB) { return pair_workspace_bytes(nA, nB); }
+
+int nm_sift_match_set_screen(int screen)
+{
+    if (screen != 0 && screen != 1) return (int)hipErrorInvalidValue;
+    g_screen.store(screen, std::memory_order_relaxed);
+    return 0;
+}
+int nm_sift_match_get_screen(void) { return match_screen(); }
 
 size_t nm_sift_match_batch_workspace_bytes(int n, const int *nA, const int *nB)
 {

@@ -30,12 +30,17 @@ def run(A, B, label):
                                                                                            256.0 * nA * nB / ms / 1e9))
 
 
-for n in (12000, 100000):
-    run(torch.rand((n, 128), device=dev, generator=g), torch.rand((n, 128), device=dev, generator=g), "uniform [0,1)")
-run(torch.rand((100000, 128), device=dev, generator=g), torch.rand((12500, 128), device=dev, generator=g), "uniform [0,1) shard")
+sets = [(torch.rand((n, 128), device=dev, generator=g), torch.rand((n, 128), device=dev, generator=g), "uniform [0,1)")
+        for n in (12000, 100000)]
+sets.append((torch.rand((100000, 128), device=dev, generator=g), torch.rand((12500, 128), device=dev, generator=g),
+             "uniform [0,1) shard"))
 frames = bench.make_frames(nm, torch, dev, [0, 1])
 ar = [nm.SiftArena(bench.W, bench.H, bench.CAP, device=dev) for _ in range(2)]
 nm.detect_describe_batch(ar, frames)
 torch.cuda.synchronize()
 n0, n1 = int(ar[0].num_items.item()), int(ar[1].num_items.item())
-run(ar[0].desc[:n0].contiguous(), ar[1].desc[:n1].contiguous(), "1080p SIFT pair")
+sets.append((ar[0].desc[:n0].contiguous(), ar[1].desc[:n1].contiguous(), "1080p SIFT pair"))
+for screen in ("f32", "bf16x3"):
+    nm.set_match_screen(screen)
+    for A, B, label in sets:
+        run(A, B, screen + " " + label)
