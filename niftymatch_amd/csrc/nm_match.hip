@@ -15,6 +15,9 @@
 //   4. match_fallback_kernel (+ match_fallback_merge_kernel), which scan all candidates exactly (a fraction of a
 //                          percent of the queries), 64 candidate slices per listed query.
 // API building blocks (transpose / bf_distance / get_sift_matches) keep the reference's layouts and are exact.
+#ifndef NM_DBG
+#define NM_DBG 0
+#endif
 #include <dlfcn.h>
 
 #include <atomic>
@@ -427,32 +430,90 @@ __device__ __forceinline__ void mfma_half(f32x16 &acc0, f32x16 &acc1, const floa
 // candidate row of group 0 at its k offset (8 h bf16 = 4 h dwords); a row is [hi: 64 dwords | lo: 64 dwords | slot: 4].
 // qf[s] / qf[8 + s] = the query's hi / lo pieces of k-step s (k = 16 s + 8 h ..+7), already scaled by -2.
 // The value differs from the exact distance by at most MatchBatch::err_coeff (sqrt na + sqrt nb)^2.
+#if NM_DBG & 4
+#define NM_MFMA "; v_mfma_f32_32x32x16_bf16 "
+#else
 #define NM_MFMA "v_mfma_f32_32x32x16_bf16 "
-__device__ __forceinline__ void mfma_half_bf16(f32x16 &acc0, f32x16 &acc1, const float *rowp, const float *slotp,
-                                               const u32x4 (&qf)[16], const u32x4 qslot)
+#endif
+// One k-step (k = 16 T .. 16 T + 15) of both accumulators: 6 MFMAs, and -- SELECT -- between them the insertion of four
+// values of the PREVIOUS 64-candidate group (p0..p3 = its accumulator registers 4 T .. 4 T + 3, slots E0 .. E0 + 3) into
+// that group's running key triple (g1 <= g2 <= g3): v_and_or (key), v_med3, v_med3, v_min per value, two or three
+// between consecutive MFMAs. Unlike the fp32 MFMA, the bf16 MFMA leaves the SIMD's VALU port free while it runs
+// (MI355X_MICROARCH.md, "instructions hidden per MFMA gap"), so the selection of one group costs nothing while the next
+// group's products are formed; with the selection AFTER the MFMAs (as in the fp32 kernel) the two waves of a SIMD ran in
+// lockstep, their selections coincided, and the MFMA pipe idled 49 % of the time (profiles/r02_j_*).
+template <bool SELECT, int E0>
+__device__ __forceinline__ void bf16_kstep(f32x16 &acc0, f32x16 &acc1, const u32x4 h0, const u32x4 l0, const u32x4 h1,
+                                           const u32x4 l1, const u32x4 qh, const u32x4 ql, float p0, float p1, float p2,
+                                           float p3, int &g1, int &g2, int &g3)
+{
+    if (SELECT) {
+        int k;
+        const int mask = ~((1 << KEY_SLOT_BITS) - 1);
+        asm volatile(NM_MFMA "%0, %6, %10, %0\n\t"
+                     "v_and_or_b32 %5, %12, %16, %17\n\t"
+                     "v_med3_i32 %4, %3, %4, %5\n\t"
+                     "v_med3_i32 %3, %2, %3, %5\n\t"
+                     NM_MFMA "%1, %8, %10, %1\n\t"
+                     "v_min_i32 %2, %2, %5\n\t"
+                     "v_and_or_b32 %5, %13, %16, %18\n\t"
+                     "v_med3_i32 %4, %3, %4, %5\n\t"
+                     NM_MFMA "%0, %6, %11, %0\n\t"
+                     "v_med3_i32 %3, %2, %3, %5\n\t"
+                     "v_min_i32 %2, %2, %5\n\t"
+                     "v_and_or_b32 %5, %14, %16, %19\n\t"
+                     NM_MFMA "%1, %8, %11, %1\n\t"
+                     "v_med3_i32 %4, %3, %4, %5\n\t"
+                     "v_med3_i32 %3, %2, %3, %5\n\t"
+                     "v_min_i32 %2, %2, %5\n\t"
+                     NM_MFMA "%0, %7, %10, %0\n\t"
+                     "v_and_or_b32 %5, %15, %16, %20\n\t"
+                     "v_med3_i32 %4, %3, %4, %5\n\t"
+                     "v_med3_i32 %3, %2, %3, %5\n\t"
+                     NM_MFMA "%1, %9, %10, %1\n\t"
+                     "v_min_i32 %2, %2, %5"
+                     : "+v"(acc0), "+v"(acc1), "+v"(g1), "+v"(g2), "+v"(g3), "=&v"(k)
+                     : "v"(h0), "v"(l0), "v"(h1), "v"(l1), "v"(qh), "v"(ql), "v"(p0), "v"(p1), "v"(p2), "v"(p3), "s"(mask),
+                       "n"(E0), "n"(E0 + 1), "n"(E0 + 2), "n"(E0 + 3)
+                     : "memory");
+    } else {
+        asm volatile(NM_MFMA "%0, %2, %6, %0\n\t" NM_MFMA "%1, %4, %6, %1\n\t"
+                     NM_MFMA "%0, %2, %7, %0\n\t" NM_MFMA "%1, %4, %7, %1\n\t"
+                     NM_MFMA "%0, %3, %6, %0\n\t" NM_MFMA "%1, %5, %6, %1"
+                     : "+v"(acc0), "+v"(acc1)
+                     : "v"(h0), "v"(l0), "v"(h1), "v"(l1), "v"(qh), "v"(ql)
+                     : "memory");
+    }
+}
+
+// (acc0, acc1) <- the 64-candidate group at rowp; SELECT: the previous group's accumulators (prev0, prev1) are folded into
+// the key triple (g1, g2, g3) meanwhile. The group's values may be read by the VALU 10 wait states after the last MFMA
+// (8-pass XDL op): the next call's first VALU instruction comes after two more MFMAs and the explicit s_nop below.
+template <bool SELECT>
+__device__ __forceinline__ void mfma_half_bf16(f32x16 &acc0, f32x16 &acc1, const f32x16 &prev0, const f32x16 &prev1,
+                                               const float *rowp, const float *slotp, const u32x4 (&qf)[16],
+                                               const u32x4 qslot, int &g1, int &g2, int &g3)
 {
     const float *r0 = rowp, *r1 = rowp + 32 * KP;
     u32x4 h0 = *reinterpret_cast<const u32x4 *>(r0), l0 = *reinterpret_cast<const u32x4 *>(r0 + 64);
     u32x4 h1 = *reinterpret_cast<const u32x4 *>(r1), l1 = *reinterpret_cast<const u32x4 *>(r1 + 64);
     const u32x4 s0 = *reinterpret_cast<const u32x4 *>(slotp), s1 = *reinterpret_cast<const u32x4 *>(slotp + 32 * KP);
-    asm volatile(NM_MFMA "%0, %2, %4, 0\n\t" NM_MFMA "%1, %3, %4, 0"
+    asm volatile(NM_MFMA "%0, %2, %4, 0\n\t" NM_MFMA "%1, %3, %4, 0\n\ts_nop 15\n\ts_nop 3"
                  : "=&v"(acc0), "=&v"(acc1) : "v"(s0), "v"(s1), "v"(qslot) : "memory");
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        u32x4 nh0 = h0, nl0 = l0, nh1 = h1, nl1 = l1;
-        if (t + 1 < 8) {                                // next k-step's fragments fly during this step's 6 MFMAs
-            nh0 = *reinterpret_cast<const u32x4 *>(r0 + 8 * (t + 1)); nl0 = *reinterpret_cast<const u32x4 *>(r0 + 64 + 8 * (t + 1));
-            nh1 = *reinterpret_cast<const u32x4 *>(r1 + 8 * (t + 1)); nl1 = *reinterpret_cast<const u32x4 *>(r1 + 64 + 8 * (t + 1));
-        }
-        asm volatile(NM_MFMA "%0, %2, %6, %0\n\t" NM_MFMA "%1, %4, %6, %1\n\t"
-                     NM_MFMA "%0, %2, %7, %0\n\t" NM_MFMA "%1, %4, %7, %1\n\t"
-                     NM_MFMA "%0, %3, %6, %0\n\t" NM_MFMA "%1, %5, %6, %1"
-                     : "+v"(acc0), "+v"(acc1)
-                     : "v"(h0), "v"(l0), "v"(h1), "v"(l1), "v"(qf[t]), "v"(qf[8 + t])
-                     : "memory");
-        h0 = nh0; l0 = nl0; h1 = nh1; l1 = nl1;
+#define NM_KSTEP(T)                                                                                                      \
+    {                                                                                                                    \
+        u32x4 nh0 = h0, nl0 = l0, nh1 = h1, nl1 = l1;                                                                    \
+        if (T + 1 < 8 && !(NM_DBG & 8)) { /* next k-step's fragments fly during this step's 6 MFMAs */                   \
+            nh0 = *reinterpret_cast<const u32x4 *>(r0 + 8 * (T + 1)); nl0 = *reinterpret_cast<const u32x4 *>(r0 + 64 + 8 * (T + 1)); \
+            nh1 = *reinterpret_cast<const u32x4 *>(r1 + 8 * (T + 1)); nl1 = *reinterpret_cast<const u32x4 *>(r1 + 64 + 8 * (T + 1)); \
+        }                                                                                                                \
+        const f32x16 &pv = (T < 4) ? prev0 : prev1;                                                                      \
+        bf16_kstep<SELECT, 4 * T>(acc0, acc1, h0, l0, h1, l1, qf[T], qf[8 + T], pv[(4 * T) & 15], pv[(4 * T + 1) & 15],    \
+                                  pv[(4 * T + 2) & 15], pv[(4 * T + 3) & 15], g1, g2, g3);                                \
+        h0 = nh0; l0 = nl0; h1 = nh1; l1 = nl1;                                                                          \
     }
-    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc0), "+v"(acc1));
+    NM_KSTEP(0) NM_KSTEP(1) NM_KSTEP(2) NM_KSTEP(3) NM_KSTEP(4) NM_KSTEP(5) NM_KSTEP(6) NM_KSTEP(7)
+#undef NM_KSTEP
 }
 #undef NM_MFMA
 
@@ -552,15 +613,54 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
         // A wave multiplies its 32 queries with 64 candidates at a time (two 32 x 32 accumulators), then folds the 32
         // values each lane holds into its running triple. Within a lane the candidate index increases with (tile, half, g, e).
         f32x16 a0, a1;
+        if (BF16) {
+            // software pipeline over the 64-candidate groups: the MFMAs of group i run while group i - 1 is selected
+            f32x16 b0, b1;
+            auto fold = [&](int g1, int g2, int g3, int tag) {
+                if (__any(g1 < best.k3)) {
+                    top3_merge(best, g1, tag);
+                    top3_merge(best, g2, tag);
+                    top3_merge(best, g3, tag);
+                }
+            };
+            for (int n = 0; n < ntiles; ++n) {
+                const float *buf = lds + (n & 1) * (TILE_C * KP);
+                const float *rowp = buf + r * KP + 4 * h;
+#if !(NM_DBG & 2)
+                if (n + 1 < ntiles) stage_load(t0 + n + 1);
+#endif
+                int g1 = KEY_INF, g2 = KEY_INF, g3 = KEY_INF;
+#if NM_DBG & 1
+                mfma_half_bf16<false>(a0, a1, b0, b1, rowp, buf + r * KP + DIM, qw, qslot, g1, g2, g3);
+                mfma_half_bf16<false>(b0, b1, a0, a1, rowp + 64 * KP, buf + (64 + r) * KP + DIM, qw, qslot, g1, g2, g3);
+#else
+                if (n == 0) {
+                    mfma_half_bf16<false>(a0, a1, b0, b1, rowp, buf + r * KP + DIM, qw, qslot, g1, g2, g3);
+                } else {
+                    mfma_half_bf16<true>(a0, a1, b0, b1, rowp, buf + r * KP + DIM, qw, qslot, g1, g2, g3);
+                    fold(g1, g2, g3, 2 * n - 1);
+                }
+                g1 = g2 = g3 = KEY_INF;
+                mfma_half_bf16<true>(b0, b1, a0, a1, rowp + 64 * KP, buf + (64 + r) * KP + DIM, qw, qslot, g1, g2, g3);
+                fold(g1, g2, g3, 2 * n);
+#endif
+#if !(NM_DBG & 2)
+                if (n + 1 < ntiles) stage_write(lds + ((n + 1) & 1) * (TILE_C * KP));
+#endif
+#if !(NM_DBG & 16)
+                __syncthreads();
+#endif
+            }
+            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(b0), "+v"(b1));
+            select_half(b0, b1, best, 2 * ntiles - 1);
+        } else
         for (int n = 0; n < ntiles; ++n) {
             const float *buf = lds + (n & 1) * (TILE_C * KP);
             const float *rowp = buf + r * KP + 4 * h, *normp = buf + r * KP + DIM + h;
             if (n + 1 < ntiles) stage_load(t0 + n + 1);
-            if (BF16) mfma_half_bf16(a0, a1, rowp, buf + r * KP + DIM, qw, qslot);
-            else mfma_half(a0, a1, rowp, normp, qf, nq);
+            mfma_half(a0, a1, rowp, normp, qf, nq);
             select_half(a0, a1, best, 2 * n);
-            if (BF16) mfma_half_bf16(a0, a1, rowp + 64 * KP, buf + (64 + r) * KP + DIM, qw, qslot);
-            else mfma_half(a0, a1, rowp + 64 * KP, normp + 64 * KP, qf, nq);
+            mfma_half(a0, a1, rowp + 64 * KP, normp + 64 * KP, qf, nq);
             select_half(a0, a1, best, 2 * n + 1);
             if (n + 1 < ntiles) stage_write(lds + ((n + 1) & 1) * (TILE_C * KP));
             __syncthreads();

@@ -8,6 +8,16 @@ from test_gpu_stages import _eq, _t
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["bf16x3", "f32"])
+def screen(request, nm):
+    """Every test of this module runs with both MFMA screens of the fused matcher (nm_sift_match_set_screen): the
+    split-bf16 one (default) and the fp32 one. The expected results are the same -- the oracle's."""
+    before = nm.get_match_screen()
+    nm.set_match_screen(request.param)
+    yield request.param
+    nm.set_match_screen(before)
+
+
 def _match(nm, cuda, A, B, amb=0.8, want_distance=False, prior=None):
     import torch
     pr = None if prior is None else _t(np.asarray(prior, np.int32), cuda)
@@ -287,6 +297,16 @@ def test_match_adversarial_rounding(nm, oracle, cuda):
         for _ in range(j % 9 - 1 if j % 9 > 1 else 0):
             B6[j, (5 * j) % 128] = np.nextafter(B6[j, (5 * j) % 128], np.float32(1e9), dtype=np.float32)
     cases["one-ulp ladders"] = (A6, B6)
+    # 6. bf16x3 screen: every element is 2^e (1 + 2^-9 + 2^-17 - 2^-23): its two-piece bf16 split leaves the largest
+    #    residual (~2^-17 relative), with the same sign in every element of every row, so the screen's dot products are
+    #    all off in the same direction by ~2^-16 relative (4e-3 absolute here) while the candidates of a query differ by
+    #    ~1e-6: only the proven bound (-> exact fallback) can get these rows right
+    bad = np.float32(1.0 + 2.0 ** -9 + 2.0 ** -17 - 2.0 ** -23)
+    A7 = (bad * 2.0 ** rng.integers(-1, 2, (200, 128))).astype(np.float32)
+    B7 = np.repeat(A7, 4, 0)
+    for j in range(B7.shape[0]):
+        B7[j, (3 * j) % 128] += np.float32((1 + j % 4) * 2.0 ** -11)
+    cases["aligned bf16 split residuals"] = (A7, np.concatenate([B7, (bad * 2.0 ** rng.integers(-1, 2, (300, 128))).astype(np.float32)]))
     for name, (A, B) in cases.items():
         A = np.ascontiguousarray(A, np.float32); B = np.ascontiguousarray(B, np.float32)
         prior = np.full(len(A), -7, np.int32)
