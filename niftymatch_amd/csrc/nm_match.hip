@@ -15,9 +15,6 @@
 //   4. match_fallback_kernel (+ match_fallback_merge_kernel), which scan all candidates exactly (a fraction of a
 //                          percent of the queries), 64 candidate slices per listed query.
 // API building blocks (transpose / bf_distance / get_sift_matches) keep the reference's layouts and are exact.
-#ifndef NM_DBG
-#define NM_DBG 0
-#endif
 #include <dlfcn.h>
 
 #include <atomic>
@@ -430,11 +427,7 @@ __device__ __forceinline__ void mfma_half(f32x16 &acc0, f32x16 &acc1, const floa
 // candidate row of group 0 at its k offset (8 h bf16 = 4 h dwords); a row is [hi: 64 dwords | lo: 64 dwords | slot: 4].
 // qf[s] / qf[8 + s] = the query's hi / lo pieces of k-step s (k = 16 s + 8 h ..+7), already scaled by -2.
 // The value differs from the exact distance by at most MatchBatch::err_coeff (sqrt na + sqrt nb)^2.
-#if NM_DBG & 4
-#define NM_MFMA "; v_mfma_f32_32x32x16_bf16 "
-#else
 #define NM_MFMA "v_mfma_f32_32x32x16_bf16 "
-#endif
 // One k-step (k = 16 T .. 16 T + 15) of both accumulators: 6 MFMAs, and -- SELECT -- between them the insertion of four
 // values of the PREVIOUS 64-candidate group (p0..p3 = its accumulator registers 4 T .. 4 T + 3, slots E0 .. E0 + 3) into
 // that group's running key triple (g1 <= g2 <= g3): v_and_or (key), v_med3, v_med3, v_min per value, two or three
@@ -503,7 +496,7 @@ __device__ __forceinline__ void mfma_half_bf16(f32x16 &acc0, f32x16 &acc1, const
 #define NM_KSTEP(T)                                                                                                      \
     {                                                                                                                    \
         u32x4 nh0 = h0, nl0 = l0, nh1 = h1, nl1 = l1;                                                                    \
-        if (T + 1 < 8 && !(NM_DBG & 8)) { /* next k-step's fragments fly during this step's 6 MFMAs */                   \
+        if (T + 1 < 8) { /* next k-step's fragments fly during this step's 6 MFMAs */                                    \
             nh0 = *reinterpret_cast<const u32x4 *>(r0 + 8 * (T + 1)); nl0 = *reinterpret_cast<const u32x4 *>(r0 + 64 + 8 * (T + 1)); \
             nh1 = *reinterpret_cast<const u32x4 *>(r1 + 8 * (T + 1)); nl1 = *reinterpret_cast<const u32x4 *>(r1 + 64 + 8 * (T + 1)); \
         }                                                                                                                \
@@ -626,14 +619,8 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
             for (int n = 0; n < ntiles; ++n) {
                 const float *buf = lds + (n & 1) * (TILE_C * KP);
                 const float *rowp = buf + r * KP + 4 * h;
-#if !(NM_DBG & 2)
                 if (n + 1 < ntiles) stage_load(t0 + n + 1);
-#endif
                 int g1 = KEY_INF, g2 = KEY_INF, g3 = KEY_INF;
-#if NM_DBG & 1
-                mfma_half_bf16<false>(a0, a1, b0, b1, rowp, buf + r * KP + DIM, qw, qslot, g1, g2, g3);
-                mfma_half_bf16<false>(b0, b1, a0, a1, rowp + 64 * KP, buf + (64 + r) * KP + DIM, qw, qslot, g1, g2, g3);
-#else
                 if (n == 0) {
                     mfma_half_bf16<false>(a0, a1, b0, b1, rowp, buf + r * KP + DIM, qw, qslot, g1, g2, g3);
                 } else {
@@ -643,13 +630,8 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
                 g1 = g2 = g3 = KEY_INF;
                 mfma_half_bf16<true>(b0, b1, a0, a1, rowp + 64 * KP, buf + (64 + r) * KP + DIM, qw, qslot, g1, g2, g3);
                 fold(g1, g2, g3, 2 * n);
-#endif
-#if !(NM_DBG & 2)
                 if (n + 1 < ntiles) stage_write(lds + ((n + 1) & 1) * (TILE_C * KP));
-#endif
-#if !(NM_DBG & 16)
                 __syncthreads();
-#endif
             }
             asm volatile("s_nop 15\n\ts_nop 3" : "+v"(b0), "+v"(b1));
             select_half(b0, b1, best, 2 * ntiles - 1);
