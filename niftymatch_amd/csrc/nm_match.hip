@@ -234,50 +234,65 @@ __device__ __forceinline__ void bf16_three(float n, unsigned &h, unsigned &m, un
 constexpr unsigned BF16_ONE = 0x3F80u;
 constexpr unsigned BF16_BIG = 0x7F7Fu;      // largest finite bf16: the "norm" of the rows that pad the last tile
 
-// One wave per row of A (nA rows) and B (nB rows, then the padding of the last 128-candidate tile) of every pair:
+// Half a wave per row of A (nA rows) and B (nB rows, then the padding of the last 128-candidate tile) of every pair, four
+// rows per wave in flight (a lane holds one float4 of two rows):
 //   * ||x||^2 as RN32 of a binary64 sum of exact squares (error <= 2^-24 relative: the screens' bounds count on it);
 //     rows past nB get +inf (fp32 screen) -- the MFMA kernels stage whole tiles;
 //   * SPLIT (bf16x3 screen): the row's split image [128 x bf16 hi | 128 x bf16 lo] (A is scaled by -2 first: exact), and
 //     for candidates the 16-byte k-slot (nb_h, nb_m, nb_l, 1, 1, 1, 0, 0) that adds the norms inside the MFMA chain.
+constexpr int PREP_ROWS = 16;       // rows per 256-thread workgroup
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void prep_kernel(MatchBatch bt)
 {
     const MatchPair &c = bt.p[blockIdx.y];
-    const int nA = c.nA, nB = c.nB, lane = threadIdx.x & 63;
+    const int nA = c.nA, nB = c.nB, lane = threadIdx.x & 63, k4 = lane & 31;
     const int padded = nm_divup_dev(nB, TILE_C) * TILE_C;
-    int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i == 0 && lane == 0 && c.fb_count) *c.fb_count = 0;   // first launch of a match call: resets the fallback list
-    const bool isA = i < nA;
-    if (!isA) i -= nA;
-    if (!isA && i >= nB) {
-        if (i < padded && lane == 0) {
-            c.nb[i] = __builtin_inff();
-            if (SPLIT) c.nbslot[i] = make_uint4(BF16_BIG, BF16_ONE << 16, BF16_ONE | (BF16_ONE << 16), 0u);
-        }
-        return;
-    }
-    const float *X = isA ? c.A : c.B;
-    const float2 v = *reinterpret_cast<const float2 *>(X + (size_t)i * DIM + 2 * lane);
-    double acc = (double)v.x * (double)v.x + (double)v.y * (double)v.y;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && c.fb_count) *c.fb_count = 0;   // first launch of a match call: resets the fallback list
+    const int r0 = blockIdx.x * PREP_ROWS + (threadIdx.x >> 6) * 4 + (lane >> 5);    // this lane's rows: r0 and r0 + 2
+    float4 v[2];
+    int row[2]; bool isA[2], live[2];
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
-    const float nrm = (float)acc;
-    if (SPLIT) {
-        const float sc = isA ? -2.0f : 1.0f;
-        unsigned h0, l0, h1, l1;
-        bf16_split(sc * v.x, h0, l0);
-        bf16_split(sc * v.y, h1, l1);
-        unsigned *row = (isA ? c.As : c.Bs) + (size_t)i * DIM;
-        row[lane] = h0 | (h1 << 16);
-        row[64 + lane] = l0 | (l1 << 16);
+    for (int q = 0; q < 2; ++q) {
+        int i = r0 + 2 * q;
+        isA[q] = i < nA;
+        if (!isA[q]) i -= nA;
+        row[q] = i;
+        live[q] = isA[q] || i < nB;
+        v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live[q]) v[q] = reinterpret_cast<const float4 *>((isA[q] ? c.A : c.B) + (size_t)i * DIM)[k4];
     }
-    if (lane == 0) {
-        (isA ? c.na : c.nb)[i] = nrm;
-        if (SPLIT && !isA) {
-            unsigned h, m, l;
-            bf16_three(nrm, h, m, l);
-            c.nbslot[i] = (nrm < 3.0e38f) ? make_uint4(h | (m << 16), l | (BF16_ONE << 16), BF16_ONE | (BF16_ONE << 16), 0u)
-                                          : make_uint4(BF16_BIG, BF16_ONE << 16, BF16_ONE | (BF16_ONE << 16), 0u);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = row[q];
+        if (!live[q]) {                                   // uniform per half wave
+            if (i < padded && k4 == 0) {
+                c.nb[i] = __builtin_inff();
+                if (SPLIT) c.nbslot[i] = make_uint4(BF16_BIG, BF16_ONE << 16, BF16_ONE | (BF16_ONE << 16), 0u);
+            }
+            continue;
+        }
+        const float4 x = v[q];
+        double acc = ((double)x.x * (double)x.x + (double)x.y * (double)x.y) + ((double)x.z * (double)x.z + (double)x.w * (double)x.w);
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+        const float nrm = (float)acc;
+        if (SPLIT) {
+            const float sc = isA[q] ? -2.0f : 1.0f;
+            unsigned h0, l0, h1, l1, h2, l2, h3, l3;
+            bf16_split(sc * x.x, h0, l0); bf16_split(sc * x.y, h1, l1);
+            bf16_split(sc * x.z, h2, l2); bf16_split(sc * x.w, h3, l3);
+            unsigned *dst = (isA[q] ? c.As : c.Bs) + (size_t)i * DIM;
+            reinterpret_cast<uint2 *>(dst)[k4] = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+            reinterpret_cast<uint2 *>(dst + 64)[k4] = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+        }
+        if (k4 == 0) {
+            (isA[q] ? c.na : c.nb)[i] = nrm;
+            if (SPLIT && !isA[q]) {
+                unsigned h, m, l;
+                bf16_three(nrm, h, m, l);
+                c.nbslot[i] = (nrm < 3.0e38f) ? make_uint4(h | (m << 16), l | (BF16_ONE << 16), BF16_ONE | (BF16_ONE << 16), 0u)
+                                              : make_uint4(BF16_BIG, BF16_ONE << 16, BF16_ONE | (BF16_ONE << 16), 0u);
+            }
         }
     }
 }
@@ -616,10 +631,14 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
                     top3_merge(best, g3, tag);
                 }
             };
+            // tile n + 1 is written into the other buffer in the MIDDLE of tile n (its loads were issued a whole tile
+            // earlier, and every wave left that buffer before the last barrier), and the loads of tile n + 2 follow at
+            // once: at the end of a tile only the barrier is left between the last MFMA of one tile and the first
+            // operand reads of the next
+            if (ntiles > 1) stage_load(t0 + 1);
             for (int n = 0; n < ntiles; ++n) {
                 const float *buf = lds + (n & 1) * (TILE_C * KP);
                 const float *rowp = buf + r * KP + 4 * h;
-                if (n + 1 < ntiles) stage_load(t0 + n + 1);
                 int g1 = KEY_INF, g2 = KEY_INF, g3 = KEY_INF;
                 if (n == 0) {
                     mfma_half_bf16<false>(a0, a1, b0, b1, rowp, buf + r * KP + DIM, qw, qslot, g1, g2, g3);
@@ -627,10 +646,11 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
                     mfma_half_bf16<true>(a0, a1, b0, b1, rowp, buf + r * KP + DIM, qw, qslot, g1, g2, g3);
                     fold(g1, g2, g3, 2 * n - 1);
                 }
+                if (n + 1 < ntiles) stage_write(lds + ((n + 1) & 1) * (TILE_C * KP));
+                if (n + 2 < ntiles) stage_load(t0 + n + 2);
                 g1 = g2 = g3 = KEY_INF;
                 mfma_half_bf16<true>(b0, b1, a0, a1, rowp + 64 * KP, buf + (64 + r) * KP + DIM, qw, qslot, g1, g2, g3);
                 fold(g1, g2, g3, 2 * n);
-                if (n + 1 < ntiles) stage_write(lds + ((n + 1) & 1) * (TILE_C * KP));
                 __syncthreads();
             }
             asm volatile("s_nop 15\n\ts_nop 3" : "+v"(b0), "+v"(b1));
@@ -875,56 +895,78 @@ __global__ __launch_bounds__(256) void match_fallback_kernel(MatchBatch bt)
     const int nB = c.nB;
     const int *__restrict__ fb_list = c.fb_list;
     float4 *__restrict__ part = c.partial;
-    __shared__ __attribute__((aligned(16))) float sX[XD_KC * XD_PITCH];
-    __shared__ __attribute__((aligned(16))) float sY[XD_KC * XD_PITCH];
+    __shared__ __attribute__((aligned(16))) float sXY[2 * XD_KC * XD_PITCH];
+    float *const sX = sXY, *const sY = sXY + XD_KC * XD_PITCH;
     const int count = *c.fb_count;
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int slice = nm_divup_dev(nB, FB_SPLIT);
     const int j0 = blockIdx.x * slice, j1 = min(j0 + slice, nB);
     if (count <= FB_ROWWISE_MAX) {
-        // a handful of rows (the usual case: 0-10 of 12k on SIFT descriptors): a 128-row tile would be almost empty, so
-        // each listed row is scanned by its own pass, one thread per candidate with the query row in registers
-        float *s_m1 = sX, *s_m2 = sX + 4;
-        int *s_i1 = reinterpret_cast<int *>(sX + 8);
-        for (int e = blockIdx.y; e < count; e += gridDim.y) {
-            const int i = fb_list[e];
+        // A handful of rows (the usual case: 0-10 of 12k on SIFT descriptors): a 128-row tile would be almost empty. The
+        // listed rows wait in LDS; the slice's candidates pass through LDS 64 at a time (coalesced loads -- a lane that
+        // streams its own 512-byte candidate row touches 64 cache lines per load instruction, which made this path
+        // ~25 us per listed row); thread (candidate = tid % 64, wave w) then holds its candidate in registers and runs
+        // the exact chain against the rows w, w + 4, ... (broadcast LDS reads). One workgroup per slice (blockIdx.y = 0).
+        constexpr int RW = (FB_ROWWISE_MAX + 3) / 4;          // rows per wave
+        __shared__ __attribute__((aligned(16))) float sQ[FB_ROWWISE_MAX * DIM];
+        static_assert(64 * KP <= 2 * XD_KC * XD_PITCH, "64 candidates at pitch KP fit the tile buffers");
+        if (blockIdx.y != 0 || count <= 0) return;
+        for (int q = tid; q < count * (DIM / 4); q += 256) {
+            const int e = q >> 5, k4 = q & 31;
+            reinterpret_cast<float4 *>(sQ)[q] = reinterpret_cast<const float4 *>(A + (size_t)fb_list[e] * DIM)[k4];
+        }
+        const int cand = tid & 63, w = tid >> 6;
+        float m1[RW], m2[RW]; int i1[RW];
+#pragma unroll
+        for (int s2 = 0; s2 < RW; ++s2) { m1[s2] = __builtin_inff(); m2[s2] = __builtin_inff(); i1[s2] = 0x7fffffff; }
+        for (int c0 = j0; c0 < j1; c0 += 64) {
             __syncthreads();
-            float m1 = __builtin_inff(), m2 = __builtin_inff(); int i1 = 0x7fffffff;
-            if (j0 + tid < j1) {                                   // uniform per wave except the last one of the slice
-                float4 x[DIM / 4];
 #pragma unroll
-                for (int k = 0; k < DIM / 4; ++k) x[k] = reinterpret_cast<const float4 *>(A + (size_t)i * DIM)[k];
-                for (int j = j0 + tid; j < j1; j += 256) {
-                    const float4 *b = reinterpret_cast<const float4 *>(B + (size_t)j * DIM);
-                    float4 y[DIM / 4];
+            for (int it = 0; it < 8; ++it) {
+                const int row = (tid >> 5) + 8 * it, k4 = tid & 31;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c0 + row < j1) v = reinterpret_cast<const float4 *>(B + (size_t)(c0 + row) * DIM)[k4];
+                *reinterpret_cast<float4 *>(&sXY[row * KP + 4 * k4]) = v;
+            }
+            __syncthreads();
+            const int j = c0 + cand;
+            float4 y[DIM / 4];
 #pragma unroll
-                    for (int k = 0; k < DIM / 4; ++k) y[k] = b[k];
+            for (int k = 0; k < DIM / 4; ++k) y[k] = *reinterpret_cast<const float4 *>(&sXY[cand * KP + 4 * k]);
+#pragma unroll
+            for (int s2 = 0; s2 < RW; ++s2) {
+                const int e = w + 4 * s2;
+                if (e < count) {                                 // uniform per wave
+                    const float4 *x = reinterpret_cast<const float4 *>(sQ + e * DIM);
                     float acc = 0.0f;
 #pragma unroll
                     for (int k = 0; k < DIM / 4; ++k) {
+                        const float4 xv = x[k];
                         float tt;
-                        tt = x[k].x - y[k].x; acc = __builtin_fmaf(tt, tt, acc);
-                        tt = x[k].y - y[k].y; acc = __builtin_fmaf(tt, tt, acc);
-                        tt = x[k].z - y[k].z; acc = __builtin_fmaf(tt, tt, acc);
-                        tt = x[k].w - y[k].w; acc = __builtin_fmaf(tt, tt, acc);
+                        tt = xv.x - y[k].x; acc = __builtin_fmaf(tt, tt, acc);
+                        tt = xv.y - y[k].y; acc = __builtin_fmaf(tt, tt, acc);
+                        tt = xv.z - y[k].z; acc = __builtin_fmaf(tt, tt, acc);
+                        tt = xv.w - y[k].w; acc = __builtin_fmaf(tt, tt, acc);
                     }
-                    if (acc < m1) { m2 = m1; m1 = acc; i1 = j; }
-                    else if (acc < m2) m2 = acc;
+                    if (j < j1) {
+                        if (acc < m1[s2]) { m2[s2] = m1[s2]; m1[s2] = acc; i1[s2] = j; }
+                        else if (acc < m2[s2]) m2[s2] = acc;
+                    }
                 }
             }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < RW; ++s2) {
+            const int e = w + 4 * s2;
+            if (e >= count) continue;
+            float a1 = m1[s2], a2 = m2[s2]; int ai = i1[s2];
 #pragma unroll
             for (int sft = 1; sft < 64; sft <<= 1) {
-                const float o1 = __shfl_xor(m1, sft), o2 = __shfl_xor(m2, sft);
-                const int oi = __shfl_xor(i1, sft);
-                top2_merge(m1, i1, m2, o1, oi, o2);
+                const float o1 = __shfl_xor(a1, sft), o2 = __shfl_xor(a2, sft);
+                const int oi = __shfl_xor(ai, sft);
+                top2_merge(a1, ai, a2, o1, oi, o2);
             }
-            const int wave = tid >> 6;
-            if ((tid & 63) == 0) { s_m1[wave] = m1; s_m2[wave] = m2; s_i1[wave] = i1; }
-            __syncthreads();
-            if (tid == 0) {
-                for (int w = 1; w < 4; ++w) top2_merge(m1, i1, m2, s_m1[w], s_i1[w], s_m2[w]);
-                part[(size_t)e * FB_SPLIT + blockIdx.x] = make_float4(m1, __int_as_float(i1), m2, 0.f);
-            }
+            if (cand == 0) part[(size_t)e * FB_SPLIT + blockIdx.x] = make_float4(a1, __int_as_float(ai), a2, 0.f);
         }
         return;
     }
@@ -1261,8 +1303,8 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
         max_a = max(max_a, j.nA);
     }
     if (bt.n == 0) return 0;
-    if (screen) hipLaunchKernelGGL(prep_kernel<true>, dim3(nm_divup(max_rows, 4), bt.n), dim3(256), 0, st, bt);
-    else hipLaunchKernelGGL(prep_kernel<false>, dim3(nm_divup(max_rows, 4), bt.n), dim3(256), 0, st, bt);
+    if (screen) hipLaunchKernelGGL(prep_kernel<true>, dim3(nm_divup(max_rows, PREP_ROWS), bt.n), dim3(256), 0, st, bt);
+    else hipLaunchKernelGGL(prep_kernel<false>, dim3(nm_divup(max_rows, PREP_ROWS), bt.n), dim3(256), 0, st, bt);
     NM_LAUNCH_CHECK();
     hipLaunchKernelGGL(nbmax_kernel, dim3(bt.n), dim3(1024), 0, st, bt);
     NM_LAUNCH_CHECK();
@@ -1289,7 +1331,9 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
     static_assert(FB_SPLIT <= MAX_CHUNKS, "fallback slices reuse the partial area");
     // few rows are ever listed (0-2 of 12k on SIFT data): a small grid drains fastest when the list is empty, and its
     // workgroups loop over the entries when it is not
-    hipLaunchKernelGGL(match_fallback_kernel, dim3(FB_SPLIT, FB_CHUNKS, bt.n), dim3(256), 0, st, bt);
+    // (~1 000 workgroups whatever the number of pairs: with 16 chunk loops for each of 16 pairs the launch spent ~150 us
+    // dispatching 16 384 workgroups that found their lists empty)
+    hipLaunchKernelGGL(match_fallback_kernel, dim3(FB_SPLIT, max(1, FB_CHUNKS / bt.n), bt.n), dim3(256), 0, st, bt);
     NM_LAUNCH_CHECK();
     hipLaunchKernelGGL(match_fallback_merge_kernel, dim3(8, bt.n), dim3(256), 0, st, bt);
     NM_LAUNCH_CHECK();

@@ -221,6 +221,26 @@ def test_fallback_rate_and_forced_fallback(nm, oracle, cuda):
     _, _, (m1r, ixr, m2r) = oracle.sift_matches(A, B, 0.8, want_distance=False)
     assert np.array_equal(ix.cpu().numpy(), ixr)
     assert np.array_equal(m1.cpu().numpy(), m1r) and np.array_equal(m2.cpu().numpy(), m2r)
+    # a handful of unprovable rows among ordinary ones (the few-rows path of the fallback: <= 24 listed rows): three
+    # near-tied candidates inside one candidate tile (a segment reports only its best two with their indices), the
+    # groups spread over the candidate slices, plus an exact duplicate of a tied candidate (lowest index must win)
+    for n_hard in (1, 7, 24):
+        A = rng.uniform(0, 255, (500, 128)).astype(np.float32)
+        B = rng.uniform(0, 255, (2900, 128)).astype(np.float32)
+        for t in range(n_hard):
+            i = 17 * t + 3
+            for c2, jj in enumerate((100 * t + 5, 100 * t + 6, 100 * t + 7)):
+                v = A[i].copy()
+                v[(7 * t + c2) % 128] += np.float32(60.0)
+                v[(11 * t + 5 * c2) % 128] += np.float32(1e-3 * c2)
+                B[jj] = v
+        B[2000] = B[5]                                             # duplicate of a tied candidate of query 3 (t = 0)
+        ws = nm.MatchWorkspace(500, 2900, cuda)
+        m1, ix, m2 = nm.sift_match_shard(_t(A, cuda), _t(B, cuda), 0, workspace=ws)
+        assert n_hard <= nm.match_fallback_count(ws, 500, 2900) <= 24, n_hard
+        _, _, (m1r, ixr, m2r) = oracle.sift_matches(A, B, 0.8, want_distance=False)
+        assert np.array_equal(ix.cpu().numpy(), ixr)
+        assert np.array_equal(m1.cpu().numpy(), m1r) and np.array_equal(m2.cpu().numpy(), m2r)
 
 
 def test_oversized_workspace_is_valid_for_smaller_calls(nm, oracle, cuda):
