@@ -499,21 +499,26 @@ __device__ __forceinline__ void bf16_kstep(f32x16 &acc0, f32x16 &acc1, const u32
 // (8-pass XDL op): the next call's first VALU instruction comes after two more MFMAs and the explicit s_nop below.
 template <bool SELECT>
 __device__ __forceinline__ void mfma_half_bf16(f32x16 &acc0, f32x16 &acc1, const f32x16 &prev0, const f32x16 &prev1,
-                                               const float *rowp, const float *slotp, const u32x4 (&qf)[16],
-                                               const u32x4 qslot, int &g1, int &g2, int &g3)
+                                               const char *tb, const unsigned (&foff)[8], const char *slotp,
+                                               const u32x4 (&qf)[16], const u32x4 qslot, int &g1, int &g2, int &g3)
 {
-    const float *r0 = rowp, *r1 = rowp + 32 * KP;
-    u32x4 h0 = *reinterpret_cast<const u32x4 *>(r0), l0 = *reinterpret_cast<const u32x4 *>(r0 + 64);
-    u32x4 h1 = *reinterpret_cast<const u32x4 *>(r1), l1 = *reinterpret_cast<const u32x4 *>(r1 + 64);
-    const u32x4 s0 = *reinterpret_cast<const u32x4 *>(slotp), s1 = *reinterpret_cast<const u32x4 *>(slotp + 32 * KP);
+    // tb = this lane's candidate row of group 0 in the tile image (512-byte rows, 16-byte chunks XOR-swizzled by row & 15,
+    // see bf16 staging in match_top2_kernel); foff[t] = byte offset of the lane's hi chunk of k-step t; lo = + 256;
+    // group 1 = + 32 rows
+    constexpr int G1 = 32 * 512;
+    u32x4 h0 = *reinterpret_cast<const u32x4 *>(tb + foff[0]), l0 = *reinterpret_cast<const u32x4 *>(tb + 256 + foff[0]);
+    u32x4 h1 = *reinterpret_cast<const u32x4 *>(tb + G1 + foff[0]), l1 = *reinterpret_cast<const u32x4 *>(tb + G1 + 256 + foff[0]);
+    const u32x4 s0 = *reinterpret_cast<const u32x4 *>(slotp), s1 = *reinterpret_cast<const u32x4 *>(slotp + 32 * 16);
     asm volatile(NM_MFMA "%0, %2, %4, 0\n\t" NM_MFMA "%1, %3, %4, 0\n\ts_nop 15\n\ts_nop 3"
                  : "=&v"(acc0), "=&v"(acc1) : "v"(s0), "v"(s1), "v"(qslot) : "memory");
 #define NM_KSTEP(T)                                                                                                      \
     {                                                                                                                    \
         u32x4 nh0 = h0, nl0 = l0, nh1 = h1, nl1 = l1;                                                                    \
         if (T + 1 < 8) { /* next k-step's fragments fly during this step's 6 MFMAs */                                    \
-            nh0 = *reinterpret_cast<const u32x4 *>(r0 + 8 * (T + 1)); nl0 = *reinterpret_cast<const u32x4 *>(r0 + 64 + 8 * (T + 1)); \
-            nh1 = *reinterpret_cast<const u32x4 *>(r1 + 8 * (T + 1)); nl1 = *reinterpret_cast<const u32x4 *>(r1 + 64 + 8 * (T + 1)); \
+            nh0 = *reinterpret_cast<const u32x4 *>(tb + foff[(T + 1) & 7]);                                              \
+            nl0 = *reinterpret_cast<const u32x4 *>(tb + 256 + foff[(T + 1) & 7]);                                        \
+            nh1 = *reinterpret_cast<const u32x4 *>(tb + G1 + foff[(T + 1) & 7]);                                         \
+            nl1 = *reinterpret_cast<const u32x4 *>(tb + G1 + 256 + foff[(T + 1) & 7]);                                   \
         }                                                                                                                \
         const f32x16 &pv = (T < 4) ? prev0 : prev1;                                                                      \
         bf16_kstep<SELECT, 4 * T>(acc0, acc1, h0, l0, h1, l1, qf[T], qf[8 + T], pv[(4 * T) & 15], pv[(4 * T + 1) & 15],    \
@@ -573,6 +578,30 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
         }
     };
 
+    // bf16x3 screen: the candidate tiles go global -> LDS directly (buffer_load ... lds: no staging registers, no
+    // ds_write pass). One wave-instruction lands 1 KiB = two 512-byte rows, lane-linear, so the tile image has NO row
+    // padding; bank conflicts are avoided by XOR-swizzling the 16-byte chunks of a row with (row & 15) -- applied to the
+    // per-lane SOURCE address here and to the fragment reads' offsets (foff), the same involution on both sides. The
+    // 16-byte norm slots live in their own 2 KiB per buffer behind the two 64 KiB images (same total as the padded layout).
+    constexpr int IMG = TILE_C * DIM * 4, SLOT0 = 2 * IMG, SLOTB = TILE_C * 16;
+    char *const ldsb = reinterpret_cast<char *>(lds);
+    unsigned foff[8], dvoff[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        foff[t] = (unsigned)(((2 * t + h) ^ (r & 15)) << 4);
+        const int p = lane & 31, key = (2 * t + (lane >> 5)) & 15;        // wave-instruction t of a wave covers rows 2 (8 wave + t) + (lane >> 5)
+        dvoff[t] = (unsigned)((lane >> 5) * (DIM * 4) + (((p & 16) | ((p & 15) ^ key)) << 4));
+    }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // scalar for the compiler: M0 and the scalar offset depend on it
+    auto dma_tile = [&](int tile, int b) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            typedef __attribute__((address_space(3))) void lds_void;
+            lds_void *dst = (lds_void *)(ldsb + b * IMG + (wave_u * 8 + t) * 1024);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, dst, 16, (int)dvoff[t], (tile * TILE_C + 2 * (wave_u * 8 + t)) * (DIM * 4), 0, 0);
+        }
+    };
+
     long u;
     while (it.next(plan, grp, u)) {
         int pc, qbl, tt, Lc;
@@ -584,7 +613,8 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
 
         // ---- segment prologue: the first candidate tile is requested first (its latency hides behind the query staging),
         //      queries -> LDS (coalesced) -> per-lane MFMA fragments in VGPRs ----
-        stage_load(t0);
+        if (BF16) { if (tid < TILE_C) sts = nbslot[t0 * TILE_C + tid]; }
+        else stage_load(t0);
 #pragma unroll 4
         for (int it = 0; it < QB / 16; ++it) {
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff, (i0 + 16 * it) * (DIM * 4), 0);
@@ -612,7 +642,12 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
             qslot = (u32x4){BF16_ONE | (BF16_ONE << 16), BF16_ONE | (nh << 16), nm | (nl << 16), 0u};
         }
         __syncthreads();
-        stage_write(lds);
+        if (BF16) {
+            dma_tile(t0, 0);
+            if (tid < TILE_C) *reinterpret_cast<uint4 *>(ldsb + SLOT0 + tid * 16) = sts;
+        } else {
+            stage_write(lds);
+        }
         __syncthreads();
 
         Top3 best;
@@ -631,26 +666,27 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
                     top3_merge(best, g3, tag);
                 }
             };
-            // tile n + 1 is written into the other buffer in the MIDDLE of tile n (its loads were issued a whole tile
-            // earlier, and every wave left that buffer before the last barrier), and the loads of tile n + 2 follow at
-            // once: at the end of a tile only the barrier is left between the last MFMA of one tile and the first
-            // operand reads of the next
-            if (ntiles > 1) stage_load(t0 + 1);
+            // tile n + 1 starts landing in the other buffer at the START of tile n (every wave left that buffer before the
+            // last barrier); the barrier at the end of tile n waits for it (vmcnt(0), emitted by the compiler)
             for (int n = 0; n < ntiles; ++n) {
-                const float *buf = lds + (n & 1) * (TILE_C * KP);
-                const float *rowp = buf + r * KP + 4 * h;
+                const int b = n & 1;
+                const char *tb = ldsb + b * IMG + r * (DIM * 4);
+                const char *sp = ldsb + SLOT0 + b * SLOTB + r * 16;
+                if (n + 1 < ntiles) {
+                    if (tid < TILE_C) sts = nbslot[(t0 + n + 1) * TILE_C + tid];
+                    dma_tile(t0 + n + 1, b ^ 1);
+                }
                 int g1 = KEY_INF, g2 = KEY_INF, g3 = KEY_INF;
                 if (n == 0) {
-                    mfma_half_bf16<false>(a0, a1, b0, b1, rowp, buf + r * KP + DIM, qw, qslot, g1, g2, g3);
+                    mfma_half_bf16<false>(a0, a1, b0, b1, tb, foff, sp, qw, qslot, g1, g2, g3);
                 } else {
-                    mfma_half_bf16<true>(a0, a1, b0, b1, rowp, buf + r * KP + DIM, qw, qslot, g1, g2, g3);
+                    mfma_half_bf16<true>(a0, a1, b0, b1, tb, foff, sp, qw, qslot, g1, g2, g3);
                     fold(g1, g2, g3, 2 * n - 1);
                 }
-                if (n + 1 < ntiles) stage_write(lds + ((n + 1) & 1) * (TILE_C * KP));
-                if (n + 2 < ntiles) stage_load(t0 + n + 2);
                 g1 = g2 = g3 = KEY_INF;
-                mfma_half_bf16<true>(b0, b1, a0, a1, rowp + 64 * KP, buf + (64 + r) * KP + DIM, qw, qslot, g1, g2, g3);
+                mfma_half_bf16<true>(b0, b1, a0, a1, tb + 64 * (DIM * 4), foff, sp + 64 * 16, qw, qslot, g1, g2, g3);
                 fold(g1, g2, g3, 2 * n);
+                if (n + 1 < ntiles && tid < TILE_C) *reinterpret_cast<uint4 *>(ldsb + SLOT0 + (b ^ 1) * SLOTB + tid * 16) = sts;
                 __syncthreads();
             }
             asm volatile("s_nop 15\n\ts_nop 3" : "+v"(b0), "+v"(b1));
