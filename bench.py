@@ -25,6 +25,9 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA (~2.5 PF
 # MFMA flops the bf16x3 screen EXECUTES per algorithmic flop: 3 products per (a_k, b_k) + one 16-deep k-slot step for
 # the norms = (3 * 128 + 16) / 128
 BF16X3_EXECUTED_PER_ALGORITHMIC = (3 * 128 + 16) / 128.0
+# what a bare v_mfma_f32_32x32x16_bf16 loop sustains on this device (1.8 GHz under dense bf16 MFMA load):
+# profiles/r02_k_mfma_bf16_peak_microbench.txt. Reported beside the nominal peak, never instead of it.
+MFMA_BF16_SUSTAINED_MEASURED_TFLOPS = 1850.0
 
 
 def make_frames(nm, torch, dev, seeds):
@@ -556,6 +559,8 @@ def main():
                     "executed_TFLOPs": round(ach * BF16X3_EXECUTED_PER_ALGORITHMIC, 3),
                     "frac_executed": round(ach * BF16X3_EXECUTED_PER_ALGORITHMIC / MFMA_BF16_PEAK_TFLOPS, 4),
                     "vs_f32_mfma_peak": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                    "sustained_bf16_mfma_measured": MFMA_BF16_SUSTAINED_MEASURED_TFLOPS,
+                    "frac_executed_of_sustained": round(ach * BF16X3_EXECUTED_PER_ALGORITHMIC / MFMA_BF16_SUSTAINED_MEASURED_TFLOPS, 4),
                     "note": "screen on split bf16 operands (a_h.b_h + a_h.b_l + a_l.b_h); match decisions are made on "
                             "distances recomputed exactly in fp32 (results bit-identical to the fp32 screen and the oracle)"}
         roof.update({"traffic": t_match if screen == "f32" else traffic.get("match_top2_kernel_bf16x3", {}).get("hbm_bytes_per_launch"),
