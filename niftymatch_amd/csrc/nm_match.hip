@@ -544,7 +544,7 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int srow = tid >> 5, scol = (tid & 31) * 4;     // staging coordinates: 16 rows x 32 float4 per pass
-    const int T = plan.T, S = plan.S;
+    const int S = plan.S;
     const int wg = blockIdx.x;
     const int xg = wg % plan.X, vg = wg / plan.X;         // XCD group (blocks b, b + X share an XCD) and position in it
     const PlanGroup grp = plan_group(plan, xg);
