@@ -181,7 +181,7 @@ def detect_256(nm, torch, dist, dev, cdev, rank, world, arenas, streams, B):
             "ms_total": round(1e3 * dt, 3), "keypoints_total": int(kp_all), "collective": "none"}
 
 
-def roofline_pyramid(B, o0_ms, all_ms, traffic):
+def roofline_pyramid(B, o0_ms, all_ms, traffic, nodog_ms=None):
     """Whole scale-space chain of one B-frame detect call against HBM. `achieved` follows the bench contract: ALGORITHMIC
     bytes (108 B per octave-pixel = 48 Gaussian + 60 DoG; the fused gradient planes add 36) over the
     measured duration. `traffic` is the HBM-side byte count of the same sequence from the rocprofv3 PMC passes in
@@ -205,6 +205,13 @@ def roofline_pyramid(B, o0_ms, all_ms, traffic):
         if t_all:
             out["physical_GBps"] = round(t_all * B / (all_ms * 1e-3) / 1e9, 1)
             out["physical_frac"] = round(t_all * B / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    if nodog_ms:
+        # what nm_sift_detect_describe_batch itself runs since round 2: the same chain WITHOUT materialised DoG planes (its
+        # detection kernel subtracts consecutive levels): 48 B/px of Gaussian levels (+ 4 for level 5) + 36 of gradients
+        out["frame_driver_chain"] = {"note": "the chain the frame driver issues: no DoG planes (detection forms them from the levels)",
+                                     "avg_ms": round(nodog_ms, 4), "us_per_frame": round(1e3 * nodog_ms / B, 2),
+                                     "algorithmic_bytes": 84.0 * sum_px * B,
+                                     "algorithmic_GBps": round(84.0 * sum_px * B / (nodog_ms * 1e-3) / 1e9, 1)}
     o0_alg = 136.0 * W * H * B           # octave 0, levels 1..5: 40 (Gaussian) + 60 (DoG) + 36 (gradients) B/px
     if o0_ms == o0_ms:                   # not NaN
         out["octave0"] = {"kernel": "octave-0 part of the same chain (5 launches), from the library profile hook during the probe",
@@ -440,7 +447,7 @@ def main():
 
     # whole-pyramid probe (after the timed region, chip otherwise idle): the scale-space launches of one B-frame detect call,
     # every octave, timed with events on the stream they run on
-    pyr_all_ms = None
+    pyr_all_ms = pyr_nodog_ms = None
     try:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(mstream):
@@ -457,8 +464,15 @@ def main():
                 nm.profile_events(nm.PROF_PYRAMID_O0, None, None)
                 mstream.synchronize()
                 pyr_ms.append(ev_pyr[0][0].elapsed_time(ev_pyr[0][1]))
+            e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            nm.scale_space_batch(arenas[:B], frames[:B], write_dog=False)
+            e2.record()
+            for _ in range(reps):
+                nm.scale_space_batch(arenas[:B], frames[:B], write_dog=False)
+            e3.record()
         mstream.synchronize()
         pyr_all_ms = e0.elapsed_time(e1) / reps
+        pyr_nodog_ms = e2.elapsed_time(e3) / reps
     except Exception as exc:
         pyr_all_ms = None
 
@@ -590,7 +604,7 @@ def main():
             "keypoints_per_s": round(kp_all * args.steps / dt, 1),
             "descriptor_comparisons_per_s": round(cmp_all * args.steps / dt, 1),
             "roofline": roof,
-            "roofline_pyramid": roofline_pyramid(B, p_ms, pyr_all_ms, traffic),
+            "roofline_pyramid": roofline_pyramid(B, p_ms, pyr_all_ms, traffic, pyr_nodog_ms),
         }
         if roof_f32 is not None:
             out["roofline_f32_screen"] = roof_f32

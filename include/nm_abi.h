@@ -316,6 +316,11 @@ NM_API int nm_sift_detect_describe_batch(nm_sift_arena *const *arenas, int n, co
  * are those of the last octave. bench.py times this sequence for the whole-pyramid roofline (SURVEY.md 8(d):
  * 108 B per octave-pixel + 36 B for the gradients).                                                              */
 NM_API int nm_sift_scale_space_batch(nm_sift_arena *const *arenas, int n, const float *const *gray, void *stream);
+/* The same chain with (write_dog = 1, what nm_sift_scale_space_batch does: levels + DoG + gradient planes, the 108 B per
+ * octave-pixel yardstick) or without (0) materialised DoG planes. nm_sift_detect_describe[_batch] runs the latter: its
+ * detection kernel subtracts consecutive levels itself, so 16 of the chain's 64 written bytes per pixel are never moved. */
+NM_API int nm_sift_scale_space_batch_ex(nm_sift_arena *const *arenas, int n, const float *const *gray, int write_dog,
+                                        void *stream);
 /* Pointers into the arena for stage-level inspection (tests, profiling): Gaussian level l (0..5) and DoG d (0..4)
  * planes of the LAST processed octave geometry are overwritten per octave, so these are meaningful only after
  * nm_sift_octave_pyramid().                                                                                      */

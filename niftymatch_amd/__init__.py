@@ -82,6 +82,7 @@ _SIGNATURES = {
     "nm_sift_detect_describe": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nm_sift_detect_describe_batch": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nm_sift_scale_space_batch": (_I, [_P, _I, _P, _P]),
+    "nm_sift_scale_space_batch_ex": (_I, [_P, _I, _P, _I, _P]),
     "nm_sift_arena_level": (_P, [_P, _I]), "nm_sift_arena_dog": (_P, [_P, _I]), "nm_sift_arena_grad": (_P, [_P]),
     "nm_sift_octave_pyramid": (_I, [_P, _I, _I, _P]),
     "nm_client_detect_describe": (_I, [_P, _I, _I, _I, _P, _P, _P]),
@@ -557,15 +558,17 @@ def detect_describe_batch(arenas, grays):
         arr([_dev(a.num_items) for a in arenas]), _stream()), "nm_sift_detect_describe_batch")
 
 
-def scale_space_batch(arenas, grays):
-    """Only the scale-space launches of detect_describe_batch (nm_sift_scale_space_batch), on the current stream."""
+def scale_space_batch(arenas, grays, write_dog=True):
+    """Only the scale-space launches (nm_sift_scale_space_batch_ex), on the current stream. write_dog=True: levels + DoG +
+    gradient planes (the 108 B per octave-pixel chain); False: what detect_describe_batch runs (no DoG planes)."""
     torch = _torch()
     n = len(arenas)
     if n != len(grays) or not 0 < n <= SIFT_MAX_BATCH:
         raise NmError("batch of %d arenas / %d frames (max %d)" % (n, len(grays), SIFT_MAX_BATCH))
-    _check(lib().nm_sift_scale_space_batch((C.c_void_p * n)(*[a._h.value for a in arenas]), n,
-                                           (C.c_void_p * n)(*[_dev(g, torch.float32) for g in grays]), _stream()),
-           "nm_sift_scale_space_batch")
+    _check(lib().nm_sift_scale_space_batch_ex((C.c_void_p * n)(*[a._h.value for a in arenas]), n,
+                                              (C.c_void_p * n)(*[_dev(g, torch.float32) for g in grays]),
+                                              1 if write_dog else 0, _stream()),
+           "nm_sift_scale_space_batch_ex")
 
 
 class SiftArena:

@@ -33,7 +33,10 @@ struct nm_sift_arena {
     std::vector<void *> allocs;
     float *taps_base; int base_radius;
     float *taps[8]; int radii[8];
-    float *level[6];           // Gaussian levels, reused by every octave (the pyramid chain is sequential)
+    float *level[6];           // Gaussian levels of octave 0 (and of every octave in the single-octave API call)
+    float *lev[20][6];         // Gaussian levels PER OCTAVE (lev[0] = level): the frame driver's detection reads them (DoG =
+                               // difference of consecutive levels, formed in the detection kernel) while the next octave's
+                               // pyramid is being computed, so the octaves cannot share planes
     float *dog[20][5];         // DoG planes PER OCTAVE: detection of octave o overlaps the pyramid of octave o+1
     hipStream_t side;          // detection / compaction stream forked off the caller's stream
     hipEvent_t ev_pyr[20], ev_join;
@@ -138,6 +141,9 @@ int nm_sift_arena_create(int width, int height, int capacity, nm_sift_arena **ou
     rc = upload(P._base_smooth, &a->taps_base, &a->base_radius);
     for (size_t i = 0; !rc && i < P._sigmas.size(); ++i) rc = upload(P._sigmas[i], &a->taps[i], &a->radii[i]);
     for (int i = 0; !rc && i < 6; ++i) rc = a->alloc(&a->level[i], a->npix);
+    for (int i = 0; i < 6; ++i) a->lev[0][i] = a->level[i];
+    for (int o = 1; !rc && o < P._num_octaves; ++o)
+        for (int i = 0; !rc && i < 6; ++i) rc = a->alloc(&a->lev[o][i], (size_t)(width >> o) * (height >> o));
     for (int o = 0; !rc && o < P._num_octaves; ++o) {
         const size_t plane = (size_t)(width >> o) * (height >> o);
         for (int i = 0; !rc && i < 5; ++i) rc = a->alloc(&a->dog[o][i], plane);
@@ -177,8 +183,18 @@ float *nm_sift_arena_level(nm_sift_arena *a, int l) { return (a && l >= 0 && l <
 float *nm_sift_arena_dog(nm_sift_arena *a, int d) { return (a && d >= 0 && d < 5) ? a->dog[0][d] : nullptr; }
 float *nm_sift_arena_grad(nm_sift_arena *a) { return a ? a->grad[0] : nullptr; }
 
+// write_dog = false (frame driver): the DoG planes are not materialised -- detection forms them from the levels -- which
+// takes 20 of the chain's 64 written bytes per pixel away (level 5 has to be stored instead: + 4). per_octave: the
+// levels live in the octave's own planes (lev[o]); otherwise in level[] (single-octave API call).
+// NM_FRAME_DOG=1: the frame driver materialises the DoG planes as in round 1 (detection then reads them).
+static bool frame_driver_writes_dog()
+{
+    static const bool v = [] { const char *e = getenv("NM_FRAME_DOG"); return e && e[0] == '1'; }();
+    return v;
+}
+
 static int octave_pyramid(nm_sift_arena *const *as, int n, int o, int ow, int oh, bool store_top, bool decimate,
-                          hipStream_t st)
+                          hipStream_t st, bool write_dog = true, bool per_octave = false)
 {
     if (o == 0) nm_prof_begin(NM_PROF_PYRAMID_O0, st);
     const size_t plane = (size_t)ow * oh;
@@ -190,13 +206,14 @@ static int octave_pyramid(nm_sift_arena *const *as, int n, int o, int ow, int oh
         b.n = n;
         for (int f = 0; f < n; ++f) {
             nm_sift_arena *a = as[f];
-            b.result[f] = (i < 5 || store_top) ? a->level[i] : nullptr;     // level 5 is only read through DoG 4
-            b.image[f] = a->level[i - 1];
-            b.dog[f] = a->dog[o][i - 1];
+            float *const *lv = per_octave ? a->lev[o] : a->level;
+            b.result[f] = (i < 5 || store_top) ? lv[i] : nullptr;     // level 5 is only read through DoG 4
+            b.image[f] = lv[i - 1];
+            b.dog[f] = write_dog ? a->dog[o][i - 1] : nullptr;
             b.grad[f] = (i >= 2 && i <= 4) ? a->grad[o] + 2 * (size_t)(i - 2) * plane : nullptr;
             // level 3 decimated IS the next octave's level 0 (pyramidata / downsample.cu); level[0] of this octave was
             // consumed by the first launch of the sequence, so its plane can take it straight away
-            b.down[f] = (decimate && i == 3) ? a->level[0] : nullptr;
+            b.down[f] = (decimate && i == 3) ? (per_octave ? a->lev[o + 1][0] : a->level[0]) : nullptr;
         }
         rc = nm_launch_convolve_batch(b, ow, oh, as[0]->taps[i - 1], as[0]->radii[i - 1], st);
     }
@@ -253,11 +270,12 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
     }
     hipStream_t side = as[0]->side;          // every detection / description launch covers all frames of the call
     bool forked = false;
+    const bool dogs = frame_driver_writes_dog();
     auto body = [&]() -> int {
         for (int o = 0; o < P._num_octaves; ++o) {
             const int ow = W >> o, oh = H >> o;
             const float xper = (float)std::pow(2.0, o);
-            int e = octave_pyramid(as, n, o, ow, oh, false, o + 1 < P._num_octaves, st);
+            int e = octave_pyramid(as, n, o, ow, oh, !dogs, o + 1 < P._num_octaves, st, dogs, true);
             if (e) return e;
             NM_RETURN_IF(hipEventRecord(as[0]->ev_pyr[o], st));
             NM_RETURN_IF(hipStreamWaitEvent(side, as[0]->ev_pyr[o], 0));
@@ -272,12 +290,14 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
             d.ow = ow; d.oh = oh; d.peak = P._peak_threshold; d.edge = P._edge_threshold; d.xper = xper;
             d.sigma0 = P._sigma_0; d.num_dogs = P._num_dog_levels; d.stage_stride = as[0]->stage_stride;
             d.n_blocks = n_blocks; d.nseg = nseg;
+            d.from_levels = dogs ? 0 : 1;
             s.n_blocks = n_blocks; s.octave = o;
             g.stage_stride = as[0]->stage_stride; g.n_blocks = n_blocks; g.octave = o;
             s.capacity = as[0]->capacity; g.capacity = as[0]->capacity;
             for (int f = 0; f < n; ++f) {
                 nm_sift_arena *a = as[f];
                 for (int i = 0; i < 5; ++i) d.dog[f][i] = a->dog[o][i];
+                for (int i = 0; i < 6; ++i) d.lev[f][i] = a->lev[o][i];
                 d.staging[f] = a->staging; d.counts[f] = a->counts;
                 s.counts[f] = a->counts; s.offsets[f] = a->offsets; s.book[f] = a->book;
                 s.d_num_items[f] = d_num_items ? d_num_items[f] : nullptr;
@@ -305,7 +325,7 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
 // The scale-space chain of nm_sift_detect_describe_batch alone (base blur, then per octave the five fused Gaussian + DoG +
 // gradient launches with the decimation in the level-3 epilogue), exactly the launches the frame driver issues on the
 // caller's stream, without detection / description: what bench.py times for the whole-pyramid roofline.
-int nm_sift_scale_space_batch(nm_sift_arena *const *as, int n, const float *const *gray, void *stream)
+int nm_sift_scale_space_batch_ex(nm_sift_arena *const *as, int n, const float *const *gray, int write_dog, void *stream)
 {
     if (!as || n <= 0 || n > NM_MAX_BATCH || !gray) return (int)hipErrorInvalidValue;
     int cur = -1;
@@ -322,8 +342,13 @@ int nm_sift_scale_space_batch(nm_sift_arena *const *as, int n, const float *cons
     for (int f = 0; f < n; ++f) { base.result[f] = as[f]->level[0]; base.image[f] = gray[f]; }
     int rc = nm_launch_convolve_batch(base, W, H, as[0]->taps_base, as[0]->base_radius, st);
     for (int o = 0; !rc && o < P._num_octaves; ++o)
-        rc = octave_pyramid(as, n, o, W >> o, H >> o, false, o + 1 < P._num_octaves, st);
+        rc = octave_pyramid(as, n, o, W >> o, H >> o, !write_dog, o + 1 < P._num_octaves, st, write_dog != 0, true);
     return rc;
+}
+
+int nm_sift_scale_space_batch(nm_sift_arena *const *as, int n, const float *const *gray, void *stream)
+{
+    return nm_sift_scale_space_batch_ex(as, n, gray, 1, stream);
 }
 
 int nm_sift_detect_describe(nm_sift_arena *a, const float *gray, float *desc, float *x, float *y, float *kpts,

@@ -29,15 +29,31 @@ __device__ __forceinline__ bool is_extremum(const float *__restrict__ cur, const
     return true;
 }
 
+// Where refine() takes its 3 x 3 x 3 neighbourhood from: three DoG planes, or four Gaussian levels whose differences they are
+// (frame driver without materialised DoG planes: dn = l1 - l0, cur = l2 - l1, up = l3 - l2, the subtraction of
+// cudamath.cu:26-35 / siftfunctions.cu:42-51 done on the fly).
+struct DogPlanes {
+    const float *__restrict__ cur, *__restrict__ dn, *__restrict__ up;
+    __device__ __forceinline__ float c(size_t i) const { return cur[i]; }
+    __device__ __forceinline__ float d(size_t i) const { return dn[i]; }
+    __device__ __forceinline__ float u(size_t i) const { return up[i]; }
+};
+struct LevelPlanes {
+    const float *__restrict__ l0, *__restrict__ l1, *__restrict__ l2, *__restrict__ l3;
+    __device__ __forceinline__ float c(size_t i) const { return l2[i] - l1[i]; }
+    __device__ __forceinline__ float d(size_t i) const { return l1[i] - l0[i]; }
+    __device__ __forceinline__ float u(size_t i) const { return l3[i] - l2[i]; }
+};
+
 // keypoint.cu:108-180. The float/double mix of the reference is kept literally; a*b+c contractions are explicit.
-__device__ __forceinline__ bool refine(const float *__restrict__ cur, const float *__restrict__ dn,
-                                       const float *__restrict__ up, int x, int y, int w, float peak, float edge,
-                                       float xper, float sigma0, int num_dogs, int level, float4 &out)
+template <typename PL>
+__device__ __forceinline__ bool refine_at(const PL &pl, int x, int y, int w, float peak, float edge,
+                                          float xper, float sigma0, int num_dogs, int level, float4 &out)
 {
     const size_t o = (size_t)y * w + x;
-#define C_(dx, dy) cur[o + (dy) * w + (dx)]
-#define D_(dx, dy) dn[o + (dy) * w + (dx)]
-#define U_(dx, dy) up[o + (dy) * w + (dx)]
+#define C_(dx, dy) pl.c(o + (dy) * w + (dx))
+#define D_(dx, dy) pl.d(o + (dy) * w + (dx))
+#define U_(dx, dy) pl.u(o + (dy) * w + (dx))
     const float c = C_(0, 0);
     const float fx = (float)(0.5 * (double)(C_(1, 0) - C_(-1, 0)));
     const float fy = (float)(0.5 * (double)(C_(0, 1) - C_(0, -1)));
@@ -84,6 +100,12 @@ __device__ __forceinline__ bool refine(const float *__restrict__ cur, const floa
         return true;
     }
     return false;
+}
+__device__ __forceinline__ bool refine(const float *__restrict__ cur, const float *__restrict__ dn,
+                                       const float *__restrict__ up, int x, int y, int w, float peak, float edge,
+                                       float xper, float sigma0, int num_dogs, int level, float4 &out)
+{
+    return refine_at(DogPlanes{cur, dn, up}, x, y, w, peak, edge, xper, sigma0, num_dogs, level, out);
 }
 
 // Bilinear, border-addressed, unnormalised fetch of the full-resolution mask (utils/cudatex2D.cu:15-19).
@@ -267,14 +289,14 @@ __device__ __forceinline__ float min3f(float a, float b, float c) { return __bui
 
 constexpr int DET_ROWS = 4;      // image rows per workgroup: 6 rows are loaded for 4 tested (measured best of 4, 5, 6, 8)
 
-template <bool DENSE>
+template <bool DENSE, bool LEV = false>
 __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
 {
     __shared__ unsigned char s_x[DET_ROWS][3][4][64];    // candidate lanes per (row, level, wave), in lane order
     __shared__ int s_cnt[DET_ROWS * 12 + 1];              // sub-list lengths, then their exclusive scan (+ total)
     __shared__ int s_acc[DET_ROWS * 3], s_last[DET_ROWS * 3], s_wtot[4], s_pref[257];
     const int frame = blockIdx.y;
-    const float *const *dog = a.dog[frame];
+    const float *const *dog = LEV ? a.lev[frame] : a.dog[frame];       // LEV: the six Gaussian levels
     const int seg = blockIdx.x % a.nseg, yg = blockIdx.x / a.nseg;
     const int y0 = yg * DET_ROWS;
     const int x = seg * 256 + threadIdx.x;
@@ -293,6 +315,19 @@ __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
     float raw_mid[2][5], raw_ev[2][5];
     auto fetch_row = [&](int yy, int buf) {
         const int yr = min(max(yy, 0), oh - 1);
+        if (LEV) {                              // DoG p = level p + 1 - level p, formed here instead of read
+            float lm[6], le[6];
+#pragma unroll
+            for (int p = 0; p < 6; ++p) {
+                const float *row = dog[p] + (size_t)yr * ow;
+                lm[p] = row[xc];
+                le[p] = 0.f;
+                if (edge_lane) le[p] = row[xe];
+            }
+#pragma unroll
+            for (int p = 0; p < 5; ++p) { raw_mid[buf][p] = lm[p + 1] - lm[p]; raw_ev[buf][p] = le[p + 1] - le[p]; }
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < 5; ++p) {
             const float *row = dog[p] + (size_t)yr * ow;
@@ -385,7 +420,11 @@ __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
             lvl = g - 3 * jr;
             px = seg * 256 + w * 64 + s_x[jr][lvl][w][c - s_cnt[lo]];
             py = y0 + jr;
-            acc = refine(dog[lvl + 1], dog[lvl], dog[lvl + 2], px, py, ow, a.peak, a.edge, a.xper, a.sigma0, a.num_dogs, lvl, kp);
+            if (LEV)
+                acc = refine_at(LevelPlanes{dog[lvl], dog[lvl + 1], dog[lvl + 2], dog[lvl + 3]}, px, py, ow, a.peak, a.edge, a.xper,
+                                a.sigma0, a.num_dogs, lvl, kp);
+            else
+                acc = refine(dog[lvl + 1], dog[lvl], dog[lvl + 2], px, py, ow, a.peak, a.edge, a.xper, a.sigma0, a.num_dogs, lvl, kp);
         }
         if (DENSE) {
             if (c < total) reinterpret_cast<float4 *>(a.dense[lvl])[(size_t)py * ow + px] = kp;    // kp stays -1 when rejected
@@ -484,7 +523,10 @@ __global__ __launch_bounds__(256) void gather_stage_kernel(NmGatherArgs a)
 int nm_launch_detect_octave(const NmDetectArgs &d, const NmScanArgs &s, const NmGatherArgs &g, hipStream_t stream)
 {
     if (d.n_blocks <= 0 || d.n <= 0) return 0;
-    hipLaunchKernelGGL(detect_stage_kernel<false>, dim3(d.nseg * nm_divup(d.oh, DET_ROWS), d.n), dim3(256), 0, stream, d);
+    if (d.from_levels)
+        hipLaunchKernelGGL((detect_stage_kernel<false, true>), dim3(d.nseg * nm_divup(d.oh, DET_ROWS), d.n), dim3(256), 0, stream, d);
+    else
+        hipLaunchKernelGGL((detect_stage_kernel<false, false>), dim3(d.nseg * nm_divup(d.oh, DET_ROWS), d.n), dim3(256), 0, stream, d);
     NM_LAUNCH_CHECK();
     hipLaunchKernelGGL(scan_book_kernel, dim3(s.n), dim3(1024), 0, stream, s);
     NM_LAUNCH_CHECK();

@@ -6,6 +6,8 @@
 struct NmDetectArgs {
     int n;                                  // frames
     const float *dog[NM_MAX_BATCH][5];      // DoG planes 0..4 of the octave
+    const float *lev[NM_MAX_BATCH][6];      // from_levels: the octave's Gaussian levels 0..5 instead -- DoG i = lev[i + 1] - lev[i]
+    int from_levels;                        // is formed on the fly (the same fp32 subtraction the pyramid kernel stores)
     int ow, oh;
     float peak, edge, xper, sigma0;
     int num_dogs;

@@ -609,7 +609,7 @@ static int launch_conv_rvt(float *result, const float *image, float *buffer, flo
     } else if (dog) {
         NM_CONV_LAUNCH(false, true, false);
     } else if (grad) {
-        return (int)hipErrorInvalidValue;
+        NM_CONV_LAUNCH(false, false, true);
     } else {
         NM_CONV_LAUNCH(false, false, false);
     }
@@ -632,6 +632,7 @@ static int launch_conv_pk(const NmConvBatch &b, int width, int height, const flo
                        ntiles, bpf, nxcd)
     if (dog && grad) NM_PK_LAUNCH(true, true);
     else if (dog) NM_PK_LAUNCH(true, false);
+    else if (grad) NM_PK_LAUNCH(false, true);       // frame driver: the DoG planes are not materialised (detection subtracts the levels)
     else NM_PK_LAUNCH(false, false);
 #undef NM_PK_LAUNCH
     NM_LAUNCH_CHECK();
@@ -661,7 +662,7 @@ static int launch_conv_rv(float *result, const float *image, float *buffer, floa
     if (VEC && buffer && !dog && !grad && result && (size_t)width * height * 4 < (1ull << 32) &&
         ((reinterpret_cast<uintptr_t>(buffer) | reinterpret_cast<uintptr_t>(result)) & 15) == 0)
         return launch_conv_pk_buf<R>(result, image, buffer, width, height, taps, stream);
-    if (VEC && !buffer && !(grad && !dog) && (size_t)width * height * 4 < (1ull << 32)) {
+    if (VEC && !buffer && (size_t)width * height * 4 < (1ull << 32)) {
         NmConvBatch b{};
         b.result[0] = result; b.image[0] = image; b.dog[0] = dog; b.grad[0] = grad; b.n = 1;
         return launch_conv_pk<R>(b, width, height, taps, stream);
@@ -718,7 +719,7 @@ int nm_launch_convolve_batch(const NmConvBatch &b, int width, int height, const 
 {
     if (b.n <= 0 || width <= 0 || height <= 0) return 0;
     if (b.n > NM_MAX_BATCH) return (int)hipErrorInvalidValue;
-    bool pk = (width % 4 == 0) && (size_t)width * height * 4 < (1ull << 32) && !(b.grad[0] && !b.dog[0]);
+    bool pk = (width % 4 == 0) && (size_t)width * height * 4 < (1ull << 32);
     for (int f = 0; f < b.n; ++f) {
         pk = pk && ((reinterpret_cast<uintptr_t>(b.image[f]) & 15) == 0);
         pk = pk && ((b.result[f] != nullptr) == (b.result[0] != nullptr)) && ((b.dog[f] != nullptr) == (b.dog[0] != nullptr)) &&

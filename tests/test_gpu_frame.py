@@ -230,3 +230,34 @@ def test_dense_candidates_take_several_refinement_passes(nm, oracle, cuda, wh):
             want.append(lists_ref[l][:n])
         assert cnt.cpu().tolist() == [len(x) for x in want]
         _eq(out[: sum(len(x) for x in want)], np.concatenate(want), "compact ordered lists, capacity %d" % cap)
+
+
+def test_frame_driver_with_materialised_dog_planes(nm, oracle, cuda, tmp_path):
+    """NM_FRAME_DOG=1 (read once per process, so a child process): the frame driver writes the DoG planes and detection
+    reads them, as in round 1, instead of forming them from the Gaussian levels. Same keypoints and descriptors."""
+    import os
+    import subprocess
+    import sys
+    frames = {"a": H.blurred_frame(3, 320, 200), "b": H.blurred_frame(4, 250, 187)}
+    np.savez(tmp_path / "frames.npz", **frames)
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import niftymatch_amd as nm\n"
+        "z = np.load(%r)\n"
+        "out = {}\n"
+        "for k in z.files:\n"
+        "    f = z[k]; a = nm.SiftArena(f.shape[1], f.shape[0], 4096)\n"
+        "    a.detect_describe(torch.from_numpy(f).cuda()); torch.cuda.synchronize()\n"
+        "    n = int(a.num_items.item())\n"
+        "    out[k + '_kpts'] = a.kpts[:n].cpu().numpy(); out[k + '_desc'] = a.desc[:n].cpu().numpy()\n"
+        "np.savez(%r, **out)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "frames.npz"), str(tmp_path / "out.npz"))
+    env = dict(os.environ, NM_FRAME_DOG="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(tmp_path / "out.npz")
+    for k, f in frames.items():
+        ref = oracle.sift_detect_describe(f, 4096)
+        _eq(got[k + "_kpts"], ref["kpts"], "keypoints, frame %s, DoG planes materialised" % k)
+        _eq(got[k + "_desc"], ref["desc"], "descriptors, frame %s, DoG planes materialised" % k)

@@ -16,13 +16,14 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 frames = bench.make_frames(nm, torch, dev, list(range(B)))
 arenas = [nm.SiftArena(bench.W, bench.H, bench.CAP, device=dev) for _ in range(B)]
+dog = not (len(sys.argv) > 3 and sys.argv[3] == "nodog")       # third argument "nodog": the chain the frame driver runs
 for _ in range(2):
-    nm.scale_space_batch(arenas, frames)
+    nm.scale_space_batch(arenas, frames, write_dog=dog)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(reps):
-    nm.scale_space_batch(arenas, frames)
+    nm.scale_space_batch(arenas, frames, write_dog=dog)
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
