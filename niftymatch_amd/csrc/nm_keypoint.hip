@@ -287,7 +287,9 @@ __device__ __forceinline__ float dpp_from_upper(float own, float edge)   // lane
 __device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 __device__ __forceinline__ float min3f(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
 
-constexpr int DET_ROWS = 4;      // image rows per workgroup: 6 rows are loaded for 4 tested (measured best of 4, 5, 6, 8)
+constexpr int DET_ROWS = 5;      // image rows per workgroup: 7 rows are loaded for 5 tested. 4 was best while the kernel read
+                                 // 5 DoG planes; reading 6 level planes, 5 rows are 0.6-0.7 % of the headline better (same box,
+                                 // three alternating runs); the 12 sub-lists per row must fit the 64-lane scan: <= 5
 
 template <bool DENSE, bool LEV = false>
 __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
