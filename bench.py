@@ -212,6 +212,9 @@ def roofline_pyramid(B, o0_ms, all_ms, traffic, nodog_ms=None):
                                      "avg_ms": round(nodog_ms, 4), "us_per_frame": round(1e3 * nodog_ms / B, 2),
                                      "algorithmic_bytes": 84.0 * sum_px * B,
                                      "algorithmic_GBps": round(84.0 * sum_px * B / (nodog_ms * 1e-3) / 1e9, 1)}
+        t_fd = traffic.get("pyramid_frame_driver", {}).get("hbm_bytes_per_frame")
+        if t_fd:
+            out["frame_driver_chain"].update({"traffic": t_fd * B, "physical_GBps": round(t_fd * B / (nodog_ms * 1e-3) / 1e9, 1)})
     o0_alg = 136.0 * W * H * B           # octave 0, levels 1..5: 40 (Gaussian) + 60 (DoG) + 36 (gradients) B/px
     if o0_ms == o0_ms:                   # not NaN
         out["octave0"] = {"kernel": "octave-0 part of the same chain (5 launches), from the library profile hook during the probe",
