@@ -237,12 +237,19 @@ __device__ __forceinline__ void desc_run(const DescSetup &d, float *__restrict__
             const float nx = nmfp::div_to_f32(fma64(ct0, (double)dx, st0 * (double)dy), dSBP, rSBP);
             const float ny = nmfp::div_to_f32(fma64(-st0, (double)dx, ct0 * (double)dy), dSBP, rSBP);
             const float nt = nmfp::div_to_f32((double)(8.0f * theta), nmfp::TWO_PI_D, nmfp::INV_TWO_PI_D);
-            const float win = (float)nmfp::exp_spec((double)fma32(nx, nx, ny * ny) / 8.0);
-            const int binx = (int)__builtin_floor((double)nx - 0.5);
-            const int biny = (int)__builtin_floor((double)ny - 0.5);
+            // exp_spec clamps its argument to [-700, 700]: t / 8 > 700 <=> t > 5600 exactly (t = nx^2 + ny^2 >= 0 is a float,
+            // the division by 8 is exact), so the clamp is taken on the float (one v_min_f32) and the binary64 compares /
+            // selects are dropped
+            const float win = (float)nmfp::exp_spec_in_range((double)__builtin_fminf(fma32(nx, nx, ny * ny), 5600.0f) / 8.0);
+            // floor((double)n - 0.5) and (float)((double)n - (bin + 0.5)) in binary32, bit for bit: (double)n - 0.5 is exact, so
+            // the floor is floor(n) - [n - floor(n) < 0.5] (both exact in binary32); bin + 0.5 is exact in binary32, and the
+            // one rounding of n - (bin + 0.5) is the same rounding of the same real number (|n| < 2^22 inside a window)
+            const float fx = __builtin_floorf(nx), fy = __builtin_floorf(ny);
+            const int binx = (int)fx - ((nx - fx) < 0.5f ? 1 : 0);
+            const int biny = (int)fy - ((ny - fy) < 0.5f ? 1 : 0);
             const int bint = (int)__builtin_floorf(nt);
-            const float rbinx = (float)((double)nx - ((double)binx + 0.5));
-            const float rbiny = (float)((double)ny - ((double)biny + 0.5));
+            const float rbinx = nx - ((float)binx + 0.5f);
+            const float rbiny = ny - ((float)biny + 0.5f);
             const float rbint = nt - (float)bint;
             const float wm = win * mod;
             // votes outside the 4x4 grid (or outside the window) become +0 into the row's pad word, so the 8 addresses

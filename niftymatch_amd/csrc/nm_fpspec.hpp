@@ -141,6 +141,26 @@ __device__ __forceinline__ float cosf_spec(float x)
     return neg ? -y : y;
 }
 
+// exp_spec for an argument the caller has already brought into [-700, 700]: the same operation sequence without the two
+// clamps (which would be no-ops).
+__device__ __forceinline__ double exp_spec_in_range(double x)
+{
+    const double px = __builtin_floor(fma64(1.4426950408889634073599, x, 0.5));
+    const int n = (int)px;
+    x = fma64(px, -6.93145751953125e-1, x);
+    x = fma64(px, -1.42860682030941723212e-6, x);
+    const double xx = x * x;
+    double p = fma64(1.26177193074810590878e-4, xx, 3.02994407707441961300e-2);
+    p = fma64(p, xx, 9.99999999999999999910e-1);
+    p = p * x;
+    double q = fma64(3.00198505138664455042e-6, xx, 2.52448340349684104192e-3);
+    q = fma64(q, xx, 2.27265548208155028766e-1);
+    q = fma64(q, xx, 2.00000000000000000009e0);
+    double r = p / (q - p);
+    r = fma64(2.0, r, 1.0);
+    return r * pow2i_d(n);
+}
+
 __device__ __forceinline__ double exp_spec(double x)
 {
     if (x > 700.0) x = 700.0;
