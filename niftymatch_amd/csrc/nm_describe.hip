@@ -94,8 +94,16 @@ __device__ __forceinline__ int orient_finish(const OriSamples &o, float &th0, fl
         const float r2 = fma32(dx, dx, dy * dy);
         if (col_ok && cy <= ymax && (double)r2 < r2lim) {
             const float wgt = nmfp::expf_spec(r2 / denom);
-            const float q = nmfp::div_to_f32((double)(36.0f * o.gv[j].y), nmfp::TWO_PI_D, nmfp::INV_TWO_PI_D);
-            const int bin = ((int)__builtin_floorf(q)) % 36;
+            // Only floor(q) of q = (float)((double)(36 theta) / 2 pi) is used. A binary32 estimate q' = (36 theta) * (1 / 2 pi)
+            // is within 1e-5 of q (q <= 36), so floor(q') = floor(q) whenever q' is at least 1e-4 away from an integer; the
+            // few samples inside that band take the exact expression.
+            const float t36 = 36.0f * o.gv[j].y;
+            const float qe = t36 * 0.15915494309189535f;
+            float fq = __builtin_floorf(qe);
+            const float dq = qe - fq;
+            if (__builtin_expect(!(dq > 1e-4f && dq < 0.9999f), 0))
+                fq = __builtin_floorf(nmfp::div_to_f32((double)t36, nmfp::TWO_PI_D, nmfp::INV_TWO_PI_D));
+            const int bin = ((int)fq) % 36;
             mine[bin * ORI_PITCH] += o.gv[j].x * wgt;   // lane-private word: plain read-add-write, program order
         }
     }
@@ -119,7 +127,7 @@ __device__ __forceinline__ int orient_finish(const OriSamples &o, float &th0, fl
 #pragma unroll
     for (int iter = 0; iter < 6; ++iter) {        // race-free circular 3-tap mean (orientation.cu:181-192)
         const float prev = __shfl(h, lm), next = __shfl(h, lp);
-        const float nh = (float)((double)((prev + h) + next) / 3.0);
+        const float nh = nmfp::div_to_f32((double)((prev + h) + next), 3.0, 1.0 / 3.0);    // == (float)(double(..) / 3.0)
         h = (lane < 36) ? nh : 0.f;
     }
     float m = (lane < 36) ? h : 0.f;
