@@ -205,6 +205,11 @@ def roofline_pyramid(B, o0_ms, all_ms, traffic, nodog_ms=None):
         if t_all:
             out["physical_GBps"] = round(t_all * B / (all_ms * 1e-3) / 1e9, 1)
             out["physical_frac"] = round(t_all * B / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            # the chain writes 2.4 bytes per byte it reads; what plain streaming kernels of such mixes move on this device
+            # (tools/micro/hbm_mix.hip, profiles/r02_l_hbm_mix_microbench.txt): 1 read : 2 written 3.7-4.3 TB/s, 1 : 3
+            # 3.2-5.0 TB/s, copy 4.6-4.7, read-only 5.5-6.5 -- the practical ceiling for `physical_GBps`, not 8 TB/s
+            out["write_heavy_streaming_measured_GBps"] = {"1r:2w": [3680, 4340], "1r:3w": [3180, 5010], "copy": [4620, 4730],
+                                                          "read_only": [5520, 6510]}
     if nodog_ms:
         # what nm_sift_detect_describe_batch itself runs since round 2: the same chain WITHOUT materialised DoG planes (its
         # detection kernel subtracts consecutive levels): 48 B/px of Gaussian levels (+ 4 for level 5) + 36 of gradients
