@@ -75,35 +75,32 @@ def build(force=False, verbose=False):
             if os.path.exists(ar):
                 os.remove(ar)
             subprocess.check_call(["ar", "rcs", ar] + [objs[s] for s in srcs])
-    # native example client of the C ABI (no Python, no torch): examples/pairs_native.cpp -> lib/pairs_native
-    example = os.path.join(ROOT, "..", "examples", "pairs_native.cpp")
-    exe = os.path.join(LIBDIR, "pairs_native")
-    if os.path.exists(example) and (force or not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(example), os.path.getmtime(LIB))):
-        cmd = [HIPCC, "--offload-arch=" + ARCH, "-O2", "-std=c++17", "-I", os.path.join(ROOT, "..", "include"), example,
-               "-L", LIBDIR, "-lnm_hip", "-Wl,-rpath,$ORIGIN", "-o", exe]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("example build failed:\n%s\n%s" % (r.stdout, r.stderr))
-    # native multi-GPU example (RCCL): examples/allpairs_rccl.cpp -> lib/allpairs_rccl
-    example = os.path.join(ROOT, "..", "examples", "allpairs_rccl.cpp")
-    exe = os.path.join(LIBDIR, "allpairs_rccl")
-    if os.path.exists(example) and (force or not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(example), os.path.getmtime(LIB))):
-        cmd = [HIPCC, "--offload-arch=" + ARCH, "-O2", "-std=c++17", "-I", os.path.join(ROOT, "..", "include"), example,
-               "-L", LIBDIR, "-lnm_hip", "-lrccl", "-lpthread", "-Wl,-rpath,$ORIGIN", "-o", exe]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("example build failed:\n%s\n%s" % (r.stdout, r.stderr))
-    # diagnostic microbenchmarks (tools/micro/*.hip -> lib/<name>): what fp32 MFMA sustains on the device
+    # Extras: the native example clients and the diagnostic microbenchmarks. They are not part of the library, so a
+    # failure here (e.g. a host without the RCCL development files) is reported and skipped, never raised.
+    inc = os.path.join(ROOT, "..", "include")
+    extras = []
+    for name, libs in (("pairs_native", []), ("allpairs_rccl", ["-lrccl", "-lpthread"])):
+        src = os.path.join(ROOT, "..", "examples", name + ".cpp")
+        if os.path.exists(src):
+            extras.append((src, os.path.join(LIBDIR, name), [HIPCC, "--offload-arch=" + ARCH, "-O2", "-std=c++17", "-I", inc, src,
+                           "-L", LIBDIR, "-lnm_hip"] + libs + ["-Wl,-rpath,$ORIGIN", "-o", os.path.join(LIBDIR, name)], True))
     micro = os.path.join(ROOT, "..", "tools", "micro")
     if os.path.isdir(micro):
         for f in sorted(os.listdir(micro)):
-            if not f.endswith(".hip"):
-                continue
-            src, exe = os.path.join(micro, f), os.path.join(LIBDIR, f[:-4])
-            if force or not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
-                r = subprocess.run([HIPCC, "--offload-arch=" + ARCH, "-O3", src, "-o", exe], capture_output=True, text=True)
-                if r.returncode != 0:
-                    raise RuntimeError("microbenchmark build failed:\n%s\n%s" % (r.stdout, r.stderr))
+            if f.endswith(".hip"):
+                src, exe = os.path.join(micro, f), os.path.join(LIBDIR, f[:-4])
+                extras.append((src, exe, [HIPCC, "--offload-arch=" + ARCH, "-O3", src, "-o", exe], False))
+
+    def _extra(job):
+        src, exe, cmd, needs_lib = job
+        newest_in = max(os.path.getmtime(src), os.path.getmtime(LIB) if needs_lib else 0)
+        if not force and os.path.exists(exe) and os.path.getmtime(exe) >= newest_in:
+            return
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write("warning: optional build of %s failed (library unaffected):\n%s\n" % (os.path.basename(exe), r.stderr[-2000:]))
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(_extra, extras))
     if verbose:
         print("built", LIB)
     return LIB

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """How long does the HOST need to enqueue one bench step (detect calls + matches) compared with the GPU time of the
 step? Tells whether the throughput bench is launch-bound on the CPU."""
 import os

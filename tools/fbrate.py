@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Exact-fallback rate of the fused matcher (rows the finalize pass cannot prove from the MFMA candidates) and call time
 on Uniform[0,1) descriptors at several sizes, and on the bench's real 1080p SIFT descriptors."""
 import os

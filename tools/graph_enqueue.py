@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Host cost and GPU throughput of replaying one captured HIP graph per detect call (vs eager launches, see
 cpu_enqueue.py)."""
 import os

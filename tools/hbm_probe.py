@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """What the box actually delivers (peaks to be confirmed on the GPU): CU count and clocks from rocminfo,
 attainable HBM bandwidth from device-to-device copies and a read-only reduction of a 4 GiB buffer."""
 import subprocess

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """The drop-in C++ API client loop (nm_client_pair_loop) on the bench's 1080p pair: microseconds per pair."""
 import ctypes as C
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Time the fused matcher in isolation (events around the MFMA kernel), 12223 x 12080 random descriptors."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """The fused matcher launched back to back (no host sync in between), as in bench.py's match phase: per-launch time of
 match_top2_kernel from the launcher's events, first launches vs steady state (clock / power behaviour under sustained
 fp32 MFMA load)."""

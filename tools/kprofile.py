@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Single-stream, one-kernel-at-a-time workload for `rocprofv3 --kernel-trace --stats`: N 1080p frames of
 detect+describe and N fused matches, each followed by a device sync, so per-kernel durations are isolated."""
 import argparse

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Octave-0 pyramid sequence of a 1080p frame, alone on the device, timed with the launcher's own HIP events
 (NM_PROF_PYRAMID_O0): min / median microseconds over N frames."""
 import os

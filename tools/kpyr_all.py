@@ -1,7 +1,10 @@
-#!/usr/bin/env python3
 """The whole scale-space chain (nm_sift_scale_space_batch: base blur + 6 octaves) of B 1080p frames, alone on the
 device: event-timed average, and -- under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` -- the dispatches that
-tools/pmc_traffic_total.py sums into HBM bytes per frame.   usage: kpyr_all.py [B=16] [reps=10]"""
+tools/pmc_traffic_total.py sums into HBM bytes per frame.   usage (the interpreter itself after `--`, never this file or env:
+the profiler initialises the GPU before the program starts, so any exec hop is forbidden on this pool):
+    rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_f --output-format csv -- python3 tools/kpyr_all.py 16 4 [nodog]
+    rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_w --output-format csv -- python3 tools/kpyr_all.py 16 4 [nodog]
+and, unprofiled:  python3 tools/kpyr_all.py [B=16] [reps=10]"""
 import os
 import sys
 

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Timings of the stages either side of the hot path at 1080p / 12k points: element-wise front end,
 warps, RANSAC. Each op is timed over back-to-back launches on one stream."""
 import os

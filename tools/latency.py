@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Single-stream latency of one frame (detect+describe) and one pair (2 frames + match): eager launches vs HIP graph
 replay. BASELINE configs[1] (640x480) and configs[2] (1080p). Prints one JSON line per configuration."""
 import json

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Per-kernel averages of arbitrary rocprofv3 --pmc counters: tools/pmc_counters.py <dir> [kernel-substring]."""
 import collections
 import csv

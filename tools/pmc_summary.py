@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KiB per dispatch).
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 64 B per 128-B request on wide streaming
 reads -> doubled here; WRITE_SIZE is exact for 16-B-per-lane stores (4-B stores are uncalibrated)."""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Summarise a rocprofv3 --kernel-trace CSV: per (kernel, grid) count / avg / min microseconds."""
 import collections
 import csv

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Pretty-print the JSON line of bench.py: tools/show_bench.py <file>."""
 import json
 import sys
