@@ -43,7 +43,7 @@ def make_frames(nm, torch, dev, seeds):
     return out
 
 
-def cpu_baseline():
+def cpu_baseline(seed0=0, seed1=1):
     """The CPU oracle (a port of the reference's semantics; the reference has no CPU path, src/utils/macros.h:1-8 is the
     whole directory) on one 1080p pair, BASELINE.md section 2: median of 3 repetitions at all host threads (the whole
     pair, nothing scaled) and at 1 thread (both frames whole + the first 1024 query rows of the match, scaled to all
@@ -53,7 +53,7 @@ def cpu_baseline():
     import statistics
     import oracle_lib as O
     import helpers as Hh
-    f0, f1 = Hh.blurred_frame(0, W, H), Hh.blurred_frame(1, W, H)
+    f0, f1 = Hh.blurred_frame(seed0, W, H), Hh.blurred_frame(seed1, W, H)
 
     def timed(fn):
         t0 = time.time()
@@ -75,13 +75,24 @@ def cpu_baseline():
     td, tm, r0, r1, m = sorted(reps_all, key=lambda r: r[0] + r[1])[1]
     out = {"value": round(1.0 / med(reps_all), 4), "unit": "frame-pairs/s", "cores": int(threads), "kind": "port",
            "value_1_thread": round(1.0 / med(reps_1), 5), "reps": 3,
-           "sample": "median of 3: one whole 1080p pair, nothing scaled, %d threads: both frames detect+describe (%.2fs) + "
-                     "%d x %d match (%.2fs); 1 thread: both frames whole + 1024 of the query rows, scaled to all rows"
-                     % (threads, td, r0["n"], r1["n"], tm)}
+           "sample": "median of 3: one whole 1080p pair (frame seeds %d, %d: pair 0 of the last timed step), nothing scaled, "
+                     "%d threads: both frames detect+describe (%.2fs) + %d x %d match (%.2fs); 1 thread: both frames whole "
+                     "+ 1024 of the query rows, scaled to all rows" % (seed0, seed1, threads, td, r0["n"], r1["n"], tm)}
     return out, (r0, r1, m[0])
 
 
-def allpairs_100k(nm, torch, dist, dev, rank, world, steps=3):
+def per_rank(torch, dist, cdev, world, value):
+    """Every rank's `value` (a float), rank-ordered, on every rank: the first real N > 1 run checks itself (a straggler or
+    a rank that did not take part shows in the list)."""
+    if world <= 1:
+        return [float(value)]
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=cdev)
+    out = torch.empty(world, dtype=torch.float64, device=cdev)
+    dist.all_gather_into_tensor(out, mine)
+    return [float(v) for v in out.tolist()]
+
+
+def allpairs_100k(nm, torch, dist, dev, cdev, rank, world, steps=3):
     """BASELINE config 5 as a secondary, separately timed measurement: all-pairs match of 100 000 x 100 000 random
     descriptors, candidates row-sharded over the ranks, ONE all-gather of 12 B per row per rank, merge on every rank.
     Not part of `value`. Verified on rank 0 against an fp64 brute force for a sample of the queries."""
@@ -113,10 +124,8 @@ def allpairs_100k(nm, torch, dist, dev, rank, world, steps=3):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    ranks_ms = per_rank(torch, dist, cdev, world, 1e3 * dt / steps)
+    dt = max(ranks_ms) * steps / 1e3
     ok = None
     if rank == 0:
         q = torch.randint(0, n, (128,), device=dev, generator=g)
@@ -129,7 +138,7 @@ def allpairs_100k(nm, torch, dist, dev, rank, world, steps=3):
             "descriptor_comparisons_per_s": round(n * float(n) * steps / dt, 1),
             "tflops_2NM128_aggregate": round(256.0 * n * n * steps / dt / 1e12, 2),
             "collective": "1 x all_gather_into_tensor of (3, N) int32 per match call" if world > 1 else "none (1 rank)",
-            "verified_sample_vs_fp64": ok}
+            "per_rank_ms_per_step": [round(v, 3) for v in ranks_ms], "verified_sample_vs_fp64": ok}
 
 
 def detect_256(nm, torch, dist, dev, cdev, rank, world, arenas, streams, B):
@@ -166,6 +175,7 @@ def detect_256(nm, torch, dist, dev, cdev, rank, world, arenas, streams, B):
     run(True)
     barrier()
     dt = time.perf_counter() - t0
+    ranks_ms = per_rank(torch, dist, cdev, world, 1e3 * dt)
     for k in kps:
         kp += k
     tot = torch.tensor([dt, float(kp.item()), float(len(frames))], dtype=torch.float64, device=cdev)
@@ -178,7 +188,8 @@ def detect_256(nm, torch, dist, dev, cdev, rank, world, arenas, streams, B):
     return {"workload": "configs[3]: %d x 1080p frames, SIFT detect+describe only, %d per rank in %d-frame calls, %d rank(s)"
                         % (n_all, len(frames), B, world),
             "frames_per_s": round(n_all / dt, 1), "keypoints_per_s": round(kp_all / dt, 1),
-            "ms_total": round(1e3 * dt, 3), "keypoints_total": int(kp_all), "collective": "none"}
+            "ms_total": round(1e3 * dt, 3), "keypoints_total": int(kp_all), "collective": "none",
+            "per_rank_ms": [round(v, 3) for v in ranks_ms]}
 
 
 def roofline_pyramid(B, o0_ms, all_ms, traffic, nodog_ms=None):
@@ -205,11 +216,6 @@ def roofline_pyramid(B, o0_ms, all_ms, traffic, nodog_ms=None):
         if t_all:
             out["physical_GBps"] = round(t_all * B / (all_ms * 1e-3) / 1e9, 1)
             out["physical_frac"] = round(t_all * B / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-            # the chain writes 2.4 bytes per byte it reads; what plain streaming kernels of such mixes move on this device
-            # (tools/micro/hbm_mix.hip, profiles/r02_l_hbm_mix_microbench.txt): 1 read : 2 written 3.7-4.3 TB/s, 1 : 3
-            # 3.2-5.0 TB/s, copy 4.6-4.7, read-only 5.5-6.5 -- the practical ceiling for `physical_GBps`, not 8 TB/s
-            out["write_heavy_streaming_measured_GBps"] = {"1r:2w": [3680, 4340], "1r:3w": [3180, 5010], "copy": [4620, 4730],
-                                                          "read_only": [5520, 6510]}
     if nodog_ms:
         # what nm_sift_detect_describe_batch itself runs since round 2: the same chain WITHOUT materialised DoG planes (its
         # detection kernel subtracts consecutive levels): 48 B/px of Gaussian levels (+ 4 for level 5) + 36 of gradients
@@ -250,11 +256,13 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=32, help="frame pairs per GPU per step")
+    ap.add_argument("--frame-sets", type=int, default=32,
+                    help="distinct sets of 2 x pairs synthetic frames held in HBM (8.3 MB per frame); step k runs on set "
+                         "k mod frame-sets, so with warmup + steps <= frame-sets no frame is ever seen twice")
     ap.add_argument("--streams", type=int, default=4)
     ap.add_argument("--batch", type=int, default=16, help="frames per nm_sift_detect_describe_batch call (16 = 8 pairs)")
     ap.add_argument("--host-threads", type=int, default=1, help="host threads that enqueue the detect calls")
-    ap.add_argument("--match-batch", type=int, default=16,
-                    help="pairs per nm_sift_match_batch_f32 call (1 = one nm_sift_match_f32 call per pair)")
+    ap.add_argument("--match-batch", type=int, default=16, help="pairs per nm_sift_match_batch_dev_f32 call")
     ap.add_argument("--match-streams", type=int, default=1,
                     help="streams the fused matches alternate over. 2 hides the small norms/finalize/fallback launches of "
                          "one match under the next match's MFMA kernel (+7 %% frame-pairs/s), but the MFMA kernels of the "
@@ -271,7 +279,75 @@ def parse_args(argv=None):
     ap.add_argument("--no-allpairs", action="store_true", help="skip the secondary config-5 measurement")
     ap.add_argument("--no-detect256", action="store_true", help="skip the secondary configs[3] measurement")
     ap.add_argument("--no-dropin", action="store_true", help="skip the secondary measurement of the drop-in C++ API loop")
+    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency probe")
+    ap.add_argument("--no-f32-loop", action="store_true", help="skip the second timed loop with the fp32 MFMA screen")
     return ap.parse_args(argv)
+
+
+def latency_probe(nm, torch, dev, frames4):
+    """Batch-1 figures (the reference's use case is one frame at a time, siftfunctions.cu:42-181): wall
+    time per call of back-to-back calls on ONE stream -- a call is one dependent launch chain, so this is its latency
+    (or the host's enqueue time where that is longer) -- for one 1080p frame and for one pair (one 2-frame detect call
+    + the device-sized match), issued eagerly and replayed as a captured HIP graph. frames4: two pairs; the graphs are
+    replayed on the second pair as well (different keypoint counts) and must give what the eager calls give."""
+    a = [nm.SiftArena(W, H, CAP, device=dev) for _ in range(2)]
+    buf = [frames4[0].clone(), frames4[1].clone()]
+    ws = nm.MatchBatchDevWorkspace(1, CAP, CAP, dev)
+    res = torch.full((CAP,), -1, dtype=torch.int32, device=dev)
+    s = torch.cuda.Stream(device=dev)
+
+    def frame():
+        a[0].detect_describe(buf[0])
+
+    def pair():
+        nm.detect_describe_batch(a, buf)
+        nm.sift_match_batch_dev([a[0].desc], [a[0].num_items], [a[1].desc], [a[1].num_items], [res], 0.8, workspace=ws)
+
+    def timeit(fn, n):
+        with torch.cuda.stream(s):
+            for _ in range(5):
+                fn()
+            s.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            s.synchronize()
+        return (time.perf_counter() - t0) / n * 1e6
+
+    out = {"what": "batch 1, one stream, back-to-back calls, us per call (1080p); pair = one 2-frame detect call + "
+                   "device-sized match"}
+    try:
+        out["frame_us_eager"] = round(timeit(frame, 50), 1)
+        out["pair_us_eager"] = round(timeit(pair, 30), 1)
+        gf, gp = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gf, stream=s):
+            frame()
+        with torch.cuda.graph(gp, stream=s):
+            pair()
+        out["frame_us_graph"] = round(timeit(gf.replay, 50), 1)
+        out["pair_us_graph"] = round(timeit(gp.replay, 30), 1)
+        # the pair graph on OTHER frames (their keypoint counts differ): must equal the eager calls on those frames
+        buf[0].copy_(frames4[2]); buf[1].copy_(frames4[3])
+        res.fill_(-1)
+        with torch.cuda.stream(s):
+            pair()
+        s.synchronize()
+        n_eager = (int(a[0].num_items.item()), int(a[1].num_items.item()))
+        want = res.clone()
+        res.fill_(-1)
+        for x in a:
+            x.num_items.zero_()
+        torch.cuda.synchronize()
+        gp.replay()
+        torch.cuda.synchronize()
+        n_graph = (int(a[0].num_items.item()), int(a[1].num_items.item()))
+        out["keypoints_second_pair"] = list(n_graph)
+        out["graph_replay_on_other_frames_equals_eager"] = bool(n_graph == n_eager and torch.equal(res, want))
+    except Exception as exc:
+        out["error"] = repr(exc)
+    for x in a:
+        x.close()
+    return out
 
 
 def main():
@@ -304,6 +380,12 @@ def main():
             dist.init_process_group("gloo")
     cdev = dev if args.backend == "nccl" else torch.device("cpu")   # where the few collective payload tensors live
     nm.lib()
+    # how many ranks the communicator really reaches (RCCL when the backend is nccl): a sum of ones over it
+    ranks_seen = 1
+    if world > 1:
+        one = torch.ones(1, dtype=torch.int32, device=cdev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        ranks_seen = int(one.item())
 
     P = args.pairs
     B = max(1, min(args.batch, nm.SIFT_MAX_BATCH))
@@ -311,119 +393,99 @@ def main():
         B -= 1
     NB = 2 * P // B                                   # detect calls per step, B frames each
     S = max(1, min(args.streams, NB))
-    # distinct seeds per rank and pair: (2i, 2i+1) is a pair
-    seeds = [2 * (rank * P + i) + k for i in range(P) for k in (0, 1)]
-    frames = make_frames(nm, torch, dev, seeds)
+    # Fresh frames every step: n_sets distinct sets of 2P frames; step k (warm-up included) runs on set k mod n_sets.
+    # Seeds are distinct per set, rank and pair: (2i, 2i+1) is a pair; set 0 of rank 0 starts at seed 0.
+    total_steps = args.warmup + args.steps
+    n_sets = max(1, min(total_steps, args.frame_sets))
+
+    def seeds_of(s):
+        return [2 * ((s * world + rank) * P + i) + k for i in range(P) for k in (0, 1)]
+    frame_sets = [make_frames(nm, torch, dev, seeds_of(s)) for s in range(n_sets)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     mstream = torch.cuda.Stream(device=dev)
-    # one arena per frame of the batch (0.4 GB each): nothing on the hot path is reused before it has been consumed
-    arenas = [nm.SiftArena(W, H, CAP, device=dev) for _ in range(2 * P)]
+    # one arena per frame of the batch (0.4 GB each): nothing on the hot path is reused before it has been consumed.
+    # Their descriptor counts live in ONE device table (the matcher reads them there; nothing comes back to the host).
+    counts_all = torch.zeros(2 * P, dtype=torch.int32, device=dev)
+    arenas = [nm.SiftArena(W, H, CAP, device=dev, num_items=counts_all[k:k + 1]) for k in range(2 * P)]
     MB = max(1, min(args.match_batch, nm.MATCH_MAX_BATCH, P))
-    bws = nm.MatchBatchWorkspace(MB, CAP, CAP, dev) if MB > 1 else None
     MS = max(1, args.match_streams)
     mstreams = [mstream] + [torch.cuda.Stream(device=dev) for _ in range(MS - 1)]
-    wss = [nm.MatchWorkspace(CAP, CAP, dev) for _ in range(MS)]
-    ws = wss[0]
+    bwss = [nm.MatchBatchDevWorkspace(MB, CAP, CAP, dev) for _ in range(MS)]
     results = [torch.full((CAP,), -1, dtype=torch.int32, device=dev) for _ in range(P)]
-
-    # keypoint counts are data-dependent but deterministic: one untimed pass gives the host-side sizes of each pair
-    counts = []
-    for c in range(NB):
-        nm.detect_describe_batch(arenas[c * B:(c + 1) * B], frames[c * B:(c + 1) * B])
-    torch.cuda.synchronize()
-    for i in range(P):
-        counts.append((int(arenas[2 * i].num_items.item()), int(arenas[2 * i + 1].num_items.item())))
+    EV_STEPS = min(args.steps, 64)                    # steps whose match launches are event-timed
+    hist = torch.zeros((max(1, args.steps), 2 * P), dtype=torch.int32, device=dev)    # the counts of every timed step
 
     def mk_events(n):
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
         for a, b in evs:
             a.record(); b.record()
         return evs
-    ev_match = mk_events(P)
     ev_pyr = mk_events(1)
     torch.cuda.synchronize()
-    match_ms, pyr_ms = [], []
+    pyr_ms = []
     done = [torch.cuda.Event() for _ in range(S)]
 
     from concurrent.futures import ThreadPoolExecutor
     T = max(1, min(args.host_threads, NB))
     pool = ThreadPoolExecutor(T) if T > 1 else None
-
-    def enqueue_detect(t):
-        # calls t, t+T, ... of the step, each on its stream (torch's current stream is per host thread; the C ABI
-        # itself takes the stream as an argument). With 16-frame calls one host thread is enough (~16 us of host time
-        # per frame); several threads matter for small batches, where interleaved issue mixes the calls' kernels.
-        for c in range(t, NB, T):
-            with torch.cuda.stream(streams[c % S]):
-                nm.detect_describe_batch(arenas[c * B:(c + 1) * B], frames[c * B:(c + 1) * B])
-
     call_done = [torch.cuda.Event() for _ in range(NB)]
 
-    def step_overlapped(timed):
-        """--overlap: the matches of the pairs of call c are queued (one match stream) as soon as call c has finished,
-        while the next calls' detection proceeds on the other streams. Same work, no probes of isolated sequences."""
-        for c in range(NB):
-            with torch.cuda.stream(streams[c % S]):
-                nm.detect_describe_batch(arenas[c * B:(c + 1) * B], frames[c * B:(c + 1) * B])
-                call_done[c].record()
-            mstream.wait_event(call_done[c])
-            with torch.cuda.stream(mstream):
-                for i in range(c * B // 2, (c + 1) * B // 2):
-                    nA, nB = counts[i]
-                    if timed:
-                        nm.profile_events(nm.PROF_MATCH_TOP2, ev_match[i][0], ev_match[i][1])
-                    nm.sift_match(arenas[2 * i].desc, arenas[2 * i + 1].desc, 0.8, prior=results[i], workspace=ws, nA=nA, nB=nB)
-                if timed:
-                    nm.profile_events(nm.PROF_MATCH_TOP2, None, None)
-        for s in range(S):
-            streams[s].wait_stream(mstream)
-        if timed:
-            mstream.synchronize()
-            match_ms.extend(a.elapsed_time(b) for a, b in ev_match)
+    def match_call(idx, evs, stream, ws, out):
+        """One nm_sift_match_batch_dev_f32 call for the pairs idx: the set sizes are the frame driver's d_num_items, read
+        on the device (no host read-back anywhere in a step)."""
+        with torch.cuda.stream(stream):
+            keep = nm.profile_event_pairs(nm.PROF_MATCH_TOP2, [evs[i] for i in idx]) if evs else None
+            nm.sift_match_batch_dev([arenas[2 * i].desc for i in idx], [arenas[2 * i].num_items for i in idx],
+                                    [arenas[2 * i + 1].desc for i in idx], [arenas[2 * i + 1].num_items for i in idx],
+                                    [out[i] for i in idx], 0.8, workspace=ws, capA=CAP, capB=CAP)
+            if evs:
+                nm.profile_event_pairs(nm.PROF_MATCH_TOP2, [])
+            del keep
 
-    def step(timed):
-        """One batch. Detect+describe of the 2P frames = NB calls of B frames each, spread over S streams (all in flight
-        together: the latency-bound small-octave and book-keeping launches of one call hide under the others'); the P
-        fused matches then run back to back on one stream (a match launch fills the chip by itself); every match launch
-        is event-timed. The scale-space chain is timed alone after the timed region (whole-pyramid probe below)."""
-        if pool is None:
-            enqueue_detect(0)
+    def step(k, evs, hist_row):
+        """One batch on frame set k mod n_sets. Detect+describe of the 2P frames = NB calls of B frames each, spread over
+        S streams (all in flight together: the latency-bound small-octave and book-keeping launches of one call hide
+        under the others'); the P fused matches then run back to back as MB-pair device-sized calls (a match launch
+        fills the chip by itself); every MFMA launch of an event-timed step is bracketed by HIP events on its stream."""
+        fr = frame_sets[k % n_sets]
+
+        def enqueue_detect(t):
+            # calls t, t+T, ... of the step, each on its stream (torch's current stream is per host thread; the C ABI
+            # itself takes the stream as an argument). With 16-frame calls one host thread is enough.
+            for c in range(t, NB, T):
+                with torch.cuda.stream(streams[c % S]):
+                    nm.detect_describe_batch(arenas[c * B:(c + 1) * B], fr[c * B:(c + 1) * B])
+                    call_done[c].record()
+        if args.overlap and B % 2 == 0:
+            # the matches of call c are queued as soon as call c has finished, while the next calls' detection proceeds
+            for c in range(NB):
+                enqueue_detect_one = streams[c % S]
+                with torch.cuda.stream(enqueue_detect_one):
+                    nm.detect_describe_batch(arenas[c * B:(c + 1) * B], fr[c * B:(c + 1) * B])
+                    call_done[c].record()
+                mstream.wait_event(call_done[c])
+                pairs_c = list(range(c * B // 2, (c + 1) * B // 2))
+                for i0 in range(0, len(pairs_c), MB):
+                    match_call(pairs_c[i0:i0 + MB], evs, mstream, bwss[0], results)
         else:
-            list(pool.map(enqueue_detect, range(T)))
-        for s in range(S):
-            done[s].record(streams[s])
-            mstream.wait_event(done[s])
-        if MB > 1:
-            # batched matches: norms / finalize / fallback once per call for all its pairs, the MFMA kernel once per pair
+            if pool is None:
+                enqueue_detect(0)
+            else:
+                list(pool.map(enqueue_detect, range(T)))
+            for s in range(S):
+                done[s].record(streams[s])
+                mstream.wait_event(done[s])
+            for q in range(1, MS):
+                mstreams[q].wait_stream(mstream)        # the matches start when the last detect call has finished
+            for ci, i0 in enumerate(range(0, P, MB)):
+                match_call(list(range(i0, min(i0 + MB, P))), evs, mstreams[ci % MS], bwss[ci % MS], results)
+            for q in range(1, MS):
+                mstream.wait_stream(mstreams[q])
+        if hist_row is not None:
             with torch.cuda.stream(mstream):
-                for i0 in range(0, P, MB):
-                    idx = list(range(i0, min(i0 + MB, P)))
-                    keep = nm.profile_event_pairs(nm.PROF_MATCH_TOP2, [ev_match[i] for i in idx]) if timed else None
-                    nm.sift_match_batch([arenas[2 * i].desc for i in idx], [arenas[2 * i + 1].desc for i in idx],
-                                        [counts[i][0] for i in idx], [counts[i][1] for i in idx],
-                                        [results[i] for i in idx], 0.8, workspace=bws)
-                    if timed:
-                        nm.profile_event_pairs(nm.PROF_MATCH_TOP2, [])
-                    del keep
-        else:
-            for k in range(1, MS):
-                mstreams[k].wait_stream(mstream)        # the matches start when the last detect call has finished
-            for i in range(P):
-                nA, nB = counts[i]
-                with torch.cuda.stream(mstreams[i % MS]):
-                    if timed:
-                        nm.profile_events(nm.PROF_MATCH_TOP2, ev_match[i][0], ev_match[i][1])
-                    nm.sift_match(arenas[2 * i].desc, arenas[2 * i + 1].desc, 0.8, prior=results[i], workspace=wss[i % MS],
-                                  nA=nA, nB=nB)
-            if timed:
-                nm.profile_events(nm.PROF_MATCH_TOP2, None, None)
-            for k in range(1, MS):
-                mstream.wait_stream(mstreams[k])
+                hist_row.copy_(counts_all)
         for s in range(S):                      # the next step's detects overwrite the arenas: wait for the matches
             streams[s].wait_stream(mstream)
-        if timed:
-            mstream.synchronize()
-            match_ms.extend(a.elapsed_time(b) for a, b in ev_match)
 
     def barrier():
         torch.cuda.synchronize()
@@ -431,30 +493,79 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    overlap = args.overlap and B % 2 == 0
-    run_step = step_overlapped if overlap else step
-    for _ in range(args.warmup):
-        run_step(False)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step(True)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed_loop(k0, evs_all, hist_rows):
+        """EXACTLY args.steps steps bracketed by barrier + synchronize; returns (max-over-ranks seconds, per-rank ms)."""
+        barrier()
+        t0 = time.perf_counter()
+        for j in range(args.steps):
+            step(k0 + j, evs_all[j * P:(j + 1) * P] if (evs_all and j < EV_STEPS) else None,
+                 hist_rows[j] if hist_rows is not None else None)
+        barrier()
+        dt = time.perf_counter() - t0
+        ranks_ms = per_rank(torch, dist, cdev, world, 1e3 * dt)
+        return max(ranks_ms) / 1e3, ranks_ms
 
-    kp_rank = sum(a + b for a, b in counts)
-    cmp_rank = sum(a * b for a, b in counts)
-    tot = torch.tensor([float(kp_rank), float(cmp_rank)], dtype=torch.float64, device=cdev)
+    def launch_times(evs_all, counts_host):
+        """(ms, flops) of every event-timed MFMA launch: 2*N*M*128 flop with the sizes the step really had."""
+        ms = [a.elapsed_time(b) for a, b in evs_all[:EV_STEPS * P]]
+        fl = [256.0 * float(counts_host[j][2 * i]) * float(counts_host[j][2 * i + 1]) for j in range(EV_STEPS) for i in range(P)]
+        return ms, fl
+
+    screen = nm.get_match_screen()
+    evs = mk_events(EV_STEPS * P)
+    for k in range(args.warmup):
+        step(k, None, None)
+    dt, ranks_ms = timed_loop(args.warmup, evs, hist)
+    torch.cuda.synchronize()
+    counts_host = hist.cpu().tolist()                 # [step][frame]: read AFTER the timed region
+    match_ms, match_fl = launch_times(evs, counts_host)
+    last_set = (total_steps - 1) % n_sets
+    # what the timed loop left in the arenas / results of pair 0, for the oracle check below
+    snap = None
+    if rank == 0:
+        nA, nB = counts_host[args.steps - 1][0], counts_host[args.steps - 1][1]
+        snap = {"n": (nA, nB), "seeds": tuple(seeds_of(last_set)[:2]),
+                "kpts": [arenas[k].kpts[:n].cpu().numpy() for k, n in ((0, nA), (1, nB))],
+                "desc": [arenas[k].desc[:n].cpu().numpy() for k, n in ((0, nA), (1, nB))],
+                "match": results[0][:nA].cpu().numpy()}
+
+    kp_rank = float(sum(sum(row) for row in counts_host[:args.steps]))
+    cmp_rank = float(sum(row[2 * i] * row[2 * i + 1] for row in counts_host[:args.steps] for i in range(P)))
+    tot = torch.tensor([kp_rank, cmp_rank], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     kp_all, cmp_all = float(tot[0].item()), float(tot[1].item())
 
-    # whole-pyramid probe (after the timed region, chip otherwise idle): the scale-space launches of one B-frame detect call,
-    # every octave, timed with events on the stream they run on
+    # the SAME timed loop with the fp32 MFMA screen (NM_MATCH_SCREEN=f32: north_star's "matcher on MFMA fp32"): its
+    # whole-job value and its per-launch roofline come from a timed region of their own, not from a probe
+    f32 = None
+    if screen != "f32" and not args.no_f32_loop:
+        try:
+            nm.set_match_screen("f32")
+            evs32 = mk_events(EV_STEPS * P)
+            hist32 = torch.zeros_like(hist)
+            step(total_steps, None, None)                                   # one warm-up step with this screen
+            dt32, _ = timed_loop(total_steps + 1, evs32, hist32)
+            torch.cuda.synchronize()
+            c32 = hist32.cpu().tolist()
+            ms32, fl32 = launch_times(evs32, c32)
+            # the last step again through the default screen, matches only: both screens must emit the same indexes
+            nm.set_match_screen(screen)
+            res2 = [torch.full((CAP,), -1, dtype=torch.int32, device=dev) for _ in range(P)]
+            for i0 in range(0, P, MB):
+                match_call(list(range(i0, min(i0 + MB, P))), None, mstream, bwss[0], res2)
+            torch.cuda.synchronize()
+            row = c32[args.steps - 1]
+            same = all(torch.equal(res2[i][:row[2 * i]], results[i][:row[2 * i]]) for i in range(P))
+            f32 = {"dt": dt32, "ms": ms32, "fl": fl32, "same": bool(same)}
+        except Exception as exc:
+            f32 = {"error": repr(exc)}
+        finally:
+            nm.set_match_screen(screen)
+
+    # whole-pyramid probe (after the timed regions, chip otherwise idle): the scale-space launches of one B-frame detect
+    # call, every octave, timed with events on the stream they run on
+    frames = frame_sets[0]
     pyr_all_ms = pyr_nodog_ms = None
     try:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -481,47 +592,15 @@ def main():
         mstream.synchronize()
         pyr_all_ms = e0.elapsed_time(e1) / reps
         pyr_nodog_ms = e2.elapsed_time(e3) / reps
-    except Exception as exc:
+    except Exception:
         pyr_all_ms = None
 
-    # the same 16-pair batched match calls with the fp32 screen (the round-1/2 kernel), after the timed region, on the
-    # otherwise idle chip: its per-launch time is the fp32-MFMA roofline reading that the default screen is compared with
-    screen = nm.get_match_screen()
-    f32_ms = []
-    if rank == 0 and screen != "f32" and MB > 1:
-        try:
-            nm.set_match_screen("f32")
-            res2 = [torch.full((CAP,), -1, dtype=torch.int32, device=dev) for _ in range(MB)]
-            idx = list(range(min(MB, P)))
-            with torch.cuda.stream(mstream):
-                for rep in range(5):                 # the first two calls are warm-up (clock, caches)
-                    evs = mk_events(len(idx))
-                    keep = nm.profile_event_pairs(nm.PROF_MATCH_TOP2, evs)
-                    nm.sift_match_batch([arenas[2 * i].desc for i in idx], [arenas[2 * i + 1].desc for i in idx],
-                                        [counts[i][0] for i in idx], [counts[i][1] for i in idx],
-                                        [res2[k] for k in range(len(idx))], 0.8, workspace=bws)
-                    nm.profile_event_pairs(nm.PROF_MATCH_TOP2, [])
-                    mstream.synchronize()
-                    del keep
-                    if rep >= 2:
-                        f32_ms.extend(a.elapsed_time(b) for a, b in evs)
-            same = all(torch.equal(res2[k][:counts[i][0]], results[i][:counts[i][0]]) for k, i in enumerate(idx))
-            f32_ms = (f32_ms, bool(same), [counts[i] for i in idx])
-        except Exception as exc:
-            f32_ms = repr(exc)
-        finally:
-            nm.set_match_screen(screen)
-
-    # what the timed loop left in the arenas / results of pair 0 (rank 0: seeds 0 and 1), for the oracle check below
-    snap = None
-    if rank == 0:
-        nA, nB = counts[0]
-        snap = {"n": (nA, nB), "kpts": [arenas[k].kpts[:n].cpu().numpy() for k, n in ((0, nA), (1, nB))],
-                "desc": [arenas[k].desc[:n].cpu().numpy() for k, n in ((0, nA), (1, nB))],
-                "match": results[0][:nA].cpu().numpy()}
+    latency = None
+    if rank == 0 and not args.no_latency:
+        latency = latency_probe(nm, torch, dev, (frame_sets[0] + frame_sets[-1])[:2] + (frame_sets[0] + frame_sets[-1])[-2:])
 
     # the reference's own C++ API driven the way a NiftyMatch application drives it (SiftParams / PyramidData / SiftData +
-    # the per-octave compute_* calls + compute_sift_matches), on pair 0, one host thread, one stream; not part of `value`
+    # the per-octave compute_* calls + compute_sift_matches), on one pair, one host thread, one stream; not part of `value`
     dropin = None
     if rank == 0 and not args.no_dropin:
         try:
@@ -547,75 +626,84 @@ def main():
     if not args.no_allpairs:
         for a in arenas:                     # give the memory back before the 100k x 100k workspaces
             a.close()
+        frame_sets = frames = None
         try:
-            extra = allpairs_100k(nm, torch, dist, dev, rank, world)
+            extra = allpairs_100k(nm, torch, dist, dev, cdev, rank, world)
         except Exception as exc:             # never lose the headline line to the secondary measurement
             extra = {"error": repr(exc)}
 
     if rank == 0:
         pairs_total = P * world * args.steps
-        nA, nB = counts[0]
-        m_ms = sum(match_ms) / len(match_ms)            # every match launch of the timed region
+        nA, nB = snap["n"]
+        m_ms = sum(match_ms) / len(match_ms)            # every event-timed MFMA launch of the timed region
         p_ms = sum(pyr_ms) / len(pyr_ms) if pyr_ms else float("nan")
-        flops = 256.0 * sum(a * b for a, b in counts) / len(counts)      # 2*N*M*128 per launch
-        # octave 0, levels 1..5 of the B frames of one call: 40 (Gaussian) + 60 (DoG) + 36 (gradients) B/px
-        pyr_bytes = 136.0 * W * H * B
         traffic = {}
         try:
             traffic = json.load(open(os.path.join(_ROOT, "profiles", "pmc_traffic.json")))
         except Exception:
             pass
         t_match = traffic.get("match_top2_kernel", {}).get("hbm_bytes_per_launch")
-        ach = flops / (m_ms * 1e-3) / 1e12
-        if screen == "f32":
-            roof = {"kernel": "match_top2_kernel<f32>", "bound": "mfma", "achieved": round(ach, 3),
-                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4)}
-        else:
-            # The contract's reading: ALGORITHMIC flops (2NM128) over the launch time, against the dense peak of the
-            # dtype the MFMAs run in (bf16). The screen executes 3.125 bf16 flops per algorithmic flop, so the pipe is
-            # `frac_executed` busy; against the fp32-MFMA roofline the path's arithmetic is specified in, the same
-            # launch reads `vs_f32_mfma_peak` (> 1: faster than any fp32-MFMA formulation can be).
-            roof = {"kernel": "match_top2_kernel<bf16x3>", "bound": "mfma", "achieved": round(ach, 3),
-                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                    "executed_TFLOPs": round(ach * BF16X3_EXECUTED_PER_ALGORITHMIC, 3),
-                    "frac_executed": round(ach * BF16X3_EXECUTED_PER_ALGORITHMIC / MFMA_BF16_PEAK_TFLOPS, 4),
-                    "vs_f32_mfma_peak": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
-                    "sustained_bf16_mfma_measured": MFMA_BF16_SUSTAINED_MEASURED_TFLOPS,
-                    "frac_executed_of_sustained": round(ach * BF16X3_EXECUTED_PER_ALGORITHMIC / MFMA_BF16_SUSTAINED_MEASURED_TFLOPS, 4),
-                    "note": "screen on split bf16 operands (a_h.b_h + a_h.b_l + a_l.b_h); match decisions are made on "
-                            "distances recomputed exactly in fp32 (results bit-identical to the fp32 screen and the oracle)"}
-        roof.update({"traffic": t_match if screen == "f32" else traffic.get("match_top2_kernel_bf16x3", {}).get("hbm_bytes_per_launch"),
-                     "traffic_note": "HBM bytes per launch from the rocprofv3 PMC passes in profiles/ (not live)",
-                     "avg_ms": round(m_ms, 4), "launches_timed": len(match_ms), "launch_shape": [nA, nB, 128],
-                     "screen": screen})
-        roof_f32 = None
-        if isinstance(f32_ms, tuple) and f32_ms[0]:
-            ms32 = sum(f32_ms[0]) / len(f32_ms[0])
-            fl32 = 256.0 * sum(a * b for a, b in f32_ms[2]) / len(f32_ms[2])
-            roof_f32 = {"kernel": "match_top2_kernel<f32>", "bound": "mfma", "achieved": round(fl32 / (ms32 * 1e-3) / 1e12, 3),
-                        "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(fl32 / (ms32 * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": t_match,
-                        "avg_ms": round(ms32, 4), "launches_timed": len(f32_ms[0]),
-                        "same_matches_as_default_screen": f32_ms[1],
-                        "note": "the fp32 screen (NM_MATCH_SCREEN=f32) on the same pairs, after the timed region"}
-        elif isinstance(f32_ms, str):
-            roof_f32 = {"error": f32_ms}
+
+        def roof_of(scr, ms, fl):
+            # ALGORITHMIC flops (2NM128, with every launch's own N and M) over the summed launch time
+            ach = sum(fl) / (sum(ms) * 1e-3) / 1e12
+            if scr == "f32":
+                r = {"kernel": "match_top2_kernel<f32>", "bound": "mfma", "achieved": round(ach, 3),
+                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                     "traffic": t_match}
+            else:
+                # against the dense peak of the dtype the MFMAs run in (bf16). The screen executes 3.125 bf16 flops per
+                # algorithmic flop, so the pipe is `frac_executed` busy; against the fp32-MFMA roofline the path's
+                # arithmetic is specified in, the same launch reads `vs_f32_mfma_peak`.
+                r = {"kernel": "match_top2_kernel<bf16x3>", "bound": "mfma", "achieved": round(ach, 3),
+                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                     "executed_TFLOPs": round(ach * BF16X3_EXECUTED_PER_ALGORITHMIC, 3),
+                     "frac_executed": round(ach * BF16X3_EXECUTED_PER_ALGORITHMIC / MFMA_BF16_PEAK_TFLOPS, 4),
+                     "vs_f32_mfma_peak": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                     "sustained_bf16_mfma_measured": MFMA_BF16_SUSTAINED_MEASURED_TFLOPS,
+                     "frac_executed_of_sustained": round(ach * BF16X3_EXECUTED_PER_ALGORITHMIC / MFMA_BF16_SUSTAINED_MEASURED_TFLOPS, 4),
+                     "traffic": traffic.get("match_top2_kernel_bf16x3", {}).get("hbm_bytes_per_launch"),
+                     "note": "screen on split bf16 operands (a_h.b_h + a_h.b_l + a_l.b_h); match decisions are made on "
+                             "distances recomputed exactly in fp32 (results bit-identical to the fp32 screen and the oracle)"}
+            r.update({"traffic_note": "HBM bytes per launch from the rocprofv3 PMC passes in profiles/ (stored, not live)",
+                      "avg_ms": round(sum(ms) / len(ms), 4), "launches_timed": len(ms),
+                      "avg_launch_flops": round(sum(fl) / len(fl), 1), "screen": scr})
+            return r
+        roof = roof_of(screen, match_ms, match_fl)
+        roof["launch_shape_last_step_pair0"] = [nA, nB, 128]
         out = {
             "metric": METRIC, "value": round(pairs_total / dt, 3), "unit": "frame-pairs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[2]: SIFT detect+describe x2 + fused BF L2 match per 1920x1080 pair", "match_screen": screen,
+                       "match_sizes": "device",
+                       "frames": "fresh every step: %d distinct sets of %d frames per rank, step k on set k mod %d "
+                                 "(warmup + steps = %d)" % (n_sets, 2 * P, n_sets, total_steps),
                        "pairs_per_gpu_per_step": P, "detect_streams": S, "frames_per_detect_call": B,
-                       "host_enqueue_threads": T, "match_streams": MS, "pairs_per_match_call": MB, "phases": "overlapped" if overlap else "detect then match",
-                       "keypoints_pair0": [nA, nB], "capacity": CAP,
+                       "host_enqueue_threads": T, "match_streams": MS, "pairs_per_match_call": MB,
+                       "phases": "overlapped" if (args.overlap and B % 2 == 0) else "detect then match",
+                       "keypoints_pair0_last_step": [nA, nB], "capacity": CAP,
                        "parallelism": "frame-pair sharding, %d rank(s), no data-path collective" % world},
-            "keypoints_per_s": round(kp_all * args.steps / dt, 1),
-            "descriptor_comparisons_per_s": round(cmp_all * args.steps / dt, 1),
+            "keypoints_per_s": round(kp_all / dt, 1),
+            "descriptor_comparisons_per_s": round(cmp_all / dt, 1),
+            "per_rank_ms": [round(v, 3) for v in ranks_ms],
+            "ranks_seen_by_communicator": ranks_seen, "backend": (args.backend if world > 1 else None),
             "roofline": roof,
             "roofline_pyramid": roofline_pyramid(B, p_ms, pyr_all_ms, traffic, pyr_nodog_ms),
         }
-        if roof_f32 is not None:
-            out["roofline_f32_screen"] = roof_f32
+        if world > 1 and args.backend == "nccl":
+            out["rccl_ranks_seen"] = ranks_seen
+        if f32 is not None:
+            if "error" in f32:
+                out["roofline_f32_screen"] = {"error": f32["error"]}
+            else:
+                out["value_f32_screen"] = round(pairs_total / f32["dt"], 3)
+                out["roofline_f32_screen"] = roof_of("f32", f32["ms"], f32["fl"])
+                out["roofline_f32_screen"].update({"same_matches_as_default_screen": f32["same"],
+                                                   "note": "the same timed loop (EXACTLY --steps steps, barrier + synchronize "
+                                                           "both sides) with the fp32 MFMA screen, run after the headline loop"})
+        if latency is not None:
+            out["latency"] = latency
         if dropin is not None:
             out["dropin_api"] = dropin
         if detect256 is not None:
@@ -624,8 +712,8 @@ def main():
             out["allpairs_100k"] = extra
         if not args.no_cpu_baseline and world == 1:        # reported at N = 1 only (the other ranks would wait for it)
             import numpy as np
-            out["cpu_baseline"], (r0, r1, m) = cpu_baseline()
-            # the oracle's pair 0 against what the timed loop produced, bit for bit (siftfunctions.cu:100-181, match.cu:83-117)
+            out["cpu_baseline"], (r0, r1, m) = cpu_baseline(*snap["seeds"])
+            # the oracle's pair against what the timed loop produced, bit for bit (siftfunctions.cu:100-181, match.cu:83-117)
             ok = snap["n"] == (r0["n"], r1["n"])
             ok = ok and all(np.array_equal(snap["kpts"][k], r["kpts"]) and np.array_equal(snap["desc"][k], r["desc"])
                             for k, r in ((0, r0), (1, r1)))

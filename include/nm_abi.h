@@ -184,6 +184,19 @@ NM_API int nm_sift_match_get_screen(void);
 NM_API size_t nm_sift_match_batch_workspace_bytes(int n, const int *nA, const int *nB);
 NM_API int nm_sift_match_batch_f32(int n, const float *const *A, const int *nA, const float *const *B, const int *nB,
                                    int *const *result, float ambiguity, void *workspace, void *stream);
+/* The same with the set sizes read from DEVICE memory: d_nA[k] / d_nB[k] point at the int the frame driver wrote
+ * (d_num_items of nm_sift_detect_describe[_batch]; the reference keeps SiftData::_num_items on the host after one
+ * synchronisation per level, sift/siftfunctions.cu:165-178, and compute_sift_matches reads it there, :15-40). A live
+ * client therefore chains detect -> match on a stream with no host read-back, and a HIP graph captured over both replays
+ * correctly on frames with different keypoint counts. capA / capB bound the sizes (values above them are clipped, as the
+ * frame driver clips at its capacity; a size <= 0 makes the pair a no-op): every grid and the workspace are laid out for
+ * them, and the work plan for the real sizes is made on the device. Results are identical to the host-sized entry called
+ * with the same sizes. workspace: nm_sift_match_batch_dev_workspace_bytes(n, capA, capB) bytes.
+ * nm_sift_match_fallback_count(workspace + k * (that / n), capA, capB, ...) reads pair k's fallback count. */
+NM_API size_t nm_sift_match_batch_dev_workspace_bytes(int n, int capA, int capB);
+NM_API int nm_sift_match_batch_dev_f32(int n, const float *const *A, const int *const *d_nA, const float *const *B,
+                                       const int *const *d_nB, int capA, int capB, int *const *result, float ambiguity,
+                                       void *workspace, void *stream);
 /* HOST functions (no device access; on a box without a GPU the MI355X geometry of 256 CUs / 8 XCDs is assumed): the work
  * distribution the matcher uses for (nA, nB). plan[0..9] = query blocks of 256 rows, candidate tiles of 128 rows, persistent
  * workgroups G, partial lists per query S (<= 64, what the workspace bound assumes), XCD groups X, workgroups per group,

@@ -51,6 +51,8 @@ _SIGNATURES = {
     "nm_profile_event_pairs": (_I, [_I, _P, _I]),
     "nm_sift_match_batch_workspace_bytes": (_SZ, [_I, _P, _P]),
     "nm_sift_match_batch_f32": (_I, [_I, _P, _P, _P, _P, _P, _F, _P, _P]),
+    "nm_sift_match_batch_dev_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "nm_sift_match_batch_dev_f32": (_I, [_I, _P, _P, _P, _P, _I, _I, _P, _F, _P, _P]),
     "nm_sift_match_workspace_bytes": (_SZ, [_I, _I]),
     "nm_sift_match_set_screen": (_I, [_I]),
     "nm_sift_match_get_screen": (_I, []),
@@ -336,6 +338,41 @@ def sift_match_batch(As, Bs, nAs, nBs, results, ambiguity=0.8, workspace=None):
     return workspace
 
 
+class MatchBatchDevWorkspace:
+    """Device scratch for nm_sift_match_batch_dev_f32: n pairs of at most (capA, capB) rows, sizes read on the device."""
+
+    def __init__(self, n, capA, capB, device):
+        torch = _torch()
+        self.n, self.capA, self.capB = n, capA, capB
+        self.pair_bytes = lib().nm_sift_match_batch_dev_workspace_bytes(1, capA, capB)
+        self.buf = torch.empty(n * self.pair_bytes, dtype=torch.uint8, device=device)
+
+
+def sift_match_batch_dev(As, d_nAs, Bs, d_nBs, results, ambiguity=0.8, workspace=None, capA=None, capB=None):
+    """len(As) <= MATCH_MAX_BATCH matches whose set sizes are int32 DEVICE tensors (e.g. SiftArena.num_items): no host
+    read-back between detect and match. capA / capB default to the rows of the descriptor tensors."""
+    torch = _torch()
+    n = len(As)
+    if not (n == len(Bs) == len(d_nAs) == len(d_nBs) == len(results)) or not 0 < n <= MATCH_MAX_BATCH:
+        raise NmError("bad batch")
+    capA = min(a.shape[0] for a in As) if capA is None else capA
+    capB = min(b.shape[0] for b in Bs) if capB is None else capB
+    if any(a.shape[0] < capA for a in As) or any(b.shape[0] < capB for b in Bs) or any(r.shape[0] < capA for r in results):
+        raise NmError("a descriptor set or result is smaller than the capacity")
+    if workspace is None:
+        workspace = MatchBatchDevWorkspace(n, capA, capB, As[0].device)
+    if workspace.buf.numel() < lib().nm_sift_match_batch_dev_workspace_bytes(n, capA, capB):
+        raise NmError("batch workspace too small")
+    arr = lambda vals: (C.c_void_p * n)(*vals)
+    _check(lib().nm_sift_match_batch_dev_f32(n, arr([_dev(a, torch.float32) for a in As]),
+                                             arr([_dev(c, torch.int32) for c in d_nAs]),
+                                             arr([_dev(b, torch.float32) for b in Bs]),
+                                             arr([_dev(c, torch.int32) for c in d_nBs]), capA, capB,
+                                             arr([_dev(r, torch.int32) for r in results]), ambiguity,
+                                             _dev(workspace.buf), _stream()), "nm_sift_match_batch_dev_f32")
+    return workspace
+
+
 MATCH_SCREENS = {"f32": 0, "bf16x3": 1}
 
 
@@ -574,7 +611,9 @@ def scale_space_batch(arenas, grays, write_dog=True):
 class SiftArena:
     """Per-stream frame arena + outputs of nm_sift_detect_describe (replaces PyramidData + SiftData)."""
 
-    def __init__(self, width, height, capacity=16384, device="cuda"):
+    def __init__(self, width, height, capacity=16384, device="cuda", num_items=None):
+        """num_items: optional 1-element int32 device tensor (e.g. a view into a table of all arenas' counts) that
+        receives the descriptor count instead of a tensor of the arena's own."""
         torch = _torch()
         self.width, self.height, self.capacity = width, height, capacity
         self._h = C.c_void_p()
@@ -591,7 +630,9 @@ class SiftArena:
         self.y = torch.zeros(capacity, dtype=torch.float32, device=device)
         self.kpts = torch.zeros((capacity, 4), dtype=torch.float32, device=device)
         self.orients = torch.zeros((capacity, 2), dtype=torch.float32, device=device)
-        self.num_items = torch.zeros(1, dtype=torch.int32, device=device)
+        if num_items is not None and (num_items.dtype != torch.int32 or num_items.numel() != 1 or num_items.device != device):
+            raise NmError("num_items must be a 1-element int32 tensor on %s" % device)
+        self.num_items = torch.zeros(1, dtype=torch.int32, device=device) if num_items is None else num_items
 
     @property
     def bytes(self):

@@ -132,12 +132,15 @@ struct SegIter {
     }
 };
 
-static int plan_max_slots(const MatchPlan &p)
+// Largest number of partial-list slots any query block needs under plan p. The (group, local query block) pairs are dealt
+// over `nlanes` callers (host: 1; device: the lanes of one wave, which then take the maximum over the wave).
+NM_HD int plan_max_slots_part(const MatchPlan &p, int lane, int nlanes)
 {
-    int S = 1;
+    int S = 1, k = 0;
     for (int x = 0; x < p.X; ++x) {
         const PlanGroup g = plan_group(p, x);
-        for (int qbl = 0; qbl < g.nq; ++qbl) {
+        for (int qbl = 0; qbl < g.nq; ++qbl, ++k) {
+            if (k % nlanes != lane) continue;
             int f, l;
             piece_owners(p, g, p.C - 1, qbl, f, l);
             const int n = plan_slot(p, g, p.C - 1, qbl, l) + 1;
@@ -147,39 +150,48 @@ static int plan_max_slots(const MatchPlan &p)
     return S;
 }
 
-static MatchPlan make_plan(int nA, int nB)
+NM_HD int hd_divup(int a, int b) { return (a + b - 1) / b; }
+
+// The plan for (nA, nB) on a device of n_cu compute units in n_xcd XCDs. REDUCE(S) turns a caller's partial maximum into
+// the maximum over all callers (identity on the host). Every caller computes the same plan.
+template <typename Reduce>
+NM_HD MatchPlan make_plan_on(int nA, int nB, int n_cu, int n_xcd, int lane, int nlanes, Reduce reduce)
 {
     MatchPlan p;
-    const int n_cu = nm_cu_count();          // one persistent workgroup per CU of the current device (256 on MI355X SPX)
-    const int n_xcd = nm_xcd_count();
-    p.qblocks = nm_divup(nA > 0 ? nA : 1, QB);
-    p.T = nm_divup(nB > 0 ? nB : 1, TILE_C);
+    p.qblocks = hd_divup(nA > 0 ? nA : 1, QB);
+    p.T = hd_divup(nB > 0 ? nB : 1, TILE_C);
     const long U = (long)p.qblocks * p.T;
     // XCD-grouped order: the whole chip is used, the query blocks split over the XCDs to within 3 %, and every XCD has a
     // few query blocks to share tiles between
     if (n_xcd > 1 && n_cu % n_xcd == 0 && U >= 4L * n_cu && p.qblocks >= 2 * n_xcd &&
-        (long)nm_divup(p.qblocks, n_xcd) * n_xcd * 100 <= (long)p.qblocks * 103) {
+        (long)hd_divup(p.qblocks, n_xcd) * n_xcd * 100 <= (long)p.qblocks * 103) {
         p.G = n_cu; p.X = n_xcd; p.Gx = n_cu / n_xcd;
         p.q_base = p.qblocks / n_xcd; p.q_rem = p.qblocks % n_xcd;
         const long upw = U / n_cu;                                   // units per workgroup
         int C = (int)((p.T + upw / 2) / (upw > 0 ? upw : 1));       // chunks ~ T / units-per-workgroup
         if (C < 1) C = 1;
         if (C > p.T) C = p.T;
-        p.Tc = nm_divup(p.T, C);
-        p.C = nm_divup(p.T, p.Tc);
-        p.S = plan_max_slots(p);
+        p.Tc = hd_divup(p.T, C);
+        p.C = hd_divup(p.T, p.Tc);
+        p.S = reduce(plan_max_slots_part(p, lane, nlanes));
         if (p.S <= MAX_CHUNKS) return p;
     }
     // plain query-block-major order over one group
-    const int min_len = nm_divup(p.T, MAX_CHUNKS - 2);            // a block spans <= MAX_CHUNKS - 2 whole ranges + 2 ends
+    const int min_len = hd_divup(p.T, MAX_CHUNKS - 2);            // a block spans <= MAX_CHUNKS - 2 whole ranges + 2 ends
     long G = U / min_len;
     if (G > n_cu) G = n_cu;
     if (G < 1) G = 1;
     p.G = (int)G; p.X = 1; p.Gx = p.G;
     p.q_base = p.qblocks; p.q_rem = 0;
     p.Tc = p.T; p.C = 1;
-    p.S = plan_max_slots(p);
+    p.S = reduce(plan_max_slots_part(p, lane, nlanes));
     return p;
+}
+
+static MatchPlan make_plan(int nA, int nB)
+{
+    // one persistent workgroup per CU of the current device (256 on MI355X SPX)
+    return make_plan_on(nA, nB, nm_cu_count(), nm_xcd_count(), 0, 1, [](int s) { return s; });
 }
 
 // Everything the small launches around the MFMA kernel need for one (A, B) pair. A batched call (nm_sift_match_batch_f32)
@@ -198,13 +210,23 @@ struct MatchPair {
     unsigned *As, *Bs;         // bf16x3 screen: split images of A (scaled by -2) and B, 512 B per row (hi | lo)
     uint4 *nbslot;             // bf16x3 screen: the candidates' norm k-slots, padded to whole tiles
     int nA, nB, S, mode, index_offset;
+    // Device-sized call (nm_sift_match_batch_dev_f32): the real sizes are read from device memory (what the frame driver
+    // left in d_num_items), nA / nB above are the CAPACITIES every grid and the workspace are laid out for, and the work
+    // plan is made on the device (nbmax_kernel) into d_plan. NULL for the host-sized entries.
+    const int *d_nA, *d_nB;
+    MatchPlan *d_plan;
 };
+// sizes / partial-list stride of a pair as the kernels see them
+__device__ __forceinline__ int pair_nA(const MatchPair &c) { return c.d_nA ? min(max(*c.d_nA, 0), c.nA) : c.nA; }
+__device__ __forceinline__ int pair_nB(const MatchPair &c) { return c.d_nB ? min(max(*c.d_nB, 0), c.nB) : c.nB; }
+__device__ __forceinline__ int pair_S(const MatchPair &c) { return c.d_plan ? c.d_plan->S : c.S; }
 constexpr int MATCH_MAX_BATCH = 16;
 struct MatchBatch {
     MatchPair p[MATCH_MAX_BATCH];
     int n;
     float ambiguity;
     float err_coeff;           // |screen value - exact d| <= err_coeff (sqrt na + sqrt nb)^2 for the screen in use
+    int n_cu, n_xcd;           // device-sized calls: the geometry the device-side plan is made for
 };
 static_assert(sizeof(MatchBatch) <= 4096, "kernel arguments are limited to 4 KB");
 
@@ -245,7 +267,7 @@ template <bool SPLIT>
 __global__ __launch_bounds__(256) void prep_kernel(MatchBatch bt)
 {
     const MatchPair &c = bt.p[blockIdx.y];
-    const int nA = c.nA, nB = c.nB, lane = threadIdx.x & 63, k4 = lane & 31;
+    const int nA = pair_nA(c), nB = pair_nB(c), lane = threadIdx.x & 63, k4 = lane & 31;
     const int padded = nm_divup_dev(nB, TILE_C) * TILE_C;
     if (blockIdx.x == 0 && threadIdx.x == 0 && c.fb_count) *c.fb_count = 0;   // first launch of a match call: resets the fallback list
     const int r0 = blockIdx.x * PREP_ROWS + (threadIdx.x >> 6) * 4 + (lane >> 5);    // this lane's rows: r0 and r0 + 2
@@ -302,8 +324,20 @@ __global__ __launch_bounds__(1024) void nbmax_kernel(MatchBatch bt)
 {
     __shared__ float s[16];
     const MatchPair &c = bt.p[blockIdx.x];
+    const int nB = pair_nB(c);
+    if (c.d_plan && threadIdx.x >= 960) {
+        // device-sized call: the last wave makes the work plan for the real sizes (make_plan_on: the same function the host
+        // runs for the host-sized entries), its lanes sharing the slot count, while the others reduce the norms
+        const int lane = threadIdx.x & 63;
+        const MatchPlan p = make_plan_on(pair_nA(c), nB, bt.n_cu, bt.n_xcd, lane, 64, [](int v) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d));
+            return v;
+        });
+        if (lane == 0) *c.d_plan = p;
+    }
     float m = 0.f;
-    for (int i = threadIdx.x; i < c.nB; i += 1024) m = __builtin_fmaxf(m, c.nb[i]);
+    for (int i = threadIdx.x; i < nB; i += 1024) m = __builtin_fmaxf(m, c.nb[i]);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, d));
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
@@ -532,20 +566,31 @@ __device__ __forceinline__ void mfma_half_bf16(f32x16 &acc0, f32x16 &acc1, const
 
 // BF16 = false: A, B are the fp32 descriptor rows. BF16 = true: A, B are the split images written by prep_kernel<true>
 // (same 512-byte rows, so the staging is identical) and nbslot replaces nb.
+// Device-sized launches (d_plan != NULL): nA_arg / nB_arg are the capacities, the real sizes and the plan made for them
+// (nbmax_kernel) are read from device memory, and the grid is one workgroup per CU of which the first plan.G work.
 template <bool BF16>
-__global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restrict__ A, int nA,
-                                                           const float *__restrict__ B, int nB,
+__global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restrict__ A, int nA_arg,
+                                                           const float *__restrict__ B, int nB_arg,
                                                            const float *__restrict__ na, const float *__restrict__ nb,
                                                            const uint4 *__restrict__ nbslot,
-                                                           MatchPlan plan, float4 *__restrict__ partial,
-                                                           float *__restrict__ partial3)
+                                                           MatchPlan plan_arg, float4 *__restrict__ partial,
+                                                           float *__restrict__ partial3,
+                                                           const int *__restrict__ d_nA, const int *__restrict__ d_nB,
+                                                           const MatchPlan *__restrict__ d_plan)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int srow = tid >> 5, scol = (tid & 31) * 4;     // staging coordinates: 16 rows x 32 float4 per pass
-    const int S = plan.S;
     const int wg = blockIdx.x;
+    int nA = nA_arg, nB = nB_arg;
+    MatchPlan plan = plan_arg;
+    if (d_plan) {                                         // uniform: scalar loads
+        nA = min(max(*d_nA, 0), nA_arg); nB = min(max(*d_nB, 0), nB_arg);
+        plan = *d_plan;
+        if (nA <= 0 || nB <= 0 || wg >= plan.G) return;   // an empty set is a no-op for the pair, as in the reference
+    }
+    const int S = plan.S;
     const int xg = wg % plan.X, vg = wg / plan.X;         // XCD group (blocks b, b + X share an XCD) and position in it
     const PlanGroup grp = plan_group(plan, xg);
     const long u_begin = group_begin(grp, vg), u_end = group_begin(grp, vg + 1);
@@ -781,7 +826,8 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(MatchBatch bt)
 {
     const MatchPair &c = bt.p[blockIdx.y];
     const float *__restrict__ A = c.A, *__restrict__ B = c.B;
-    const int nA = c.nA, S = c.S, mode = c.mode, index_offset = c.index_offset;
+    const int nA = pair_nA(c), S = pair_S(c), mode = c.mode, index_offset = c.index_offset;
+    if (nA <= 0 || pair_nB(c) <= 0) return;              // device-sized call with an empty set: nothing was screened
     const float4 *__restrict__ partial = c.partial;
     const float *__restrict__ partial3 = c.partial3;
     const float *__restrict__ na = c.na;
@@ -798,7 +844,7 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(MatchBatch bt)
     float rest = __builtin_inff();
 #pragma unroll
     for (int k = 0; k < 4; ++k) { cd[k] = __builtin_inff(); ci[k] = -1; }
-    const int nB = c.nB;
+    const int nB = pair_nB(c);
     auto insert = [&](float d, int j) {
         if (j < 0 || j >= nB) return;                // absent, or a row of the last tile's padding (bf16x3: finite "norm")
 #pragma unroll
@@ -928,7 +974,7 @@ __global__ __launch_bounds__(256) void match_fallback_kernel(MatchBatch bt)
 {
     const MatchPair &c = bt.p[blockIdx.z];
     const float *__restrict__ A = c.A, *__restrict__ B = c.B;
-    const int nB = c.nB;
+    const int nB = pair_nB(c);
     const int *__restrict__ fb_list = c.fb_list;
     float4 *__restrict__ part = c.partial;
     __shared__ __attribute__((aligned(16))) float sXY[2 * XD_KC * XD_PITCH];
@@ -1276,7 +1322,7 @@ static float screen_err_coeff(int screen) { return screen ? 2.75e-5f : 1.56e-5f;
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static MatchWs carve(void *workspace, int nA, int nB, const MatchPlan &p)
+static MatchWs carve(void *workspace, int nA, int nB)
 {
     MatchWs w;
     char *base = static_cast<char *>(workspace);
@@ -1310,6 +1356,7 @@ struct MatchJob {                 // host-side description of one pair of a (pos
     float *min1, *min2;
     int *idx1;
     void *workspace;
+    const int *d_nA, *d_nB;       // device-sized call: nA / nB above are the capacities, the real sizes live here
 };
 
 // norms (1 launch for all pairs) -> MFMA top-2 (1 launch per pair) -> finalize, fallback, merge (1 launch each)
@@ -1323,22 +1370,31 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
     bt.ambiguity = ambiguity;
     bt.err_coeff = screen_err_coeff(screen);
     int max_rows = 0, max_a = 0;
+    bool dev_sized = false;
     for (int k = 0; k < n; ++k) {
         const MatchJob &j = jobs[k];
         if (j.nA <= 0 || j.nB <= 0) continue;                 // empty sets: a no-op for this pair, as in the reference
         const int q = bt.n++;
-        plans[q] = make_plan(j.nA, j.nB);
-        const MatchWs w = carve(j.workspace, j.nA, j.nB, plans[q]);
+        const bool dev = j.d_nA != nullptr;
+        if (q > 0 && dev != dev_sized) return (int)hipErrorInvalidValue;
+        dev_sized = dev;
+        if (!dev) plans[q] = make_plan(j.nA, j.nB);
+        const MatchWs w = carve(j.workspace, j.nA, j.nB);
         MatchPair &c = bt.p[q];
         c.A = j.A; c.B = j.B; c.nA = j.nA; c.nB = j.nB; c.na = w.na; c.nb = w.nb; c.partial = w.partial;
-        c.partial3 = w.partial3; c.fb_count = w.fb_count; c.fb_list = w.fb_list; c.nbmax = reinterpret_cast<float *>(w.fb_count + 16); c.S = plans[q].S; c.mode = j.mode;
+        c.partial3 = w.partial3; c.fb_count = w.fb_count; c.fb_list = w.fb_list; c.nbmax = reinterpret_cast<float *>(w.fb_count + 16);
+        c.S = dev ? MAX_CHUNKS : plans[q].S; c.mode = j.mode;
         c.index_offset = j.index_offset; c.result = j.result; c.min1 = j.min1; c.min2 = j.min2; c.idx1 = j.idx1;
         c.As = w.As; c.Bs = w.Bs; c.nbslot = w.nbslot;
+        c.d_nA = j.d_nA; c.d_nB = j.d_nB;
+        c.d_plan = dev ? reinterpret_cast<MatchPlan *>(w.fb_count + 32) : nullptr;      // inside the 256-byte counter block
         if (j.nA >= (1 << 22) || j.nB >= (1 << 22)) return (int)hipErrorInvalidValue;   // 32-bit byte ranges of the SRDs
         max_rows = max(max_rows, j.nA + nm_divup(j.nB, TILE_C) * TILE_C);
         max_a = max(max_a, j.nA);
     }
     if (bt.n == 0) return 0;
+    const int n_cu = nm_cu_count();
+    bt.n_cu = n_cu; bt.n_xcd = nm_xcd_count();
     if (screen) hipLaunchKernelGGL(prep_kernel<true>, dim3(nm_divup(max_rows, PREP_ROWS), bt.n), dim3(256), 0, st, bt);
     else hipLaunchKernelGGL(prep_kernel<false>, dim3(nm_divup(max_rows, PREP_ROWS), bt.n), dim3(256), 0, st, bt);
     NM_LAUNCH_CHECK();
@@ -1351,14 +1407,17 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     for (int q = 0; q < bt.n; ++q) {
         const MatchPair &c = bt.p[q];
+        // device-sized: one workgroup per CU, of which the first plan.G (decided on the device) work
+        const int grid = dev_sized ? n_cu : plans[q].G;
+        const MatchPlan plan_arg = dev_sized ? MatchPlan{} : plans[q];
         nm_prof_begin(NM_PROF_MATCH_TOP2, st);
         if (screen)
-            hipLaunchKernelGGL(match_top2_kernel<true>, dim3(plans[q].G), dim3(512), lds_bytes, st,
+            hipLaunchKernelGGL(match_top2_kernel<true>, dim3(grid), dim3(512), lds_bytes, st,
                                reinterpret_cast<const float *>(c.As), c.nA, reinterpret_cast<const float *>(c.Bs), c.nB,
-                               c.na, c.nb, c.nbslot, plans[q], c.partial, c.partial3);
+                               c.na, c.nb, c.nbslot, plan_arg, c.partial, c.partial3, c.d_nA, c.d_nB, c.d_plan);
         else
-            hipLaunchKernelGGL(match_top2_kernel<false>, dim3(plans[q].G), dim3(512), lds_bytes, st, c.A, c.nA, c.B, c.nB,
-                               c.na, c.nb, c.nbslot, plans[q], c.partial, c.partial3);
+            hipLaunchKernelGGL(match_top2_kernel<false>, dim3(grid), dim3(512), lds_bytes, st, c.A, c.nA, c.B, c.nB,
+                               c.na, c.nb, c.nbslot, plan_arg, c.partial, c.partial3, c.d_nA, c.d_nB, c.d_plan);
         nm_prof_end(NM_PROF_MATCH_TOP2, st);
         NM_LAUNCH_CHECK();
     }
@@ -1379,7 +1438,7 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
 static int run_fused(const float *A, int nA, const float *B, int nB, int mode, int index_offset, float ambiguity,
                      int *result, float *min1, int *idx1, float *min2, void *workspace, hipStream_t st)
 {
-    const MatchJob j{A, B, nA, nB, mode, index_offset, result, min1, min2, idx1, workspace};
+    const MatchJob j{A, B, nA, nB, mode, index_offset, result, min1, min2, idx1, workspace, nullptr, nullptr};
     return run_fused_batch(&j, 1, ambiguity, st);
 }
 
@@ -1446,8 +1505,35 @@ int nm_sift_match_batch_f32(int n, const float *const *A, const int *nA, const f
     MatchJob jobs[MATCH_MAX_BATCH];
     char *ws = static_cast<char *>(workspace);
     for (int k = 0; k < n; ++k) {
-        jobs[k] = MatchJob{A[k], B[k], nA[k], nB[k], 0, 0, result[k], nullptr, nullptr, nullptr, ws};
+        jobs[k] = MatchJob{A[k], B[k], nA[k], nB[k], 0, 0, result[k], nullptr, nullptr, nullptr, ws, nullptr, nullptr};
         ws += pair_workspace_bytes(nA[k], nB[k]);
+    }
+    return run_fused_batch(jobs, n, ambiguity, nm_stream(stream));
+}
+
+// Device-sized batch: what a live client needs -- the frame driver leaves its descriptor count on the DEVICE
+// (d_num_items, siftfunctions.cu:165-178 keeps it on the host after a synchronisation per level), and this entry reads it
+// there. Every grid and the workspace are laid out for (capA, capB); the work plan is made on the device for the real
+// sizes. No host synchronisation, no allocation: detect -> match chains on a stream and can be captured in a HIP graph
+// that is replayed on different frames.
+size_t nm_sift_match_batch_dev_workspace_bytes(int n, int capA, int capB)
+{
+    return (size_t)(n > 0 ? n : 0) * pair_workspace_bytes(capA, capB);
+}
+
+int nm_sift_match_batch_dev_f32(int n, const float *const *A, const int *const *d_nA, const float *const *B,
+                                const int *const *d_nB, int capA, int capB, int *const *result, float ambiguity,
+                                void *workspace, void *stream)
+{
+    if (n <= 0) return 0;
+    if (n > MATCH_MAX_BATCH || !A || !d_nA || !B || !d_nB || !result || !workspace || capA <= 0 || capB <= 0)
+        return (int)hipErrorInvalidValue;
+    MatchJob jobs[MATCH_MAX_BATCH];
+    char *ws = static_cast<char *>(workspace);
+    for (int k = 0; k < n; ++k) {
+        if (!A[k] || !B[k] || !d_nA[k] || !d_nB[k] || !result[k]) return (int)hipErrorInvalidValue;
+        jobs[k] = MatchJob{A[k], B[k], capA, capB, 0, 0, result[k], nullptr, nullptr, nullptr, ws, d_nA[k], d_nB[k]};
+        ws += pair_workspace_bytes(capA, capB);
     }
     return run_fused_batch(jobs, n, ambiguity, nm_stream(stream));
 }
@@ -1492,8 +1578,7 @@ int nm_sift_match_plan_segments(int nA, int nB, int wg, int *segments, int max_s
 int nm_sift_match_fallback_count(const void *workspace, int nA, int nB, int *host_count, void *stream)
 {
     if (!workspace || !host_count || nA <= 0 || nB <= 0) return (int)hipErrorInvalidValue;
-    const MatchPlan p = make_plan(nA, nB);
-    MatchWs w = carve(const_cast<void *>(workspace), nA, nB, p);
+    MatchWs w = carve(const_cast<void *>(workspace), nA, nB);
     NM_RETURN_IF(hipMemcpyAsync(host_count, w.fb_count, sizeof(int), hipMemcpyDeviceToHost, nm_stream(stream)));
     return (int)hipStreamSynchronize(nm_stream(stream));
 }

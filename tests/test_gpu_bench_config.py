@@ -106,3 +106,38 @@ def test_match_batch_16_pairs_on_real_descriptors(nm, oracle, cuda, bench16):
             del D
     # the last call on ws1 was the shard call of pair 9: real SIFT descriptors rarely need the exact fallback
     assert 0 <= nm.match_fallback_count(ws1, cnt[pairs[9][0]], cnt[pairs[9][1]]) < 200
+
+
+def test_match_batch_dev_16_pairs_on_real_descriptors(nm, oracle, cuda, bench16):
+    """nm_sift_match_batch_dev_f32: the same 16 pairs with the set sizes read from the frame driver's d_num_items ON THE
+    DEVICE (what bench.py's timed loop issues: no host read-back between detect and match; the reference's flow is
+    siftfunctions.cu:165-178 -> :15-40). Must equal the host-sized batched call on every pair and the oracle's scan
+    (match.cu:83-117) on pairs 0 and 9; rows past the real size stay untouched. Both MFMA screens."""
+    import torch
+    _, arenas, _ = bench16
+    cnt = [int(a.num_items.item()) for a in arenas]
+    pairs = [(2 * i, 2 * i + 1) for i in range(8)] + [(2 * i + 1, 2 * i) for i in range(8)]
+    host = [torch.full((CAP,), -1, dtype=torch.int32, device=cuda) for _ in pairs]
+    nm.sift_match_batch([arenas[a].desc for a, _ in pairs], [arenas[b].desc for _, b in pairs],
+                        [cnt[a] for a, _ in pairs], [cnt[b] for _, b in pairs], host, 0.8,
+                        workspace=nm.MatchBatchWorkspace(16, CAP, CAP, cuda))
+    before = nm.get_match_screen()
+    ws = nm.MatchBatchDevWorkspace(16, CAP, CAP, cuda)
+    try:
+        for screen in ("bf16x3", "f32"):
+            nm.set_match_screen(screen)
+            dev = [torch.full((CAP,), -5, dtype=torch.int32, device=cuda) for _ in pairs]
+            nm.sift_match_batch_dev([arenas[a].desc for a, _ in pairs], [arenas[a].num_items for a, _ in pairs],
+                                    [arenas[b].desc for _, b in pairs], [arenas[b].num_items for _, b in pairs],
+                                    dev, 0.8, workspace=ws)
+            torch.cuda.synchronize()
+            for k, (a, b) in enumerate(pairs):
+                assert torch.equal(dev[k][:cnt[a]], host[k][:cnt[a]]), "pair %d (%s): device-sized != host-sized" % (k, screen)
+                assert bool((dev[k][cnt[a]:] == -5).all()), "pair %d: rows past nA were written" % k
+            for k in (0, 9):
+                a, b = pairs[k]
+                ref, _, _ = oracle.sift_matches(arenas[a].desc[:cnt[a]].cpu().numpy(), arenas[b].desc[:cnt[b]].cpu().numpy(),
+                                                0.8, want_distance=False, prior=np.full(cnt[a], -5, np.int32))
+                assert np.array_equal(dev[k][:cnt[a]].cpu().numpy(), ref), "pair %d (%s) vs oracle" % (k, screen)
+    finally:
+        nm.set_match_screen(before)

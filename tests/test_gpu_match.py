@@ -392,3 +392,58 @@ def test_native_allgather_entry_and_packed_merge(nm, oracle, cuda):
     assert lib.nm_sift_match_merge_packed_f32(packed.data_ptr(), 4, 1500, res2.data_ptr(), 1.5, None) == 0
     torch.cuda.synchronize()
     assert np.array_equal(res2.cpu().numpy(), ref)
+
+
+def test_match_batch_dev_sizes_sweep(nm, oracle, cuda):
+    """Device-sized entry on ragged sizes under one capacity: the plan is made on the device for the real sizes (plain
+    order for small sets, XCD-grouped for large ones), sizes above the capacity are clipped, empty sets and negative
+    counts make the pair a no-op (prior untouched), near-ties still reach the exact fallback."""
+    import torch
+    cap_a, cap_b = 4096, 5000
+    shapes = [(700, 900), (1, 1), (1300, 257), (0, 50), (4096, 5000), (300, 4000), (50, 0), (4096, 130), (2049, 1500)]
+    rng = np.random.default_rng(11)
+    n = len(shapes)
+    As = [H.synth.descriptors(500 + k, cap_a) for k in range(n)]
+    Bs = [H.synth.descriptors(600 + k, cap_b) for k in range(n)]
+    Bs[0][7] = As[0][3]; Bs[0][800] = As[0][3]              # duplicate candidates: tie on the lowest index
+    for i in range(40):                                     # near-ties closer than the screen can resolve -> fallback
+        for c in range(3):
+            v = As[8][i].copy()
+            v[(7 * i + c) % 128] += np.float32(0.25)
+            v[(11 * i + 5 * c) % 128] += np.float32(1e-6 * c)
+            Bs[8][3 * i + c] = v
+    tA = [_t(a, cuda) for a in As]
+    tB = [_t(b, cuda) for b in Bs]
+    sizes_a = [s[0] for s in shapes]; sizes_b = [s[1] for s in shapes]
+    dA = _t(np.array(sizes_a, np.int32), cuda)
+    dB = _t(np.array(sizes_b, np.int32), cuda)
+    results = [torch.full((cap_a,), -9, dtype=torch.int32, device=cuda) for _ in shapes]
+    ws = nm.MatchBatchDevWorkspace(n, cap_a, cap_b, cuda)
+    nm.sift_match_batch_dev(tA, [dA[k:k + 1] for k in range(n)], tB, [dB[k:k + 1] for k in range(n)], results, 0.8,
+                            workspace=ws, capA=cap_a, capB=cap_b)
+    torch.cuda.synchronize()
+    for k, (na, nb) in enumerate(shapes):
+        if na == 0 or nb == 0:
+            assert bool((results[k] == -9).all()), k
+            continue
+        ref, _, _ = oracle.sift_matches(As[k][:na], Bs[k][:nb], 0.8, want_distance=False, prior=np.full(na, -9, np.int32))
+        assert np.array_equal(results[k][:na].cpu().numpy(), ref), (k, na, nb)
+        assert bool((results[k][na:] == -9).all()), (k, na, nb)
+    # the SAME call with other sizes in the same device ints (what a HIP graph replay sees): clipping and negatives
+    dA.copy_(_t(np.array([cap_a + 77, 5, -3, 10, 1000, 4096, 9, 77, 256], np.int32), cuda))
+    dB.copy_(_t(np.array([cap_b + 1, 3, 10, -1, 5000, 128, 129, 5000, 128], np.int32), cuda))
+    for r in results:
+        r.fill_(-9)
+    nm.sift_match_batch_dev(tA, [dA[k:k + 1] for k in range(n)], tB, [dB[k:k + 1] for k in range(n)], results, 0.8,
+                            workspace=ws, capA=cap_a, capB=cap_b)
+    torch.cuda.synchronize()
+    sa = np.clip(dA.cpu().numpy(), 0, cap_a); sb = np.clip(dB.cpu().numpy(), 0, cap_b)
+    for k in range(n):
+        na, nb = int(sa[k]), int(sb[k])
+        if na == 0 or nb == 0:
+            assert bool((results[k] == -9).all()), k
+            continue
+        ref, _, _ = oracle.sift_matches(As[k][:na], Bs[k][:nb], 0.8, want_distance=False, prior=np.full(na, -9, np.int32))
+        assert np.array_equal(results[k][:na].cpu().numpy(), ref), (k, na, nb)
+        assert bool((results[k][na:] == -9).all()), (k, na, nb)
+    assert nm.lib().nm_sift_match_batch_dev_f32(n, None, None, None, None, cap_a, cap_b, None, 0.8, None, None) != 0

@@ -70,6 +70,50 @@ def test_frame_and_match_capture_into_hip_graph(nm, oracle, cuda):
     _eq(a0.desc[:n2], r2["desc"], "second frame through the same graph")
 
 
+def test_detect_match_graph_replays_on_different_frames(nm, oracle, cuda):
+    """One HIP graph over batched detect+describe of a pair AND the device-sized match (nm_sift_match_batch_dev_f32 reads
+    the keypoint counts the frame driver left on the device): replayed on three different frame pairs, whose keypoint
+    counts all differ, it must reproduce the oracle's descriptors and matches (siftfunctions.cu:100-181 -> :15-40;
+    match.cu:83-117). The host-sized matcher entry cannot do this: its sizes are baked into the captured launches."""
+    import torch
+    w, h, cap = 640, 480, 8192
+    seeds = [(0, 1), (2, 3), (5, 4)]
+    fr = {s: H.blurred_frame(s, w, h) for p in seeds for s in p}
+    fr[4] = np.roll(fr[5], (2, 3), axis=(0, 1)).copy()          # a shifted copy: many true matches
+    ref = {s: oracle.sift_detect_describe(f, cap) for s, f in fr.items()}
+    assert len({ref[s]["n"] for s in fr}) == len(fr), "the frames must differ in their keypoint counts"
+    a = [nm.SiftArena(w, h, cap), nm.SiftArena(w, h, cap)]
+    d = [_t(fr[0], cuda), _t(fr[1], cuda)]
+    res = torch.full((cap,), -1, dtype=torch.int32, device=cuda)
+    ws = nm.MatchBatchDevWorkspace(1, cap, cap, cuda)
+    s = torch.cuda.Stream()
+
+    def enqueue():
+        nm.detect_describe_batch(a, d)
+        nm.sift_match_batch_dev([a[0].desc], [a[0].num_items], [a[1].desc], [a[1].num_items], [res], 0.8, workspace=ws)
+    with torch.cuda.stream(s):
+        enqueue()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        enqueue()
+    for p in seeds:
+        d[0].copy_(_t(fr[p[0]], cuda)); d[1].copy_(_t(fr[p[1]], cuda))
+        for x in a:
+            x.desc.zero_(); x.num_items.zero_()
+        res.fill_(-1)
+        g.replay()
+        torch.cuda.synchronize()
+        r0, r1 = ref[p[0]], ref[p[1]]
+        assert int(a[0].num_items.item()) == r0["n"] and int(a[1].num_items.item()) == r1["n"]
+        _eq(a[0].desc[:r0["n"]], r0["desc"], "descriptors of frame %d from graph replay" % p[0])
+        _eq(a[1].desc[:r1["n"]], r1["desc"], "descriptors of frame %d from graph replay" % p[1])
+        want, _, _ = oracle.sift_matches(r0["desc"], r1["desc"], 0.8, want_distance=False)
+        assert np.array_equal(res[:r0["n"]].cpu().numpy(), want), p
+        assert bool((res[r0["n"]:] == -1).all())
+    assert (want >= 0).mean() > 0.3
+
+
 def test_batched_pair_call_captures_into_hip_graph(nm, oracle, cuda):
     """nm_sift_detect_describe_batch forks onto the arenas' side streams with events only: capturable, replayable."""
     import torch
