@@ -1,7 +1,9 @@
 // pairs_native.cpp -- the frame-pair loop of bench.py with no Python and no torch: C ABI (include/nm_abi.h) + HIP runtime.
 // Same synthetic input as bench.py / tests (SplitMix64 counter noise frames, sigma-4 zero-padded Gaussian pre-blur done
-// by nm_convolve_f32), same two-phase step (batched detect+describe calls over a few streams, then batched match calls). Prints the keypoint counts of the first pair (12223 / 12080 for seeds 0 / 1 at 1080p, as everywhere else) and
-// the throughput.
+// by nm_convolve_f32), same two-phase step (batched detect+describe calls over a few streams, then batched DEVICE-SIZED
+// match calls: the matcher reads the keypoint counts the frame driver left on the device, nothing comes back to the host
+// inside the loop). Prints the keypoint counts of the first pair (12223 / 12080 for seeds 0 / 1 at 1080p, as everywhere
+// else), read back AFTER the timed loop, and the throughput.
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 -Iinclude examples/pairs_native.cpp -Lniftymatch_amd/lib -lnm_hip \
 //         -Wl,-rpath,$PWD/niftymatch_amd/lib -o pairs_native && ./pairs_native [pairs=32] [batch=16] [steps=10] [WxH]
 #include <hip/hip_runtime.h>
@@ -75,7 +77,7 @@ int main(int argc, char **argv)
     }
     const int MB = P < NM_SIFT_MATCH_MAX_BATCH ? P : NM_SIFT_MATCH_MAX_BATCH;     // pairs per batched match call
     void *ws;
-    CHECK(hipMalloc(&ws, (size_t)MB * nm_sift_match_workspace_bytes(CAP, CAP)));
+    CHECK(hipMalloc(&ws, nm_sift_match_batch_dev_workspace_bytes(MB, CAP, CAP)));
     std::vector<int *> result(P);
     for (int i = 0; i < P; ++i) CHECK(hipMalloc(&result[i], CAP * 4));
     hipStream_t st[S], ms;
@@ -93,11 +95,6 @@ int main(int argc, char **argv)
                                                 &cnt[c * B], st[c % S]));
         }
     };
-    detect();
-    CHECK(hipDeviceSynchronize());
-    std::vector<int> n(F);
-    for (int f = 0; f < F; ++f) CHECK(hipMemcpy(&n[f], cnt[f], 4, hipMemcpyDeviceToHost));
-
     auto step = [&]() {
         detect();
         for (int s = 0; s < S; ++s) {
@@ -106,13 +103,14 @@ int main(int argc, char **argv)
         }
         for (int i0 = 0; i0 < P; i0 += MB) {
             const float *a[NM_SIFT_MATCH_MAX_BATCH], *b[NM_SIFT_MATCH_MAX_BATCH];
-            int na[NM_SIFT_MATCH_MAX_BATCH], nb[NM_SIFT_MATCH_MAX_BATCH], *res[NM_SIFT_MATCH_MAX_BATCH];
+            const int *na[NM_SIFT_MATCH_MAX_BATCH], *nb[NM_SIFT_MATCH_MAX_BATCH];
+            int *res[NM_SIFT_MATCH_MAX_BATCH];
             const int m = (P - i0 < MB) ? P - i0 : MB;
             for (int k = 0; k < m; ++k) {
                 const int i = i0 + k;
-                a[k] = desc[2 * i]; b[k] = desc[2 * i + 1]; na[k] = n[2 * i]; nb[k] = n[2 * i + 1]; res[k] = result[i];
+                a[k] = desc[2 * i]; b[k] = desc[2 * i + 1]; na[k] = cnt[2 * i]; nb[k] = cnt[2 * i + 1]; res[k] = result[i];
             }
-            CHECK(nm_sift_match_batch_f32(m, a, na, b, nb, res, 0.8f, ws, ms));
+            CHECK(nm_sift_match_batch_dev_f32(m, a, na, b, nb, CAP, CAP, res, 0.8f, ws, ms));
         }
         CHECK(hipEventRecord(mdone, ms));
         for (int s = 0; s < S; ++s) CHECK(hipStreamWaitEvent(st[s], mdone, 0));   // next step reuses the arenas
@@ -124,6 +122,8 @@ int main(int argc, char **argv)
     CHECK(hipDeviceSynchronize());
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
+    std::vector<int> n(F);
+    for (int f = 0; f < F; ++f) CHECK(hipMemcpy(&n[f], cnt[f], 4, hipMemcpyDeviceToHost));
     std::vector<int> r0(n[0]);
     CHECK(hipMemcpy(r0.data(), result[0], (size_t)n[0] * 4, hipMemcpyDeviceToHost));
     int matched = 0;
