@@ -309,6 +309,18 @@ typedef struct nm_sift_arena nm_sift_arena;
 NM_API int nm_sift_arena_create(int width, int height, int capacity, nm_sift_arena **arena);
 NM_API void nm_sift_arena_destroy(nm_sift_arena *arena);
 NM_API size_t nm_sift_arena_bytes(const nm_sift_arena *arena);
+/* The reference's run-time knobs for the calls that follow on this arena. SiftParams::_peak_threshold and
+ * _edge_threshold are public fields a client sets between frames (sift/siftparams.h:97-98; read per call by
+ * compute_keypoints, sift/siftfunctions.cu:123-125): defaults 0 and 10. edge_threshold must be > 0. All arenas of one
+ * batched call must hold the same pair. Host-side setters (no stream operation): they take effect for the calls ENQUEUED
+ * afterwards; a HIP graph captured earlier keeps the values it was captured with.                                 */
+NM_API int nm_sift_arena_set_params(nm_sift_arena *arena, float peak_threshold, float edge_threshold);
+NM_API int nm_sift_arena_get_params(const nm_sift_arena *arena, float *peak_threshold, float *edge_threshold);
+/* compute_keypoints_with_mask (sift/siftfunctions.cu:65-98, kernels/keypoint.cu:204-224): detection only where the
+ * full-resolution mask, fetched with the reference's bilinear border texture at ((x+0.5) xper, (y+0.5) xper), is >= 1.
+ * mask: caller-owned DEVICE plane of exactly the arena's width x height floats, read by every later call until it is
+ * replaced; NULL removes it. Per arena: the frames of a batched call may have different masks or none.               */
+NM_API int nm_sift_arena_set_mask(nm_sift_arena *arena, const float *mask, int mask_width, int mask_height);
 /* gray: width*height fp32 on the device. Outputs on the device: desc capacity x 128, x,y capacity (full-resolution
  * coordinates, descriptor.cu:75-77), d_num_items = number of descriptors written (<= capacity,
  * siftfunctions.cu:165-169). kpts (capacity float4) and orients (capacity float2) are optional (NULL).        */

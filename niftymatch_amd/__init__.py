@@ -81,6 +81,9 @@ _SIGNATURES = {
     "nm_sift_arena_create": (_I, [_I, _I, _I, _P]),
     "nm_sift_arena_destroy": (None, [_P]),
     "nm_sift_arena_bytes": (_SZ, [_P]),
+    "nm_sift_arena_set_params": (_I, [_P, _F, _F]),
+    "nm_sift_arena_get_params": (_I, [_P, _P, _P]),
+    "nm_sift_arena_set_mask": (_I, [_P, _P, _I, _I]),
     "nm_sift_detect_describe": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nm_sift_detect_describe_batch": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nm_sift_scale_space_batch": (_I, [_P, _I, _P, _P]),
@@ -649,6 +652,20 @@ class SiftArena:
         _check(lib().nm_sift_detect_describe(self._h, _dev(gray, torch.float32), _dev(self.desc), _dev(self.x),
                                              _dev(self.y), _dev(self.kpts), _dev(self.orients), _dev(self.num_items),
                                              _stream()), "nm_sift_detect_describe")
+
+    def set_params(self, peak_threshold=0.0, edge_threshold=10.0):
+        """SiftParams::_peak_threshold / _edge_threshold for the calls enqueued from now on."""
+        _check(lib().nm_sift_arena_set_params(self._h, peak_threshold, edge_threshold), "nm_sift_arena_set_params")
+
+    def set_mask(self, mask=None):
+        """Full-resolution float32 device mask (height, width) as in compute_keypoints_with_mask, or None. The arena
+        keeps a reference to the tensor."""
+        torch = _torch()
+        if mask is not None and (tuple(mask.shape) != (self.height, self.width) or mask.device != self.device):
+            raise NmError("mask must be a (%d, %d) tensor on %s" % (self.height, self.width, self.device))
+        self._mask = mask
+        _check(lib().nm_sift_arena_set_mask(self._h, _dev(mask, torch.float32) if mask is not None else None,
+                                            self.width, self.height), "nm_sift_arena_set_mask")
 
     def octave_pyramid(self, ow, oh):
         _check(lib().nm_sift_octave_pyramid(self._h, ow, oh, _stream()), "nm_sift_octave_pyramid")

@@ -45,6 +45,7 @@ struct nm_sift_arena {
     int *counts, *offsets; int max_blocks;
     NmFrameBook *book;
     float *kpts, *orients;     // internal lists used when the caller passes NULL
+    const float *mask;         // nm_sift_arena_set_mask: caller-owned full-resolution plane (width x height) or NULL
 
     template <typename T>
     int alloc(T **p, size_t n)
@@ -121,6 +122,7 @@ int nm_sift_arena_create(int width, int height, int capacity, nm_sift_arena **ou
     if (!a) return (int)hipErrorOutOfMemory;
     a->width = width; a->height = height; a->capacity = capacity;
     a->side = nullptr; a->ev_join = nullptr;
+    a->mask = nullptr;
     a->device = -1;
     (void)hipGetDevice(&a->device);
     for (int o = 0; o < 20; ++o) a->ev_pyr[o] = nullptr;
@@ -179,6 +181,32 @@ void nm_sift_arena_destroy(nm_sift_arena *a)
 }
 
 size_t nm_sift_arena_bytes(const nm_sift_arena *a) { return a ? a->bytes : 0; }
+
+// The reference's run-time knobs on the frame driver: SiftParams::_peak_threshold / _edge_threshold are public fields read
+// per compute_keypoints call (sift/siftparams.h:97-98, siftfunctions.cu:123-125); compute_keypoints_with_mask
+// (siftfunctions.cu:65-98) restricts detection to where the full-resolution mask's bilinear fetch is >= 1 (keypoint.cu:214).
+int nm_sift_arena_set_params(nm_sift_arena *a, float peak_threshold, float edge_threshold)
+{
+    if (!a || !(edge_threshold > 0.f) || peak_threshold != peak_threshold) return (int)hipErrorInvalidValue;
+    a->params._peak_threshold = peak_threshold;
+    a->params._edge_threshold = edge_threshold;
+    return 0;
+}
+
+int nm_sift_arena_get_params(const nm_sift_arena *a, float *peak_threshold, float *edge_threshold)
+{
+    if (!a) return (int)hipErrorInvalidValue;
+    if (peak_threshold) *peak_threshold = a->params._peak_threshold;
+    if (edge_threshold) *edge_threshold = a->params._edge_threshold;
+    return 0;
+}
+
+int nm_sift_arena_set_mask(nm_sift_arena *a, const float *mask, int mask_width, int mask_height)
+{
+    if (!a || (mask && (mask_width != a->width || mask_height != a->height))) return (int)hipErrorInvalidValue;
+    a->mask = mask;
+    return 0;
+}
 float *nm_sift_arena_level(nm_sift_arena *a, int l) { return (a && l >= 0 && l < 6) ? a->level[l] : nullptr; }
 float *nm_sift_arena_dog(nm_sift_arena *a, int d) { return (a && d >= 0 && d < 5) ? a->dog[0][d] : nullptr; }
 float *nm_sift_arena_grad(nm_sift_arena *a) { return a ? a->grad[0] : nullptr; }
@@ -242,6 +270,10 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
         if (!as[f] || !gray[f] || !desc[f] || !x[f] || !y[f]) return (int)hipErrorInvalidValue;
         if (as[f]->width != as[0]->width || as[f]->height != as[0]->height || as[f]->capacity != as[0]->capacity)
             return (int)hipErrorInvalidValue;
+        // one set of thresholds per call (they are launch arguments); masks are per frame
+        if (as[f]->params._peak_threshold != as[0]->params._peak_threshold ||
+            as[f]->params._edge_threshold != as[0]->params._edge_threshold)
+            return (int)hipErrorInvalidValue;
         for (int g = 0; g < f; ++g)
             if (as[g] == as[f]) return (int)hipErrorInvalidValue;
     }
@@ -291,6 +323,7 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
             d.sigma0 = P._sigma_0; d.num_dogs = P._num_dog_levels; d.stage_stride = as[0]->stage_stride;
             d.n_blocks = n_blocks; d.nseg = nseg;
             d.from_levels = dogs ? 0 : 1;
+            d.mask_w = W; d.mask_h = H;
             s.n_blocks = n_blocks; s.octave = o;
             g.stage_stride = as[0]->stage_stride; g.n_blocks = n_blocks; g.octave = o;
             s.capacity = as[0]->capacity; g.capacity = as[0]->capacity;
@@ -299,6 +332,7 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
                 for (int i = 0; i < 5; ++i) d.dog[f][i] = a->dog[o][i];
                 for (int i = 0; i < 6; ++i) d.lev[f][i] = a->lev[o][i];
                 d.staging[f] = a->staging; d.counts[f] = a->counts;
+                d.masks[f] = a->mask; d.any_mask |= a->mask ? 1 : 0;
                 s.counts[f] = a->counts; s.offsets[f] = a->offsets; s.book[f] = a->book;
                 s.d_num_items[f] = d_num_items ? d_num_items[f] : nullptr;
                 g.staging[f] = a->staging; g.counts[f] = a->counts; g.offsets[f] = a->offsets; g.book[f] = a->book;

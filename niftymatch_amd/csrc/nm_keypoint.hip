@@ -291,7 +291,7 @@ constexpr int DET_ROWS = 5;      // image rows per workgroup: 7 rows are loaded 
                                  // 5 DoG planes; reading 6 level planes, 5 rows are 0.6-0.7 % of the headline better (same box,
                                  // three alternating runs); the 12 sub-lists per row must fit the 64-lane scan: <= 5
 
-template <bool DENSE, bool LEV = false>
+template <bool DENSE, bool LEV = false, bool MASKED = DENSE>
 __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
 {
     __shared__ unsigned char s_x[DET_ROWS][3][4][64];    // candidate lanes per (row, level, wave), in lane order
@@ -309,6 +309,7 @@ __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
     const int xe = (lane == 0) ? max(xc - 1, 0) : min(xc + 1, ow - 1);
     const bool edge_lane = (lane == 0) || (lane == 63);
     const float thr = 0.8f * a.peak;
+    const float *const mask = MASKED ? (DENSE ? a.mask : a.masks[frame]) : nullptr;
 
     // sliding 3-row window per plane: row maxima/minima of (left, mid, right); centre row keeps mid and max/min(l, r).
     // Rows are FETCHED one iteration ahead of being absorbed into the window (raw values wait in registers), so the
@@ -364,8 +365,8 @@ __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
         if (j + 1 < DET_ROWS) fetch_row(y + 2, (j + 1) & 1);
         absorb_row(j & 1, s_dn, j & 1);
         bool interior = xin && x >= 1 && x <= ow - 2 && y >= 1 && y <= oh - 2;
-        if (DENSE && a.mask && interior)     // masked detection: the bilinear border fetch of the full-resolution mask must be 1
-            interior = mask_fetch(a.mask, a.mask_w, a.mask_h, ((float)x + 0.5f) * a.xper, ((float)y + 0.5f) * a.xper) >= 1.f;
+        if (MASKED && mask && interior)      // masked detection: the bilinear border fetch of the full-resolution mask must be 1
+            interior = mask_fetch(mask, a.mask_w, a.mask_h, ((float)x + 0.5f) * a.xper, ((float)y + 0.5f) * a.xper) >= 1.f;
         float m9[5], n9[5], m8[5], n8[5];
 #pragma unroll
         for (int p = 0; p < 5; ++p) {
@@ -525,10 +526,11 @@ __global__ __launch_bounds__(256) void gather_stage_kernel(NmGatherArgs a)
 int nm_launch_detect_octave(const NmDetectArgs &d, const NmScanArgs &s, const NmGatherArgs &g, hipStream_t stream)
 {
     if (d.n_blocks <= 0 || d.n <= 0) return 0;
-    if (d.from_levels)
-        hipLaunchKernelGGL((detect_stage_kernel<false, true>), dim3(d.nseg * nm_divup(d.oh, DET_ROWS), d.n), dim3(256), 0, stream, d);
-    else
-        hipLaunchKernelGGL((detect_stage_kernel<false, false>), dim3(d.nseg * nm_divup(d.oh, DET_ROWS), d.n), dim3(256), 0, stream, d);
+    const dim3 grid(d.nseg * nm_divup(d.oh, DET_ROWS), d.n);
+    if (d.from_levels && d.any_mask) hipLaunchKernelGGL((detect_stage_kernel<false, true, true>), grid, dim3(256), 0, stream, d);
+    else if (d.from_levels) hipLaunchKernelGGL((detect_stage_kernel<false, true, false>), grid, dim3(256), 0, stream, d);
+    else if (d.any_mask) hipLaunchKernelGGL((detect_stage_kernel<false, false, true>), grid, dim3(256), 0, stream, d);
+    else hipLaunchKernelGGL((detect_stage_kernel<false, false, false>), grid, dim3(256), 0, stream, d);
     NM_LAUNCH_CHECK();
     hipLaunchKernelGGL(scan_book_kernel, dim3(s.n), dim3(1024), 0, stream, s);
     NM_LAUNCH_CHECK();

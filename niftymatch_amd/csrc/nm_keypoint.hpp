@@ -21,6 +21,9 @@ struct NmDetectArgs {
     float *dense[3];
     const float *mask;
     int mask_w, mask_h;
+    // frame driver (nm_sift_arena_set_mask): optional full-resolution mask per frame, mask_w x mask_h as above
+    const float *masks[NM_MAX_BATCH];
+    int any_mask;
 };
 
 struct NmScanArgs {

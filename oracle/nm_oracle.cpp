@@ -515,11 +515,29 @@ NMO_API void nmo_sift_matches(const float *A, int nA, const float *B, int nB, fl
  * functions above in the reference's orchestration order (sift/siftfunctions.cu:42-181).
  * Outputs (all optional except desc/x/y): kpts_out = compacted float4 list in output order, orient_out = float2.
  * Returns the number of descriptors written (<= capacity, Q13).                                             */
+/* The same client loop with the reference's run-time knobs: SiftParams::_peak_threshold / _edge_threshold are public
+ * fields passed per call (sift/siftparams.h:97-98, siftfunctions.cu:123-125), and compute_keypoints_with_mask
+ * (siftfunctions.cu:65-98) takes a full-resolution mask texture sampled at ((x+0.5) xper, (y+0.5) xper)
+ * (keypoint.cu:204-224). mask: width x height floats or NULL.                                                 */
+NMO_API int nmo_sift_detect_describe_ex(const float *gray, int width, int height, int capacity, float peak_threshold,
+                                        float edge_threshold, const float *mask, float *desc, float *xs, float *ys,
+                                        float *kpts_out, float *orient_out, int *counts_out);
+
 NMO_API int nmo_sift_detect_describe(const float *gray, int width, int height, int capacity, float *desc,
                                      float *xs, float *ys, float *kpts_out, float *orient_out,
                                      int *counts_out /* [num_octaves*3] accepted per (octave, level) or NULL */)
 {
     nmo_params P; nmo_sift_params(width, height, &P);
+    return nmo_sift_detect_describe_ex(gray, width, height, capacity, P.peak_threshold, P.edge_threshold, nullptr, desc, xs,
+                                       ys, kpts_out, orient_out, counts_out);
+}
+
+NMO_API int nmo_sift_detect_describe_ex(const float *gray, int width, int height, int capacity, float peak_threshold,
+                                        float edge_threshold, const float *mask, float *desc, float *xs, float *ys,
+                                        float *kpts_out, float *orient_out, int *counts_out)
+{
+    nmo_params P; nmo_sift_params(width, height, &P);
+    P.peak_threshold = peak_threshold; P.edge_threshold = edge_threshold;
     const size_t npix = (size_t)width * height;
     const int nlev = P.level_max - P.level_min + 1;          /* 6 (pyramidata.cu:28) */
     const int ndog = P.level_max - P.level_min;              /* 5 */
@@ -547,7 +565,7 @@ NMO_API int nmo_sift_detect_describe(const float *gray, int width, int height, i
         int cnt[3] = {0, 0, 0};
         for (int i = 1; i < ndog - 1; ++i) {
             for (size_t k = 0; k < 4 * npix; ++k) keymap[k] = -1.0f;
-            nmo_find_keypoints(dog[i].data(), dog[i - 1].data(), dog[i + 1].data(), nullptr, 0, 0, ow, oh,
+            nmo_find_keypoints(dog[i].data(), dog[i - 1].data(), dog[i + 1].data(), mask, width, height, ow, oh,
                                P.peak_threshold, P.edge_threshold, xper, P.sigma_0, P.num_dog_levels, i - 1,
                                keymap.data());
             coll[i - 1].assign(4 * (size_t)ow * oh, -1.f);

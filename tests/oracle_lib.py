@@ -177,10 +177,14 @@ def sift_matches(A, B, ambiguity=0.8, want_distance=True, prior=None):
     return res, D, (m1, ix, m2)
 
 
-def sift_detect_describe(gray, capacity=16384):
+def sift_detect_describe(gray, capacity=16384, peak=None, edge=None, mask=None):
+    """peak / edge: SiftParams::_peak_threshold / _edge_threshold (defaults 0 / 10); mask: full-resolution float plane."""
     gray = _f32(gray)
     h, w = gray.shape
     p = sift_params(w, h)
+    if peak is not None or edge is not None or mask is not None:
+        return _sift_detect_describe_ex(gray, capacity, p.peak_threshold if peak is None else peak,
+                                        p.edge_threshold if edge is None else edge, mask, p)
     desc = np.zeros((capacity, 128), np.float32)
     xs = np.zeros(capacity, np.float32)
     ys = np.zeros(capacity, np.float32)
@@ -191,6 +195,22 @@ def sift_detect_describe(gray, capacity=16384):
                                        _fp(ys), _fp(kp), _fp(ori), _fp(counts))
     return dict(n=n, desc=desc[:n], x=xs[:n], y=ys[:n], kpts=kp[:n], orient=ori[:n],
                 counts=counts.reshape(-1, 3))
+
+
+def _sift_detect_describe_ex(gray, capacity, peak, edge, mask, p):
+    h, w = gray.shape
+    desc = np.zeros((capacity, 128), np.float32)
+    xs = np.zeros(capacity, np.float32)
+    ys = np.zeros(capacity, np.float32)
+    kp = np.zeros((capacity, 4), np.float32)
+    ori = np.zeros((capacity, 2), np.float32)
+    counts = np.zeros(p.num_octaves * 3, np.int32)
+    m = None if mask is None else _f32(mask)
+    assert m is None or m.shape == (h, w)
+    n = lib().nmo_sift_detect_describe_ex(_fp(gray), C.c_int(w), C.c_int(h), C.c_int(capacity), C.c_float(peak),
+                                          C.c_float(edge), _fp(m), _fp(desc), _fp(xs), _fp(ys), _fp(kp), _fp(ori),
+                                          _fp(counts))
+    return dict(n=n, desc=desc[:n], x=xs[:n], y=ys[:n], kpts=kp[:n], orient=ori[:n], counts=counts.reshape(-1, 3))
 
 
 def octave_pyramid(level0, width, height, want_grad=True):
