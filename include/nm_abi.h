@@ -168,7 +168,15 @@ NM_API int nm_get_sift_matches_f32(const float *distance, int rows, int cols, in
  * A: nA x 128, B: nB x 128 row-major. Fused MFMA path; `distance` (nA x nB) is optional (NULL = do not
  * materialise; extension). result[i] in {-1, 0..nB-1}, left untouched when the second-best distance is <= 0
  * (match.cu:107-116). Match decisions are made on distances recomputed exactly in the reference's summation
- * order; rows whose best two cannot be proven from the MFMA pass are re-scanned exactly. workspace: nm_sift_match_workspace_bytes(nA, nB) bytes of device scratch.                            */
+ * order; rows whose best two cannot be proven from the MFMA pass are re-scanned exactly. workspace:
+ * nm_sift_match_workspace_bytes(nA, nB) bytes of device scratch.
+ * Domain: ANY float input gives the reference scan's answer. The MFMA screens themselves work on descriptors whose
+ * squared norms are finite and below 1e37; a query row outside that, and every row of a call in which ANY candidate is
+ * outside it (NaN, +-inf, huge), is matched by the exact fallback alone, i.e. by the scan of match.cu:88-116 with its
+ * behaviour on such values: a NaN distance to candidate 0 stays the row's minimum for good (the row becomes -1), a NaN
+ * distance to any other candidate is skipped (`current < x` is false), and min2 is exact also above 2139095040 -- the scan
+ * overwrites it with the old minimum at every replacement (:97), so its initial value 2139095040.0f only bounds a row whose
+ * minimum sits at candidate 0. Such calls are correct, not fast (one exact 128-D distance per pair of rows).        */
 NM_API size_t nm_sift_match_workspace_bytes(int nA, int nB);
 /* Which MFMA screen the fused matcher runs before its exact finalize (process-wide; results are identical):
  * 0 = fp32 (v_mfma_f32_32x32x2_f32 on the descriptors themselves), 1 = bf16x3 (v_mfma_f32_32x32x16_bf16 on operands
@@ -214,9 +222,14 @@ NM_API int nm_sift_match_f32(const float *A, int nA, const float *B, int nB, flo
  * the exact full-scan fallback because the MFMA candidate pass could not prove its top-2. Synchronises the stream. */
 NM_API int nm_sift_match_fallback_count(const void *workspace, int nA, int nB, int *host_count, void *stream);
 /* Multi-GPU building blocks (no reference counterpart: the reference is single-GPU). A shard call scans the local
- * rows [0,nB_shard) of B and emits, per query row, the exact (min1, index1 + index_offset, min2) of that shard
- * with the scan semantics of match.cu:91-105. The merge combines n_shards such triples per row, given shard-major
- * (n_shards x nA), in ascending shard order so that the lowest global index wins ties, and applies the ratio test. */
+ * rows [0,nB_shard) of B and emits, per query row: min1 = the smallest non-NaN distance of the shard, index1 +
+ * index_offset = its lowest index (-1 if the shard has no distance below +inf), min2 = the smallest of the shard's OTHER
+ * non-NaN distances, +inf if there is none -- NOT clamped to the scan's initial 2139095040.0f, which only bounds a row
+ * whose minimum sits at global candidate 0 (match.cu:91,97) and is applied by the merge. The shard that holds global
+ * candidate 0 (index_offset == 0) reports (NaN, 0, smallest other) for a row whose distance to that candidate is NaN, as
+ * the scan keeps it. The merge combines n_shards such triples per row, given shard-major (n_shards x nA), in ascending
+ * shard order so that the lowest global index wins ties, and applies the clamp and the ratio test: the result equals
+ * the single-GPU scan for every input. */
 NM_API int nm_sift_match_shard_f32(const float *A, int nA, const float *B_shard, int nB_shard, int index_offset,
                                    float *min1, int *idx1, float *min2, void *workspace, void *stream);
 NM_API int nm_sift_match_merge_f32(const float *min1, const int *idx1, const float *min2, int n_shards, int nA,

@@ -34,6 +34,10 @@ constexpr int TILE_C = 128;        // candidates per LDS tile
 constexpr int QB = 256;            // queries per workgroup (32 per wave, fragments resident in VGPRs)
 constexpr float MIN2_INIT = 2139095040.0f;   // (float)0x7f800000, match.cu:91
 constexpr int MAX_CHUNKS = 64;     // upper bound of the number S of segments (partial lists) per query block of any plan
+// Domain of the MFMA screens: descriptors whose squared norms are finite and below NORM_LIMIT (every distance is then finite,
+// <= 4e37). A query row outside it, or ANY candidate outside it, is matched by the exact fallback alone -- the reference's
+// scan, whose behaviour on NaN / inf distances (match.cu:91-116: comparisons with a NaN are false) is reproduced there.
+constexpr float NORM_LIMIT = 1.0e37f;
 
 // Work = qblocks x T units, a unit being (256 queries) x (one 128-candidate tile). The grid is G persistent workgroups
 // (one per CU: the kernel owns the LDS), each taking a contiguous range of `base` or `base+1` units of a linear order:
@@ -336,8 +340,10 @@ __global__ __launch_bounds__(1024) void nbmax_kernel(MatchBatch bt)
         });
         if (lane == 0) *c.d_plan = p;
     }
+    // +inf as soon as one candidate norm is not a finite number below NORM_LIMIT (fmax would drop a NaN): the finalize
+    // pass then sends EVERY row of the pair to the exact fallback, which is the reference's own scan
     float m = 0.f;
-    for (int i = threadIdx.x; i < nB; i += 1024) m = __builtin_fmaxf(m, c.nb[i]);
+    for (int i = threadIdx.x; i < nB; i += 1024) { const float v = c.nb[i]; m = (v < NORM_LIMIT) ? __builtin_fmaxf(m, v) : __builtin_inff(); }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, d));
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
@@ -803,13 +809,20 @@ __device__ __forceinline__ float exact_dist(const float4 *__restrict__ a, const 
     return acc;
 }
 
-// Scan semantics of match.cu:91-116 on an exact (min1, idx, min2) triple. mode 0: ratio test -> result[i] (untouched when
-// min2 <= 0); mode 1: emit the shard triple with the global index.
-__device__ __forceinline__ void emit_match(int i, float m1, int idx, float m2, int mode, int index_offset, float ambiguity,
+// Last step of the reference's scan (match.cu:91-116), given what the scan's comparisons make of a row: m1 = its smallest
+// non-NaN distance at the LOWEST index idx (or NaN with idx 0 when the distance to candidate 0 is NaN: `current < NaN` is
+// false for good), m2 = the smallest of the OTHER non-NaN distances, +inf when there is none. The scan starts min_2 at
+// 2139095040.0f (the int 0x7f800000 converted, not +inf) and OVERWRITES it with the old minimum at every replacement
+// (:97), so that initial value survives only while the minimum sits at candidate 0: clamp iff idx == 0 (idx < 0: the row
+// has no distance below +inf at all; its ratio test fails either way).
+// mode 0: ratio test -> result[i] (untouched when min2 <= 0); mode 1: emit the shard triple, min2 UNCLAMPED -- the merge
+// over the shards applies the clamp, on the global index (idx here is already global).
+__device__ __forceinline__ void emit_match(int i, float m1, int idx, float m2, int mode, float ambiguity,
                                            int *__restrict__ result, float *__restrict__ min1_out,
                                            int *__restrict__ idx_out, float *__restrict__ min2_out)
 {
-    if (mode == 1) { min1_out[i] = m1; idx_out[i] = idx + index_offset; min2_out[i] = m2; return; }
+    if (mode == 1) { min1_out[i] = m1; idx_out[i] = idx; min2_out[i] = m2; return; }
+    if (idx <= 0 && MIN2_INIT < m2) m2 = MIN2_INIT;
     if (m2 > 0) {
         const float q = m1 / m2;
         result[i] = (q < ambiguity) ? idx : -1;
@@ -880,15 +893,21 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(MatchBatch bt)
 #pragma unroll
     for (int k = 0; k < 4; ++k) { ed[k] = __shfl(d, ((threadIdx.x & 63) & ~3) + k); ei[k] = ci[k]; }
     if (!live || sub != 0) return;
-    float m1 = 0.f, m2 = MIN2_INIT; int idx = 0; bool have = false;
+    const float nai = na[i];
+    if (!(nai < NORM_LIMIT) || !(*c.nbmax < NORM_LIMIT)) {           // outside the screens' domain (NaN, inf, huge): exact scan
+        const int pos = atomicAdd(fb_count, 1);
+        fb_list[pos] = i;
+        return;
+    }
+    // exact minimum at the lowest index and second smallest of the recomputed candidates (+inf: there is no second)
+    float m1 = __builtin_inff(), m2 = __builtin_inff(); int idx = 0x7fffffff;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (ei[k] < 0) continue;
-        if (!have) { m1 = ed[k]; idx = ei[k]; have = true; }
-        else if (ed[k] < m1 || (ed[k] == m1 && ei[k] < idx)) { m2 = m1; m1 = ed[k]; idx = ei[k]; }
+        if (ed[k] < m1 || (ed[k] == m1 && ei[k] < idx)) { m2 = m1; m1 = ed[k]; idx = ei[k]; }
         else if (ed[k] < m2) m2 = ed[k];
     }
-    if (!have) return;
+    if (idx == 0x7fffffff) return;
     // Proof obligation ("matcher theorem"): every candidate j that was NOT recomputed must have a
     // reference distance d_ref(j) > m2. With u = 2^-24, gamma_n = n u / (1 - n u):
     //   * the MFMA value is a 130-step fma chain nb^ + na^ - 2 sum a_k b_k with 129 roundings, products exact:
@@ -902,7 +921,6 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(MatchBatch bt)
     // sqrt na + sqrt nb_max):  value(j) <= (M + 2 gamma_129 s^2) (1 + 2^-18) =: bound, and rest <= value(j) <= bound.
     // Hence rest > bound proves the row; otherwise the row is re-scanned exactly. Deterministic for every input
     // (2 gamma_129 = 1.5378e-5; the constants below carry the slop of evaluating the bound itself in fp32).
-    const float nai = na[i];
     const float sq = __builtin_fminf(2.0f * __builtin_sqrtf(nai) + __builtin_sqrtf(m2),
                                      __builtin_sqrtf(nai) + __builtin_sqrtf(*c.nbmax));
     const float bound = (m2 * 1.00001f + bt.err_coeff * (sq * sq)) * 1.00001f + 1e-30f;      // 1 + 2^-17 = 1.0000076
@@ -913,7 +931,7 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(MatchBatch bt)
         fb_list[pos] = i;
         return;
     }
-    emit_match(i, m1, idx, m2, mode, index_offset, ambiguity, result, min1_out, idx_out, min2_out);
+    emit_match(i, m1, idx + index_offset, m2, mode, ambiguity, result, min1_out, idx_out, min2_out);
 }
 
 // Exact squared distances, the reference's own arithmetic (match.cu:36-42): for every (row vector x, column vector y)
@@ -1131,14 +1149,22 @@ __global__ __launch_bounds__(256) void match_fallback_merge_kernel(MatchBatch bt
     float *__restrict__ min1_out = c.min1, *__restrict__ min2_out = c.min2;
     int *__restrict__ idx_out = c.idx1;
     const int count = *fb_count;
+    const bool holds0 = (mode == 0) || (index_offset == 0);      // this call's candidate 0 is the scan's candidate 0
     for (int e = blockIdx.x * 256 + threadIdx.x; e < count; e += gridDim.x * 256) {
+        // the slices left NaN distances out and never record +inf (strict < from +inf): the scan's view of candidates >= 1
         float m1 = __builtin_inff(), m2 = __builtin_inff(); int i1 = 0x7fffffff;
         for (int sl = 0; sl < FB_SPLIT; ++sl) {
             const float4 p = part[(size_t)e * FB_SPLIT + sl];
             top2_merge(m1, i1, m2, p.x, __float_as_int(p.y), p.z);
         }
-        if (MIN2_INIT < m2) m2 = MIN2_INIT;
-        emit_match(fb_list[e], m1, i1, m2, mode, index_offset, ambiguity, result, min1_out, idx_out, min2_out);
+        const int row = fb_list[e];
+        int idx = (i1 == 0x7fffffff) ? (holds0 ? 0 : -1) : i1 + index_offset;
+        if (holds0) {
+            // match.cu:90: the scan STARTS from the distance to candidate 0; a NaN there is never replaced
+            const float d0 = exact_dist(reinterpret_cast<const float4 *>(c.A + (size_t)row * DIM), reinterpret_cast<const float4 *>(c.B));
+            if (d0 != d0) { m2 = m1; m1 = d0; idx = 0; }
+        }
+        emit_match(row, m1, idx, m2, mode, ambiguity, result, min1_out, idx_out, min2_out);
     }
 }
 
@@ -1149,17 +1175,17 @@ __global__ __launch_bounds__(256) void match_merge_kernel(const float *__restric
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nA) return;
-    float m1 = min1[i], m2 = min2[i]; int idx = idx1[i];
-    for (int g = 1; g < n_shards; ++g) {
+    float m1 = __builtin_inff(), m2 = __builtin_inff(); int idx = -1;             // the neutral (empty shard) triple
+    for (int g = 0; g < n_shards; ++g) {
         const float a1 = min1[(size_t)g * nA + i], a2 = min2[(size_t)g * nA + i];
         const int ai = idx1[(size_t)g * nA + i];
-        if (a1 < m1) { m2 = (m1 < a2) ? m1 : a2; m1 = a1; idx = ai; }
-        else { const float c = (a1 < m2) ? a1 : m2; m2 = c; }
+        // a NaN minimum can only come from the shard holding global candidate 0 (every shard before it is empty): it is
+        // the scan's min_1_distance for good (match.cu:90,96)
+        if (a1 != a1) { m1 = a1; idx = 0; m2 = a2; }
+        else if (a1 < m1) { m2 = (m1 < a2) ? m1 : a2; m1 = a1; idx = ai; }
+        else if (a1 < m2) m2 = a1;
     }
-    if (m2 > 0) {
-        const float q = m1 / m2;
-        result[i] = (q < ambiguity) ? idx : -1;
-    }
+    emit_match(i, m1, idx, m2, 0, ambiguity, result, nullptr, nullptr, nullptr);     // clamps iff the minimum sits at 0
 }
 
 // An empty candidate shard (world > nB, or uneven tiny sets): the neutral triple, so that the merge ignores the shard.
@@ -1168,7 +1194,7 @@ __global__ __launch_bounds__(256) void shard_neutral_kernel(float *__restrict__ 
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nA) return;
-    min1[i] = __builtin_inff(); idx1[i] = -1; min2[i] = MIN2_INIT;
+    min1[i] = __builtin_inff(); idx1[i] = -1; min2[i] = __builtin_inff();
 }
 
 // The same merge on the buffer an all-gather of per-rank (min1[nA], idx1[nA], min2[nA]) blocks produces: element c of row i
@@ -1178,19 +1204,16 @@ __global__ __launch_bounds__(256) void match_merge_packed_kernel(const int *__re
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nA) return;
-    float m1 = __int_as_float(packed[i]), m2 = __int_as_float(packed[2 * (size_t)nA + i]);
-    int idx = packed[(size_t)nA + i];
-    for (int g = 1; g < n_shards; ++g) {
+    float m1 = __builtin_inff(), m2 = __builtin_inff(); int idx = -1;
+    for (int g = 0; g < n_shards; ++g) {
         const int *p = packed + (size_t)g * 3 * nA;
         const float a1 = __int_as_float(p[i]), a2 = __int_as_float(p[2 * (size_t)nA + i]);
         const int ai = p[(size_t)nA + i];
-        if (a1 < m1) { m2 = (m1 < a2) ? m1 : a2; m1 = a1; idx = ai; }
-        else { const float c = (a1 < m2) ? a1 : m2; m2 = c; }
+        if (a1 != a1) { m1 = a1; idx = 0; m2 = a2; }
+        else if (a1 < m1) { m2 = (m1 < a2) ? m1 : a2; m1 = a1; idx = ai; }
+        else if (a1 < m2) m2 = a1;
     }
-    if (m2 > 0) {
-        const float q = m1 / m2;
-        result[i] = (q < ambiguity) ? idx : -1;
-    }
+    emit_match(i, m1, idx, m2, 0, ambiguity, result, nullptr, nullptr, nullptr);
 }
 
 // ---- exact API building blocks ----
@@ -1292,11 +1315,11 @@ __global__ __launch_bounds__(256) void set_matches_kernel(int *__restrict__ resu
         m2 = (hi < s2) ? hi : s2;                                     // the loser's own second is >= hi
     }
     if (lane == 0) {
-        if (MIN2_INIT < m2) m2 = MIN2_INIT;                           // the scan starts min2 at 2139095040.0f
-        if (m2 > 0) {
-            const float q = m1 / m2;
-            result[row] = (q < ambiguity) ? i1 : -1;
-        }
+        // (m1, i1, m2): what the scan's comparisons see -- NaN entries left out, +inf never recorded (strict < from +inf)
+        int idx = (i1 == 0x7fffffff) ? 0 : i1;
+        const float d0 = d[0];                                        // match.cu:90: a NaN at column 0 is never replaced
+        if (d0 != d0) { m2 = m1; m1 = d0; idx = 0; }
+        emit_match(row, m1, idx, m2, 0, ambiguity, result, nullptr, nullptr, nullptr);
     }
 }
 

@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <limits>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -505,6 +506,66 @@ NMO_API void nmo_sift_matches(const float *A, int nA, const float *B, int nB, fl
         if (min2_out) min2_out[i] = min2;
         if (min2 > 0) {
             const float a = min1 / min2;
+            result[i] = (a < ambiguity) ? idx : -1;
+        }
+    }
+}
+
+/* Multi-GPU building blocks (no reference counterpart: the reference is single-GPU). What a rank holding the candidate rows
+ * [index_offset, index_offset + nB) reports per query, such that nmo_sift_match_merge over the shards in ascending order
+ * reproduces the reference's scan over the whole set (match.cu:91-105) for EVERY input, including distances above
+ * 2139095040 and non-finite ones:
+ *   - the scan's comparisons skip a NaN distance at any candidate but the very first (`current < x` is false), while a
+ *     NaN at global candidate 0 stays in min_1_distance for good; so a shard leaves NaN distances out, except that the
+ *     shard holding global candidate 0 (index_offset == 0) reports min1 = NaN, idx = 0 when that distance is NaN;
+ *   - when the scan replaces its minimum it OVERWRITES min_2_distance with the previous minimum (match.cu:97), so for a
+ *     row whose minimum is not at candidate 0 min2 is the true second smallest, also above 2139095040; only a row whose
+ *     minimum sits at candidate 0 keeps the initial 2139095040.0f as an upper bound. A shard therefore reports min2 =
+ *     the smallest of its OTHER non-NaN distances, +inf when there is none, unclamped; the merge applies the clamp.
+ * A shard with no distance below +inf reports (+inf, idx 0 if it holds global candidate 0 else -1, min2 as above).   */
+NMO_API void nmo_sift_match_shard(const float *A, int nA, const float *B, int nB, int index_offset, float *min1_out,
+                                  int *idx_out, float *min2_out)
+{
+    const float inf = std::numeric_limits<float>::infinity();
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < nA; ++i) {
+        float m1 = inf, m2 = inf; int idx = -1;
+        bool first_nan = false;
+        for (int j = 0; j < nB; ++j) {
+            float acc = 0.0f;
+            for (int k = 0; k < 128; ++k) {
+                const float t = A[(size_t)i * 128 + k] - B[(size_t)j * 128 + k];
+                acc = std::fmaf(t, t, acc);
+            }
+            if (j == 0 && index_offset == 0 && acc != acc) first_nan = true;
+            if (acc < m1) { m2 = m1; m1 = acc; idx = j; }        /* strict <: lowest index wins; NaN and +inf fall through */
+            else if (acc < m2) m2 = acc;
+        }
+        if (first_nan) { min1_out[i] = std::numeric_limits<float>::quiet_NaN(); idx_out[i] = 0; min2_out[i] = m1; continue; }
+        min1_out[i] = m1;
+        idx_out[i] = idx >= 0 ? idx + index_offset : (index_offset == 0 && nB > 0 ? 0 : -1);
+        min2_out[i] = m2;
+    }
+}
+
+/* Merge of shard-major (n_shards x nA) triples in ascending shard order, then the ratio test of match.cu:107-116.
+ * A NaN min1 (global candidate 0) survives every comparison, as in the scan. */
+NMO_API void nmo_sift_match_merge(const float *min1, const int *idx1, const float *min2, int n_shards, int nA, int *result,
+                                  float ambiguity)
+{
+    for (int i = 0; i < nA; ++i) {
+        float m1 = std::numeric_limits<float>::infinity(), m2 = m1; int idx = -1;      /* the neutral (empty shard) triple */
+        for (int g = 0; g < n_shards; ++g) {
+            const float a1 = min1[(size_t)g * nA + i], a2 = min2[(size_t)g * nA + i];
+            /* a NaN minimum can only come from the shard holding global candidate 0; every shard before it is empty */
+            if (a1 != a1) { m1 = a1; idx = 0; m2 = a2; }
+            else if (a1 < m1) { m2 = (m1 < a2) ? m1 : a2; m1 = a1; idx = idx1[(size_t)g * nA + i]; }
+            else if (a1 < m2) m2 = a1;
+        }
+        /* the minimum never left candidate 0 (idx -1: no distance below +inf anywhere; the ratio test gives -1 either way) */
+        if (idx <= 0 && (float)0x7f800000 < m2) m2 = (float)0x7f800000;
+        if (m2 > 0) {
+            const float a = m1 / m2;
             result[i] = (a < ambiguity) ? idx : -1;
         }
     }

@@ -177,6 +177,27 @@ def sift_matches(A, B, ambiguity=0.8, want_distance=True, prior=None):
     return res, D, (m1, ix, m2)
 
 
+def sift_match_shard(A, B, index_offset=0):
+    """Per-query (min1, global index, min2) of one candidate shard, min2 unclamped (see nmo_sift_match_shard)."""
+    A, B = _f32(A), _f32(B)
+    na, nb = A.shape[0], B.shape[0]
+    m1 = np.empty(na, np.float32)
+    ix = np.empty(na, np.int32)
+    m2 = np.empty(na, np.float32)
+    lib().nmo_sift_match_shard(_fp(A), C.c_int(na), _fp(B), C.c_int(nb), C.c_int(index_offset), _fp(m1), _fp(ix), _fp(m2))
+    return m1, ix, m2
+
+
+def sift_match_merge(m1_all, ix_all, m2_all, ambiguity=0.8, prior=None):
+    m1_all, m2_all = _f32(m1_all), _f32(m2_all)
+    ix_all = np.ascontiguousarray(ix_all, np.int32)
+    n_shards, na = m1_all.shape
+    res = np.full(na, -1, np.int32) if prior is None else np.ascontiguousarray(prior, np.int32).copy()
+    lib().nmo_sift_match_merge(_fp(m1_all), _fp(ix_all), _fp(m2_all), C.c_int(n_shards), C.c_int(na), _fp(res),
+                               C.c_float(ambiguity))
+    return res
+
+
 def sift_detect_describe(gray, capacity=16384, peak=None, edge=None, mask=None):
     """peak / edge: SiftParams::_peak_threshold / _edge_threshold (defaults 0 / 10); mask: full-resolution float plane."""
     gray = _f32(gray)

@@ -20,7 +20,8 @@ def _free_port():
 
 
 def _cpu_merge(m1_all, ix_all, m2_all, ambiguity, prior):
-    """Reference merge (ascending shard order, strict <) in plain torch."""
+    """Reference merge (ascending shard order, strict <) in plain torch; the scan's initial min2 survives only while the
+    minimum sits at global candidate 0 (match.cu:91,97)."""
     n_shards, nA = m1_all.shape
     res = torch.full((nA,), -1, dtype=torch.int32) if prior is None else prior.clone()
     for i in range(nA):
@@ -31,6 +32,8 @@ def _cpu_merge(m1_all, ix_all, m2_all, ambiguity, prior):
                 m2 = min(m1, a2); m1 = a1; ix = ai
             else:
                 m2 = min(m2, a1)
+        if ix <= 0:
+            m2 = min(m2, float(MIN2_INIT))
         if m2 > 0:
             res[i] = ix if np.float32(m1) / np.float32(m2) < np.float32(ambiguity) else -1
     return res
@@ -48,8 +51,8 @@ def _worker(rank, world, port, q):
     b, e = parallel.block_range(len(B), world, rank)
 
     def shard_fn(Aq, Bs, off):
-        _, _, (m1, ix, m2) = O.sift_matches(Aq.numpy(), Bs.numpy(), 0.8, want_distance=False)
-        return torch.from_numpy(m1), torch.from_numpy(ix + off), torch.from_numpy(m2)
+        m1, ix, m2 = O.sift_match_shard(Aq.numpy(), Bs.numpy(), off)
+        return torch.from_numpy(m1), torch.from_numpy(ix), torch.from_numpy(m2)
 
     # ambiguity 1.5: the duplicated candidate (ratio exactly 1) is reported, so the tie-break is observable
     res = parallel.match_sharded(torch.from_numpy(A), torch.from_numpy(B[b:e].copy()), b, 1.5, shard_fn=shard_fn,
@@ -91,8 +94,8 @@ def test_single_process_path_without_init():
     A = H.synth.descriptors(3, 50); B = H.synth.descriptors(4, 60)
 
     def shard_fn(Aq, Bs, off):
-        _, _, (m1, ix, m2) = O.sift_matches(Aq.numpy(), Bs.numpy(), 0.8, want_distance=False)
-        return torch.from_numpy(m1), torch.from_numpy(ix + off), torch.from_numpy(m2)
+        m1, ix, m2 = O.sift_match_shard(Aq.numpy(), Bs.numpy(), off)
+        return torch.from_numpy(m1), torch.from_numpy(ix), torch.from_numpy(m2)
     res = parallel.match_sharded(torch.from_numpy(A), torch.from_numpy(B), 0, 0.8, shard_fn=shard_fn, merge_fn=_cpu_merge)
     ref, _, _ = O.sift_matches(A, B, 0.8, want_distance=False)
     assert res.numpy().tolist() == ref.tolist()

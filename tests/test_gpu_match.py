@@ -112,7 +112,8 @@ def test_shard_and_merge_equals_unsharded(nm, oracle, cuda):
     A = H.synth.descriptors(1, 1500)
     B = H.synth.descriptors(2, 2100)
     B[100] = B[1900]                                     # cross-shard tie: the lower global index must win
-    ref, _, (m1r, ixr, m2r) = oracle.sift_matches(A, B, 0.8, want_distance=False)
+    ref, _, _ = oracle.sift_matches(A, B, 0.8, want_distance=False)
+    m1r, ixr, m2r = oracle.sift_match_shard(A, B, 0)
     bounds = [0, 700, 1400, 2100]
     m1s, ixs, m2s = [], [], []
     for g in range(3):
@@ -175,11 +176,12 @@ def test_match_random_shapes_sweep(nm, oracle, cuda):
     for na, nb in shapes:
         A = H.synth.descriptors(100 + na, na)
         B = H.synth.descriptors(200 + nb, nb)
-        ref, _, (m1, ix, m2) = oracle.sift_matches(A, B, 0.8, want_distance=False)
+        ref, _, _ = oracle.sift_matches(A, B, 0.8, want_distance=False)
         got, _ = _match(nm, cuda, A, B)
         assert np.array_equal(got, ref), (na, nb)
+        m1, ix, m2 = oracle.sift_match_shard(A, B, 5)        # min2 unclamped: +inf for a one-row shard
         t = nm.sift_match_shard(_t(A, cuda), _t(B, cuda), 5)
-        assert np.array_equal(t[1].cpu().numpy(), ix + 5), (na, nb)
+        assert np.array_equal(t[1].cpu().numpy(), ix), (na, nb)
         assert np.array_equal(t[0].cpu().numpy(), m1) and np.array_equal(t[2].cpu().numpy(), m2), (na, nb)
 
 
@@ -218,7 +220,7 @@ def test_fallback_rate_and_forced_fallback(nm, oracle, cuda):
     ws = nm.MatchWorkspace(300, 900, cuda)
     m1, ix, m2 = nm.sift_match_shard(_t(A, cuda), _t(B, cuda), 0, workspace=ws)
     assert nm.match_fallback_count(ws, 300, 900) > 100
-    _, _, (m1r, ixr, m2r) = oracle.sift_matches(A, B, 0.8, want_distance=False)
+    m1r, ixr, m2r = oracle.sift_match_shard(A, B, 0)
     assert np.array_equal(ix.cpu().numpy(), ixr)
     assert np.array_equal(m1.cpu().numpy(), m1r) and np.array_equal(m2.cpu().numpy(), m2r)
     # a handful of unprovable rows among ordinary ones (the few-rows path of the fallback: <= 24 listed rows): three
@@ -238,7 +240,7 @@ def test_fallback_rate_and_forced_fallback(nm, oracle, cuda):
         ws = nm.MatchWorkspace(500, 2900, cuda)
         m1, ix, m2 = nm.sift_match_shard(_t(A, cuda), _t(B, cuda), 0, workspace=ws)
         assert n_hard <= nm.match_fallback_count(ws, 500, 2900) <= 24, n_hard
-        _, _, (m1r, ixr, m2r) = oracle.sift_matches(A, B, 0.8, want_distance=False)
+        m1r, ixr, m2r = oracle.sift_match_shard(A, B, 0)
         assert np.array_equal(ix.cpu().numpy(), ixr)
         assert np.array_equal(m1.cpu().numpy(), m1r) and np.array_equal(m2.cpu().numpy(), m2r)
 
@@ -330,7 +332,8 @@ def test_match_adversarial_rounding(nm, oracle, cuda):
     for name, (A, B) in cases.items():
         A = np.ascontiguousarray(A, np.float32); B = np.ascontiguousarray(B, np.float32)
         prior = np.full(len(A), -7, np.int32)
-        ref, _, (m1r, ixr, m2r) = oracle.sift_matches(A, B, 0.8, want_distance=False, prior=prior)
+        ref, _, _ = oracle.sift_matches(A, B, 0.8, want_distance=False, prior=prior)
+        m1r, ixr, m2r = oracle.sift_match_shard(A, B, 0)
         got, _ = _match(nm, cuda, A, B, prior=prior)
         assert np.array_equal(got, ref), name
         ws = nm.MatchWorkspace(len(A), len(B), cuda)
@@ -447,3 +450,66 @@ def test_match_batch_dev_sizes_sweep(nm, oracle, cuda):
         assert np.array_equal(results[k][:na].cpu().numpy(), ref), (k, na, nb)
         assert bool((results[k][na:] == -9).all()), (k, na, nb)
     assert nm.lib().nm_sift_match_batch_dev_f32(n, None, None, None, None, cap_a, cap_b, None, 0.8, None, None) != 0
+
+
+def test_match_outside_the_comfortable_domain(nm, oracle, cuda):
+    """Exact set_matches semantics (match.cu:88-116) where round 2 deviated: distances above 2139095040 (min_2 is
+    overwritten at every replacement, :97, so the initial value only survives while the minimum sits at candidate 0),
+    M = 1, and non-finite inputs (a NaN in candidate 0 turns every row into -1; a NaN elsewhere is skipped by the scan's
+    comparisons). Fused matcher (both screens), materialised distance + get_sift_matches, shard triples and the merge for
+    several shard splits incl. empty shards: everything equal to the oracle, whose scan is checked against a literal
+    transcription of the reference loop on the CPU (tests/test_oracle_match_semantics.py)."""
+    import torch
+    from test_oracle_match_semantics import _cases
+    u32 = lambda a: np.ascontiguousarray(a).view(np.uint32)
+    for name, (A, B) in _cases().items():
+        for amb in (0.8, 1.5):
+            prior = np.full(len(A), -7, np.int32)
+            ref, Dref, _ = oracle.sift_matches(A, B, amb, want_distance=True, prior=prior)
+            got, D = _match(nm, cuda, A, B, amb=amb, want_distance=True, prior=prior)
+            assert np.array_equal(got, ref), (name, amb)
+            nan = np.isnan(Dref)                         # a NaN's sign / payload is not specified; everything else bit for bit
+            assert np.array_equal(np.isnan(D), nan) and np.array_equal(u32(D)[~nan], u32(Dref)[~nan]), name
+            res = nm.get_sift_matches(_t(Dref, cuda), amb, prior=_t(prior, cuda))
+            assert np.array_equal(res.cpu().numpy(), ref), (name, amb, "get_sift_matches")
+        m1r, ixr, m2r = oracle.sift_match_shard(A, B, 0)
+        m1, ix, m2 = nm.sift_match_shard(_t(A, cuda), _t(B, cuda), 0)
+        assert np.array_equal(ix.cpu().numpy(), ixr), name
+        assert np.array_equal(u32(m1.cpu().numpy()) & 0x7fffffff, u32(m1r) & 0x7fffffff), name     # NaN: sign bit is free
+        assert np.array_equal(u32(m2.cpu().numpy()), u32(m2r)), name
+        ref, _, _ = oracle.sift_matches(A, B, 1.5, want_distance=False, prior=prior)
+        for fr in ([0, 0.34, 1.0], [0, 0, 0.5, 0.5, 1.0], [0, 0.04, 1.0]):
+            bounds = [int(round(f * len(B))) for f in fr]
+            tr = []
+            for b, e in zip(bounds[:-1], bounds[1:]):
+                Bs = B[b:e] if e > b else np.zeros((1, 128), np.float32)
+                tr.append(nm.sift_match_shard(_t(A, cuda), _t(Bs, cuda)[: e - b], b))
+            res = nm.sift_match_merge(torch.stack([t[0] for t in tr]), torch.stack([t[1] for t in tr]),
+                                      torch.stack([t[2] for t in tr]), 1.5, prior=_t(prior, cuda))
+            torch.cuda.synchronize()
+            assert np.array_equal(res.cpu().numpy(), ref), (name, bounds)
+
+
+def test_nonfinite_pair_does_not_disturb_its_batch(nm, oracle, cuda):
+    """A pair with NaN descriptors inside batched calls (host- and device-sized): that pair follows the reference's scan
+    (through the exact fallback), the other pairs of the call are unaffected."""
+    import torch
+    rng = np.random.default_rng(3)
+    As = [H.synth.descriptors(700 + k, 600) for k in range(3)]
+    Bs = [H.synth.descriptors(800 + k, 900) for k in range(3)]
+    Bs[1][0, 3] = np.nan                      # every row of pair 1 -> -1
+    As[2][5, 7] = np.inf; Bs[2][17, 0] = np.nan
+    tA = [_t(a, cuda) for a in As]; tB = [_t(b, cuda) for b in Bs]
+    refs = [oracle.sift_matches(As[k], Bs[k], 0.8, want_distance=False, prior=np.full(600, -9, np.int32))[0] for k in range(3)]
+    assert (refs[1] == -1).all() and (refs[0] >= 0).any()
+    results = [torch.full((600,), -9, dtype=torch.int32, device=cuda) for _ in range(3)]
+    nm.sift_match_batch(tA, tB, [600] * 3, [900] * 3, results, 0.8)
+    torch.cuda.synchronize()
+    for k in range(3):
+        assert np.array_equal(results[k].cpu().numpy(), refs[k]), k
+    results = [torch.full((600,), -9, dtype=torch.int32, device=cuda) for _ in range(3)]
+    nA = _t(np.array([600, 600, 600], np.int32), cuda); nB = _t(np.array([900, 900, 900], np.int32), cuda)
+    nm.sift_match_batch_dev(tA, [nA[k:k + 1] for k in range(3)], tB, [nB[k:k + 1] for k in range(3)], results, 0.8)
+    torch.cuda.synchronize()
+    for k in range(3):
+        assert np.array_equal(results[k].cpu().numpy(), refs[k]), k
