@@ -140,16 +140,18 @@ struct SegIter {
 // over `nlanes` callers (host: 1; device: the lanes of one wave, which then take the maximum over the wave).
 NM_HD int plan_max_slots_part(const MatchPlan &p, int lane, int nlanes)
 {
-    int S = 1, k = 0;
-    for (int x = 0; x < p.X; ++x) {
+    int S = 1;
+    // query block k belongs to group x = the one whose [q0, q0 + nq) holds it (plan_group), found without a loop so that
+    // the lanes of a wave run the same instructions on their own k (a `continue` per foreign k would serialise them)
+    const int cut = p.q_rem * (p.q_base + 1);
+    for (int k = lane; k < p.qblocks; k += nlanes) {
+        const int x = (k < cut) ? k / (p.q_base + 1) : p.q_rem + (k - cut) / p.q_base;
         const PlanGroup g = plan_group(p, x);
-        for (int qbl = 0; qbl < g.nq; ++qbl, ++k) {
-            if (k % nlanes != lane) continue;
-            int f, l;
-            piece_owners(p, g, p.C - 1, qbl, f, l);
-            const int n = plan_slot(p, g, p.C - 1, qbl, l) + 1;
-            if (n > S) S = n;
-        }
+        const int qbl = k - g.q0;
+        int f, l;
+        piece_owners(p, g, p.C - 1, qbl, f, l);
+        const int n = plan_slot(p, g, p.C - 1, qbl, l) + 1;
+        if (n > S) S = n;
     }
     return S;
 }
