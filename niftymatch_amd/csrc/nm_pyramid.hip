@@ -2,6 +2,8 @@
 // gradient. Replaces kernels/convolution.cu:16-159, kernels/downsample.cu:6-29, kernels/cudamath.cu:26-80 of the
 // reference. All kernels are HBM/L2 streaming stencils; arithmetic order is fixed by the fp spec:
 //   conv: taps k = -r..r, sum = fma(x[k], w[r-k], sum) starting from +0, rows first, then columns, zero padding.
+#include <cstdlib>
+
 #include "nm_common.hpp"
 #include "nm_fpspec.hpp"
 #include "../../include/nm_abi.h"
@@ -329,27 +331,203 @@ __device__ __forceinline__ bool grad_pair(v2f xm, v2f xp, v2f ym, v2f yp, v2f &g
 
 }  // namespace
 
+// Geometry shared by the packed kernels (64-column tiles / strips, 32 output rows per step).
+template <int R>
+struct PkGeom {
+    static constexpr int TW = 64, TH = 32;
+    static constexpr int RA = (R + 3) & ~3;
+    static constexpr int IN_W = TW + 2 * RA;             // staged columns (image x = x0 - RA + c)
+    static constexpr int IN_P2 = IN_W + 2;               // pitch in column PAIRS-of-rows; (2*IN_P2) % 32 == 4*odd: see above
+    static constexpr int ROWS = TH + 2 * R;              // even
+    static constexpr int RP = ROWS / 2;                  // row pairs; <= 32
+    static constexpr int MID_P = TW + 4;                 // row-pass result pitch (16-byte aligned rows, skewed banks)
+    static constexpr int OFF = RA - R;                   // first staged column the taps touch (for output column 0)
+    static constexpr int W0 = OFF & ~1;                  // even start of the b128 window
+    static constexpr int D = OFF - W0;
+    static constexpr int NC = (8 + 2 * R + D + 1) & ~1;  // window columns per task (even)
+    static constexpr int V = IN_W / 4;
+    static_assert(RP <= 32 && (IN_P2 % 2) == 0, "tile geometry");
+};
+
+// global -> registers: row pairs (gy_first + 2 p, gy_first + 2 p + 1), p < npairs, of the IN_W staged columns; zero outside the image
+template <int R, int NL>
+__device__ __forceinline__ void pk_load_pairs(float4 (&a)[NL], float4 (&b)[NL], const float *__restrict__ image, int npairs,
+                                              int gy_first, int x0, int width, int height, int tid)
+{
+    using G = PkGeom<R>;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int t = tid + 256 * i;
+        const int p = t / G::V, c4 = t - p * G::V;
+        const int gy = gy_first + 2 * p, gx = x0 - G::RA + 4 * c4;
+        a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        b[i] = a[i];
+        if (t < npairs * G::V && gx >= 0 && gx < width) {
+            if (gy >= 0 && gy < height) a[i] = *reinterpret_cast<const float4 *>(image + (size_t)gy * width + gx);
+            if (gy + 1 >= 0 && gy + 1 < height) b[i] = *reinterpret_cast<const float4 *>(image + (size_t)(gy + 1) * width + gx);
+        }
+    }
+}
+
+// registers -> LDS, row-pair interleaved, into the pairs [pair_first, pair_first + npairs) of s_in
+template <int R, int NL>
+__device__ __forceinline__ void pk_store_pairs(const float4 (&a)[NL], const float4 (&b)[NL], float *s_in, int npairs,
+                                               int pair_first, int tid)
+{
+    using G = PkGeom<R>;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int t = tid + 256 * i;
+        const int p = t / G::V, c4 = t - p * G::V;
+        if (t < npairs * G::V) {
+            float4 *q = reinterpret_cast<float4 *>(&s_in[((pair_first + p) * G::IN_P2 + 4 * c4) * 2]);
+            q[0] = make_float4(a[i].x, b[i].x, a[i].y, b[i].y);
+            q[1] = make_float4(a[i].z, b[i].z, a[i].w, b[i].w);
+        }
+    }
+}
+
+// rows: task = (row pair p, 8 output columns cg*8..): 16 outputs as 8 packed (rowA, rowB) accumulators -> s_mid rows 2p, 2p+1
+template <int R, bool WRITE_BUF>
+__device__ __forceinline__ void pk_row_task(const float *s_in, float *s_mid, const unsigned long long (&w)[2 * R + 1], int p,
+                                            int cg, float *__restrict__ buffer, int x0, int y0, int width, int height)
+{
+    using G = PkGeom<R>;
+    constexpr int NC = G::NC, D = G::D;
+    const v2f *src = reinterpret_cast<const v2f *>(&s_in[(p * G::IN_P2 + cg * 8 + G::W0) * 2]);
+    v2f win[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) win[j] = src[j];
+    v2f o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (v2f){0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t <= 2 * R; ++t) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = pk_fma_s(win[D + i + t], w[2 * R - t], o[i]);
+    }
+    float4 *qa = reinterpret_cast<float4 *>(&s_mid[(2 * p) * G::MID_P + cg * 8]);
+    float4 *qb = reinterpret_cast<float4 *>(&s_mid[(2 * p + 1) * G::MID_P + cg * 8]);
+    qa[0] = make_float4(o[0].x, o[1].x, o[2].x, o[3].x);
+    qa[1] = make_float4(o[4].x, o[5].x, o[6].x, o[7].x);
+    qb[0] = make_float4(o[0].y, o[1].y, o[2].y, o[3].y);
+    qb[1] = make_float4(o[4].y, o[5].y, o[6].y, o[7].y);
+    if (WRITE_BUF) {     // API path: the row pass of the tile's own rows is the caller's `buffer` (convolution.cu:141-159)
+        const int gx = x0 + cg * 8;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int rr = 2 * p + half, gy = y0 - R + rr;
+            if (rr >= R && rr < R + G::TH && gy < height && gx < width) {
+                float4 *q = reinterpret_cast<float4 *>(buffer + (size_t)gy * width + gx);
+                q[0] = half ? make_float4(o[0].y, o[1].y, o[2].y, o[3].y) : make_float4(o[0].x, o[1].x, o[2].x, o[3].x);
+                if (gx + 4 < width)
+                    q[1] = half ? make_float4(o[4].y, o[5].y, o[6].y, o[7].y) : make_float4(o[4].x, o[5].x, o[6].x, o[7].x);
+            }
+        }
+    }
+}
+
+// columns + epilogue: task = (column pair xp, 4 output rows): 8 outputs as 4 packed (x, x+1) accumulators; DoG, gradient of
+// the input level and the decimated next-octave plane come from the LDS tiles
+template <int R, bool WRITE_DOG, bool WRITE_GRAD, bool WRITE_BUF>
+__device__ __forceinline__ void pk_cols_epilogue(const float *s_in, const float *s_mid, const unsigned long long (&w)[2 * R + 1],
+                                                 int tid, int x0, int y0, int width, int height, float *__restrict__ result,
+                                                 float *__restrict__ dog, float2 *__restrict__ grad, float *__restrict__ down)
+{
+    using G = PkGeom<R>;
+    constexpr int RA = G::RA, IN_P2 = G::IN_P2, MID_P = G::MID_P;
+    constexpr int NY = 4;
+    const int xp = tid & 31, yg = tid >> 5;
+    v2f o[NY];
+    {
+        const float *src = &s_mid[(yg * NY) * MID_P + 2 * xp];
+        v2f win[NY + 2 * R];
+#pragma unroll
+        for (int j = 0; j < NY + 2 * R; ++j) win[j] = *reinterpret_cast<const v2f *>(src + j * MID_P);
+#pragma unroll
+        for (int i = 0; i < NY; ++i) o[i] = (v2f){0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t <= 2 * R; ++t) {
+#pragma unroll
+            for (int i = 0; i < NY; ++i) o[i] = pk_fma_s(win[i + t], w[2 * R - t], o[i]);
+        }
+    }
+    const int gx = x0 + 2 * xp;
+    if (gx < width) {
+        // input-level values around the 2 x 4 patch, from the interleaved tile: rows yy-1 .. yy+4, columns x-1 .. x+2
+        const int cc = RA + 2 * xp;
+        // One b128 read of the interleaved tile at an even column c returns (row 2p, c), (row 2p+1, c), (row 2p, c+1),
+        // (row 2p+1, c+1): the 6 x 4 patch comes from 3-4 row pairs x 3 aligned reads, conflict-free (a lane's address
+        // advances by 4 floats with xp), instead of 28 scalar reads that hit 8 banks 4 ways each.
+        constexpr int PAR = (R - 1) & 1;                  // parity of the first needed row (yg * NY is even)
+        constexpr int J0 = WRITE_GRAD ? 0 : 1, J1 = WRITE_GRAD ? NY + 1 : NY;      // rows j needed
+        constexpr int P0 = (PAR + J0) >> 1, P1 = (PAR + J1) >> 1;                  // row pairs relative to rp0
+        const int rp0 = (yg * NY + R - 1) >> 1;
+        float patch[2 * (P1 + 1)][4];                       // [row relative to 2 rp0][column x-1 .. x+2]
+#pragma unroll
+        for (int pp = P0; pp <= P1; ++pp) {
+            const float *base = &s_in[((rp0 + pp) * IN_P2 + cc) * 2];
+            const float4 m = *reinterpret_cast<const float4 *>(base);
+            patch[2 * pp][1] = m.x; patch[2 * pp + 1][1] = m.y; patch[2 * pp][2] = m.z; patch[2 * pp + 1][2] = m.w;
+            if (WRITE_GRAD) {
+                const float4 l = *reinterpret_cast<const float4 *>(base - 4), rr4 = *reinterpret_cast<const float4 *>(base + 4);
+                patch[2 * pp][0] = l.z; patch[2 * pp + 1][0] = l.w; patch[2 * pp][3] = rr4.x; patch[2 * pp + 1][3] = rr4.y;
+            }
+        }
+        v2f mid[NY + 2], lft[NY + 2], rgt[NY + 2];      // columns (x, x+1), (x-1, x), (x+1, x+2) of each row
+#pragma unroll
+        for (int j = 0; j < NY + 2; ++j) {
+            if (WRITE_GRAD || (j >= 1 && j <= NY)) mid[j] = (v2f){patch[PAR + j][1], patch[PAR + j][2]};
+            if (WRITE_GRAD && j >= 1 && j <= NY) {
+                lft[j] = (v2f){patch[PAR + j][0], patch[PAR + j][1]};
+                rgt[j] = (v2f){patch[PAR + j][2], patch[PAR + j][3]};
+            }
+        }
+        const unsigned row_bytes = (unsigned)width * 4u;
+        const bool in0 = gx >= 1, in1 = gx + 1 < width - 1;
+#pragma unroll
+        for (int i = 0; i < NY; ++i) {
+            const int gy = y0 + yg * NY + i;
+            if (gy < height) {
+                const unsigned off = (unsigned)gy * row_bytes + (unsigned)gx * 4u;       // < 4 GiB: checked by the host
+                if (result) *reinterpret_cast<float2 *>(reinterpret_cast<char *>(result) + off) = make_float2(o[i].x, o[i].y);
+                if (!WRITE_BUF && down && !(gy & 1)) {         // next octave's level 0 = every other pixel of every other row (gx is even)
+                    const int dw = width >> 1, dx = gx >> 1, dy = gy >> 1;
+                    if (dx < dw && dy < (height >> 1)) down[(size_t)dy * dw + dx] = o[i].x;
+                }
+                if (WRITE_DOG) {
+                    const v2f d = o[i] - mid[i + 1];
+                    *reinterpret_cast<float2 *>(reinterpret_cast<char *>(dog) + off) = make_float2(d.x, d.y);
+                }
+                if (WRITE_GRAD) {
+                    v2f g, r;
+                    const bool ok = grad_pair(lft[i + 1], rgt[i + 1], mid[i], mid[i + 2], g, r);
+                    if (__builtin_expect(!ok, 0)) {      // out-of-domain input (denormal-range or huge differences)
+                        const float2 a = grad_of(lft[i + 1].x, rgt[i + 1].x, mid[i].x, mid[i + 2].x);
+                        const float2 b = grad_of(lft[i + 1].y, rgt[i + 1].y, mid[i].y, mid[i + 2].y);
+                        g = (v2f){a.x, b.x};
+                        r = (v2f){a.y, b.y};
+                    }
+                    const bool rowin = gy >= 1 && gy < height - 1;
+                    const bool k0 = rowin && in0, k1 = rowin && in1;
+                    *reinterpret_cast<float4 *>(reinterpret_cast<char *>(grad) + 2 * (size_t)off) =
+                        make_float4(k0 ? g.x : 0.f, k0 ? r.x : 0.f, k1 ? g.y : 0.f, k1 ? r.y : 0.f);
+                }
+            }
+        }
+    }
+}
+
 template <int R, bool WRITE_DOG, bool WRITE_GRAD, bool WRITE_BUF = false>
 __global__ __launch_bounds__(256) void conv_pk_kernel(NmConvBatch batch, int width, int height,
                                                      const float *__restrict__ taps, int tiles_x, int ntiles,
                                                      int blocks_per_frame, int nxcd)
 {
-    constexpr int TW = 64, TH = 32;
-    constexpr int RA = (R + 3) & ~3;
-    constexpr int IN_W = TW + 2 * RA;             // staged columns (image x = x0 - RA + c)
-    constexpr int IN_P2 = IN_W + 2;               // pitch in column PAIRS-of-rows; (2*IN_P2) % 32 == 4*odd: see above
-    constexpr int ROWS = TH + 2 * R;              // even
-    constexpr int RP = ROWS / 2;                  // row pairs; <= 32
-    constexpr int MID_P = TW + 4;                 // row-pass result pitch (16-byte aligned rows, skewed banks)
-    constexpr int OFF = RA - R;                   // first staged column the taps touch (for output column 0)
-    constexpr int W0 = OFF & ~1;                  // even start of the b128 window
-    constexpr int D = OFF - W0;
-    constexpr int NC = (8 + 2 * R + D + 1) & ~1;  // window columns per task (even)
-    constexpr int V = IN_W / 4;
-    constexpr int NLOAD = (RP * V + 255) / 256;
-    static_assert(RP <= 32 && (IN_P2 % 2) == 0, "tile geometry");
-    __shared__ __attribute__((aligned(16))) float s_in[RP * IN_P2 * 2];
-    __shared__ __attribute__((aligned(16))) float s_mid[ROWS * MID_P];
+    using G = PkGeom<R>;
+    constexpr int TW = G::TW, TH = G::TH, RP = G::RP;
+    constexpr int NLOAD = (RP * G::V + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float s_in[RP * G::IN_P2 * 2];
+    __shared__ __attribute__((aligned(16))) float s_mid[G::ROWS * G::MID_P];
 
     const int tid = threadIdx.x;
     const int frame = blockIdx.x / blocks_per_frame;              // blocks_per_frame % nxcd == 0: blockIdx % nxcd is the XCD
@@ -364,7 +542,7 @@ __global__ __launch_bounds__(256) void conv_pk_kernel(NmConvBatch batch, int wid
     const float *__restrict__ image = batch.image[frame];
     float *__restrict__ dog = batch.dog[frame];
     float2 *__restrict__ grad = reinterpret_cast<float2 *>(batch.grad[frame]);
-    float *__restrict__ down = batch.down[frame];
+    float *__restrict__ down = batch.down[frame];               // WRITE_BUF: the API launcher passes `buffer` in this slot
 
     unsigned long long w[2 * R + 1];             // taps as scalar operands of v_pk_fma_f32 (low dword = the float)
 #pragma unroll
@@ -373,155 +551,28 @@ __global__ __launch_bounds__(256) void conv_pk_kernel(NmConvBatch batch, int wid
     // phase 1: global -> LDS, two rows per thread, interleaved
     {
         float4 a[NLOAD], b[NLOAD];
-#pragma unroll
-        for (int i = 0; i < NLOAD; ++i) {
-            const int t = tid + 256 * i;
-            const int p = t / V, c4 = t - p * V;
-            const int gy = y0 - R + 2 * p, gx = x0 - RA + 4 * c4;
-            a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            b[i] = a[i];
-            if (t < RP * V && gx >= 0 && gx < width) {
-                if (gy >= 0 && gy < height) a[i] = *reinterpret_cast<const float4 *>(image + (size_t)gy * width + gx);
-                if (gy + 1 >= 0 && gy + 1 < height) b[i] = *reinterpret_cast<const float4 *>(image + (size_t)(gy + 1) * width + gx);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NLOAD; ++i) {
-            const int t = tid + 256 * i;
-            const int p = t / V, c4 = t - p * V;
-            if (t < RP * V) {
-                float4 *q = reinterpret_cast<float4 *>(&s_in[(p * IN_P2 + 4 * c4) * 2]);
-                q[0] = make_float4(a[i].x, b[i].x, a[i].y, b[i].y);
-                q[1] = make_float4(a[i].z, b[i].z, a[i].w, b[i].w);
-            }
-        }
+        pk_load_pairs<R, NLOAD>(a, b, image, RP, y0 - R, x0, width, height, tid);
+        pk_store_pairs<R, NLOAD>(a, b, s_in, RP, 0, tid);
     }
     __syncthreads();
-
-    // phase 2: rows. task = (row pair p, 8 output columns cg*8..): 16 outputs as 8 packed (rowA, rowB) accumulators
+    // phase 2: rows
     {
         const int p = tid & 31, cg = tid >> 5;
-        if (p < RP) {
-            const v2f *src = reinterpret_cast<const v2f *>(&s_in[(p * IN_P2 + cg * 8 + W0) * 2]);
-            v2f win[NC];
-#pragma unroll
-            for (int j = 0; j < NC; ++j) win[j] = src[j];
-            v2f o[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] = (v2f){0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t <= 2 * R; ++t) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) o[i] = pk_fma_s(win[D + i + t], w[2 * R - t], o[i]);
-            }
-            float4 *qa = reinterpret_cast<float4 *>(&s_mid[(2 * p) * MID_P + cg * 8]);
-            float4 *qb = reinterpret_cast<float4 *>(&s_mid[(2 * p + 1) * MID_P + cg * 8]);
-            qa[0] = make_float4(o[0].x, o[1].x, o[2].x, o[3].x);
-            qa[1] = make_float4(o[4].x, o[5].x, o[6].x, o[7].x);
-            qb[0] = make_float4(o[0].y, o[1].y, o[2].y, o[3].y);
-            qb[1] = make_float4(o[4].y, o[5].y, o[6].y, o[7].y);
-            if (WRITE_BUF) {     // API path: the row pass of the tile's own rows is the caller's `buffer` (convolution.cu:141-159)
-                float *__restrict__ buffer = batch.down[frame];          // the API launcher passes `buffer` in this slot
-                const int gx = x0 + cg * 8;
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int rr = 2 * p + half, gy = y0 - R + rr;
-                    if (rr >= R && rr < R + TH && gy < height && gx < width) {
-                        float4 *q = reinterpret_cast<float4 *>(buffer + (size_t)gy * width + gx);
-                        q[0] = half ? make_float4(o[0].y, o[1].y, o[2].y, o[3].y) : make_float4(o[0].x, o[1].x, o[2].x, o[3].x);
-                        if (gx + 4 < width)
-                            q[1] = half ? make_float4(o[4].y, o[5].y, o[6].y, o[7].y) : make_float4(o[4].x, o[5].x, o[6].x, o[7].x);
-                    }
-                }
-            }
-        }
+        if (p < RP) pk_row_task<R, WRITE_BUF>(s_in, s_mid, w, p, cg, down, x0, y0, width, height);
     }
     __syncthreads();
-
-    // phase 3: columns. task = (column pair xp, 4 output rows): 8 outputs as 4 packed (x, x+1) accumulators
-    {
-        constexpr int NY = 4;
-        const int xp = tid & 31, yg = tid >> 5;
-        v2f o[NY];
-        {
-            const float *src = &s_mid[(yg * NY) * MID_P + 2 * xp];
-            v2f win[NY + 2 * R];
-#pragma unroll
-            for (int j = 0; j < NY + 2 * R; ++j) win[j] = *reinterpret_cast<const v2f *>(src + j * MID_P);
-#pragma unroll
-            for (int i = 0; i < NY; ++i) o[i] = (v2f){0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t <= 2 * R; ++t) {
-#pragma unroll
-                for (int i = 0; i < NY; ++i) o[i] = pk_fma_s(win[i + t], w[2 * R - t], o[i]);
-            }
-        }
-        const int gx = x0 + 2 * xp;
-        if (gx < width) {
-            // input-level values around the 2 x 4 patch, from the interleaved tile: rows yy-1 .. yy+4, columns x-1 .. x+2
-            const int cc = RA + 2 * xp;
-            // One b128 read of the interleaved tile at an even column c returns (row 2p, c), (row 2p+1, c), (row 2p, c+1),
-            // (row 2p+1, c+1): the 6 x 4 patch comes from 3-4 row pairs x 3 aligned reads, conflict-free (a lane's address
-            // advances by 4 floats with xp), instead of 28 scalar reads that hit 8 banks 4 ways each.
-            constexpr int PAR = (R - 1) & 1;                  // parity of the first needed row (yg * NY is even)
-            constexpr int J0 = WRITE_GRAD ? 0 : 1, J1 = WRITE_GRAD ? NY + 1 : NY;      // rows j needed
-            constexpr int P0 = (PAR + J0) >> 1, P1 = (PAR + J1) >> 1;                  // row pairs relative to rp0
-            const int rp0 = (yg * NY + R - 1) >> 1;
-            float patch[2 * (P1 + 1)][4];                       // [row relative to 2 rp0][column x-1 .. x+2]
-#pragma unroll
-            for (int pp = P0; pp <= P1; ++pp) {
-                const float *base = &s_in[((rp0 + pp) * IN_P2 + cc) * 2];
-                const float4 m = *reinterpret_cast<const float4 *>(base);
-                patch[2 * pp][1] = m.x; patch[2 * pp + 1][1] = m.y; patch[2 * pp][2] = m.z; patch[2 * pp + 1][2] = m.w;
-                if (WRITE_GRAD) {
-                    const float4 l = *reinterpret_cast<const float4 *>(base - 4), rr4 = *reinterpret_cast<const float4 *>(base + 4);
-                    patch[2 * pp][0] = l.z; patch[2 * pp + 1][0] = l.w; patch[2 * pp][3] = rr4.x; patch[2 * pp + 1][3] = rr4.y;
-                }
-            }
-            v2f mid[NY + 2], lft[NY + 2], rgt[NY + 2];      // columns (x, x+1), (x-1, x), (x+1, x+2) of each row
-#pragma unroll
-            for (int j = 0; j < NY + 2; ++j) {
-                if (WRITE_GRAD || (j >= 1 && j <= NY)) mid[j] = (v2f){patch[PAR + j][1], patch[PAR + j][2]};
-                if (WRITE_GRAD && j >= 1 && j <= NY) {
-                    lft[j] = (v2f){patch[PAR + j][0], patch[PAR + j][1]};
-                    rgt[j] = (v2f){patch[PAR + j][2], patch[PAR + j][3]};
-                }
-            }
-            const unsigned row_bytes = (unsigned)width * 4u;
-            const bool in0 = gx >= 1, in1 = gx + 1 < width - 1;
-#pragma unroll
-            for (int i = 0; i < NY; ++i) {
-                const int gy = y0 + yg * NY + i;
-                if (gy < height) {
-                    const unsigned off = (unsigned)gy * row_bytes + (unsigned)gx * 4u;       // < 4 GiB: checked by the host
-                    if (result) *reinterpret_cast<float2 *>(reinterpret_cast<char *>(result) + off) = make_float2(o[i].x, o[i].y);
-                    if (!WRITE_BUF && down && !(gy & 1)) {         // next octave's level 0 = every other pixel of every other row (gx is even)
-                        const int dw = width >> 1, dx = gx >> 1, dy = gy >> 1;
-                        if (dx < dw && dy < (height >> 1)) down[(size_t)dy * dw + dx] = o[i].x;
-                    }
-                    if (WRITE_DOG) {
-                        const v2f d = o[i] - mid[i + 1];
-                        *reinterpret_cast<float2 *>(reinterpret_cast<char *>(dog) + off) = make_float2(d.x, d.y);
-                    }
-                    if (WRITE_GRAD) {
-                        v2f g, r;
-                        const bool ok = grad_pair(lft[i + 1], rgt[i + 1], mid[i], mid[i + 2], g, r);
-                        if (__builtin_expect(!ok, 0)) {      // out-of-domain input (denormal-range or huge differences)
-                            const float2 a = grad_of(lft[i + 1].x, rgt[i + 1].x, mid[i].x, mid[i + 2].x);
-                            const float2 b = grad_of(lft[i + 1].y, rgt[i + 1].y, mid[i].y, mid[i + 2].y);
-                            g = (v2f){a.x, b.x};
-                            r = (v2f){a.y, b.y};
-                        }
-                        const bool rowin = gy >= 1 && gy < height - 1;
-                        const bool k0 = rowin && in0, k1 = rowin && in1;
-                        *reinterpret_cast<float4 *>(reinterpret_cast<char *>(grad) + 2 * (size_t)off) =
-                            make_float4(k0 ? g.x : 0.f, k0 ? r.x : 0.f, k1 ? g.y : 0.f, k1 ? r.y : 0.f);
-                    }
-                }
-            }
-        }
-    }
+    // phase 3: columns + epilogue
+    pk_cols_epilogue<R, WRITE_DOG, WRITE_GRAD, WRITE_BUF>(s_in, s_mid, w, tid, x0, y0, width, height, result, dog, grad, down);
 }
+
+// (Round 3, measured and removed: a STREAMING form of this kernel -- a workgroup owns a 64-column strip segment and marches
+// down it in 32-row bands, fetching and row-filtering only the 32 new input rows per band, moving the last 2R rows of both LDS
+// tiles to their head, with the next band's rows prefetched into registers -- is bit-identical and does 38 % less staging
+// and row-pass work, but ran the 16-frame chain in 78-83 us per frame instead of 66-68 (segments of 4 / 6 / 9 / 17 bands:
+// 84.5 / 85 / 90 / 97). With its stores off 51, with the prefetch loads off 63, with both off 38 us: inside one workgroup the
+// phases of a band are strictly sequential, and on gfx950 stores count in vmcnt, so waiting for the prefetched rows also
+// waits for the previous band's stores. Many short workgroups overlap each other's memory phases better than few long
+// ones overlap their own. profiles/r03_c_conv_strip_experiment.txt)
 
 // Exhaustive self-test of sqrt_rn's fast path against the IEEE expansion (tests/test_gpu_stages.py).
 __global__ __launch_bounds__(256) void selftest_sqrt_kernel(unsigned long long *mismatches)
@@ -624,9 +675,9 @@ static int launch_conv_pk(const NmConvBatch &b, int width, int height, const flo
     const int tiles_x = nm_divup(width, 64), tiles_y = nm_divup(height, 32);
     const int ntiles = tiles_x * tiles_y;
     const int nxcd = nm_xcd_count();
+    const bool dog = b.dog[0] != nullptr, grad = b.grad[0] != nullptr;
     const int bpf = nm_divup(ntiles, nxcd) * nxcd;
     dim3 grid(bpf * b.n);
-    const bool dog = b.dog[0] != nullptr, grad = b.grad[0] != nullptr;
 #define NM_PK_LAUNCH(DOG, GRAD)                                                                                     \
     hipLaunchKernelGGL((conv_pk_kernel<R, DOG, GRAD>), grid, dim3(256), 0, stream, b, width, height, taps, tiles_x, \
                        ntiles, bpf, nxcd)
