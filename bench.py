@@ -192,7 +192,7 @@ def detect_256(nm, torch, dist, dev, cdev, rank, world, arenas, streams, B):
             "per_rank_ms": [round(v, 3) for v in ranks_ms]}
 
 
-def roofline_pyramid(B, o0_ms, all_ms, traffic, nodog_ms=None):
+def roofline_pyramid(B, o0_ms, all_ms, traffic, nodog_ms=None, dogonly_ms=None):
     """Whole scale-space chain of one B-frame detect call against HBM. `achieved` follows the bench contract: ALGORITHMIC
     bytes (108 B per octave-pixel = 48 Gaussian + 60 DoG; the fused gradient planes add 36) over the
     measured duration. `traffic` is the HBM-side byte count of the same sequence from the rocprofv3 PMC passes in
@@ -216,6 +216,13 @@ def roofline_pyramid(B, o0_ms, all_ms, traffic, nodog_ms=None):
         if t_all:
             out["physical_GBps"] = round(t_all * B / (all_ms * 1e-3) / 1e9, 1)
             out["physical_frac"] = round(t_all * B / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    if dogonly_ms:
+        # exactly the reference's convolve + compute_dog work: Gaussian levels + DoG planes, WITHOUT the gradient planes the
+        # chain above also produces in the same launches (36 B/px that the 108 B/px yardstick does not count)
+        out["levels_dog_only"] = {"note": "the same chain without the fused gradient planes: the 108 B per octave-pixel workload alone",
+                                  "avg_ms": round(dogonly_ms, 4), "us_per_frame": round(1e3 * dogonly_ms / B, 2),
+                                  "achieved": round(alg108 / (dogonly_ms * 1e-3) / 1e9, 1),
+                                  "frac": round(alg108 / (dogonly_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     if nodog_ms:
         # what nm_sift_detect_describe_batch itself runs since round 2: the same chain WITHOUT materialised DoG planes (its
         # detection kernel subtracts consecutive levels): 48 B/px of Gaussian levels (+ 4 for level 5) + 36 of gradients
@@ -566,7 +573,7 @@ def main():
     # whole-pyramid probe (after the timed regions, chip otherwise idle): the scale-space launches of one B-frame detect
     # call, every octave, timed with events on the stream they run on
     frames = frame_sets[0]
-    pyr_all_ms = pyr_nodog_ms = None
+    pyr_all_ms = pyr_nodog_ms = pyr_dogonly_ms = None
     try:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(mstream):
@@ -589,9 +596,16 @@ def main():
             for _ in range(reps):
                 nm.scale_space_batch(arenas[:B], frames[:B], write_dog=False)
             e3.record()
+            e4, e5 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            nm.scale_space_batch(arenas[:B], frames[:B], write_dog=True, write_grad=False)
+            e4.record()
+            for _ in range(reps):
+                nm.scale_space_batch(arenas[:B], frames[:B], write_dog=True, write_grad=False)
+            e5.record()
         mstream.synchronize()
         pyr_all_ms = e0.elapsed_time(e1) / reps
         pyr_nodog_ms = e2.elapsed_time(e3) / reps
+        pyr_dogonly_ms = e4.elapsed_time(e5) / reps
     except Exception:
         pyr_all_ms = None
 
@@ -689,7 +703,7 @@ def main():
             "per_rank_ms": [round(v, 3) for v in ranks_ms],
             "ranks_seen_by_communicator": ranks_seen, "backend": (args.backend if world > 1 else None),
             "roofline": roof,
-            "roofline_pyramid": roofline_pyramid(B, p_ms, pyr_all_ms, traffic, pyr_nodog_ms),
+            "roofline_pyramid": roofline_pyramid(B, p_ms, pyr_all_ms, traffic, pyr_nodog_ms, pyr_dogonly_ms),
         }
         if world > 1 and args.backend == "nccl":
             out["rccl_ranks_seen"] = ranks_seen

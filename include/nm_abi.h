@@ -356,7 +356,9 @@ NM_API int nm_sift_detect_describe_batch(nm_sift_arena *const *arenas, int n, co
 NM_API int nm_sift_scale_space_batch(nm_sift_arena *const *arenas, int n, const float *const *gray, void *stream);
 /* The same chain with (write_dog = 1, what nm_sift_scale_space_batch does: levels + DoG + gradient planes, the 108 B per
  * octave-pixel yardstick) or without (0) materialised DoG planes. nm_sift_detect_describe[_batch] runs the latter: its
- * detection kernel subtracts consecutive levels itself, so 16 of the chain's 64 written bytes per pixel are never moved. */
+ * detection kernel subtracts consecutive levels itself, so 16 of the chain's 64 written bytes per pixel are never moved.
+ * write_dog | 2: the same without the fused gradient planes, i.e. with write_dog = 3 exactly the work of the reference's
+ * convolve + compute_dog loops (6 level writes + 5 DoG planes per octave: the 108 B per octave-pixel yardstick alone). */
 NM_API int nm_sift_scale_space_batch_ex(nm_sift_arena *const *arenas, int n, const float *const *gray, int write_dog,
                                         void *stream);
 /* Pointers into the arena for stage-level inspection (tests, profiling): Gaussian level l (0..5) and DoG d (0..4)

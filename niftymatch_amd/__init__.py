@@ -598,16 +598,17 @@ def detect_describe_batch(arenas, grays):
         arr([_dev(a.num_items) for a in arenas]), _stream()), "nm_sift_detect_describe_batch")
 
 
-def scale_space_batch(arenas, grays, write_dog=True):
+def scale_space_batch(arenas, grays, write_dog=True, write_grad=True):
     """Only the scale-space launches (nm_sift_scale_space_batch_ex), on the current stream. write_dog=True: levels + DoG +
-    gradient planes (the 108 B per octave-pixel chain); False: what detect_describe_batch runs (no DoG planes)."""
+    gradient planes; False: what detect_describe_batch runs (no DoG planes). write_grad=False leaves the fused gradient
+    planes out: with write_dog=True that is exactly the reference's convolve + compute_dog work (108 B per octave-pixel)."""
     torch = _torch()
     n = len(arenas)
     if n != len(grays) or not 0 < n <= SIFT_MAX_BATCH:
         raise NmError("batch of %d arenas / %d frames (max %d)" % (n, len(grays), SIFT_MAX_BATCH))
     _check(lib().nm_sift_scale_space_batch_ex((C.c_void_p * n)(*[a._h.value for a in arenas]), n,
                                               (C.c_void_p * n)(*[_dev(g, torch.float32) for g in grays]),
-                                              1 if write_dog else 0, _stream()),
+                                              (1 if write_dog else 0) | (0 if write_grad else 2), _stream()),
            "nm_sift_scale_space_batch_ex")
 
 

@@ -222,7 +222,7 @@ static bool frame_driver_writes_dog()
 }
 
 static int octave_pyramid(nm_sift_arena *const *as, int n, int o, int ow, int oh, bool store_top, bool decimate,
-                          hipStream_t st, bool write_dog = true, bool per_octave = false)
+                          hipStream_t st, bool write_dog = true, bool per_octave = false, bool write_grad = true)
 {
     if (o == 0) nm_prof_begin(NM_PROF_PYRAMID_O0, st);
     const size_t plane = (size_t)ow * oh;
@@ -238,7 +238,7 @@ static int octave_pyramid(nm_sift_arena *const *as, int n, int o, int ow, int oh
             b.result[f] = (i < 5 || store_top) ? lv[i] : nullptr;     // level 5 is only read through DoG 4
             b.image[f] = lv[i - 1];
             b.dog[f] = write_dog ? a->dog[o][i - 1] : nullptr;
-            b.grad[f] = (i >= 2 && i <= 4) ? a->grad[o] + 2 * (size_t)(i - 2) * plane : nullptr;
+            b.grad[f] = (write_grad && i >= 2 && i <= 4) ? a->grad[o] + 2 * (size_t)(i - 2) * plane : nullptr;
             // level 3 decimated IS the next octave's level 0 (pyramidata / downsample.cu); level[0] of this octave was
             // consumed by the first launch of the sequence, so its plane can take it straight away
             b.down[f] = (decimate && i == 3) ? (per_octave ? a->lev[o + 1][0] : a->level[0]) : nullptr;
@@ -375,8 +375,11 @@ int nm_sift_scale_space_batch_ex(nm_sift_arena *const *as, int n, const float *c
     base.n = n;
     for (int f = 0; f < n; ++f) { base.result[f] = as[f]->level[0]; base.image[f] = gray[f]; }
     int rc = nm_launch_convolve_batch(base, W, H, as[0]->taps_base, as[0]->base_radius, st);
+    // write_dog bit 0: materialise the DoG planes; bit 1: leave the gradient planes out (measurement of the plain
+    // Gaussian + DoG chain, the 108 B per octave-pixel of SURVEY.md 8(d), without the fused 36 B of gradients)
+    const bool dogs = (write_dog & 1) != 0, grads = (write_dog & 2) == 0;
     for (int o = 0; !rc && o < P._num_octaves; ++o)
-        rc = octave_pyramid(as, n, o, W >> o, H >> o, !write_dog, o + 1 < P._num_octaves, st, write_dog != 0, true);
+        rc = octave_pyramid(as, n, o, W >> o, H >> o, !dogs, o + 1 < P._num_octaves, st, dogs, true, grads);
     return rc;
 }
 

@@ -340,7 +340,8 @@ struct PkGeom {
     static constexpr int IN_P2 = IN_W + 2;               // pitch in column PAIRS-of-rows; (2*IN_P2) % 32 == 4*odd: see above
     static constexpr int ROWS = TH + 2 * R;              // even
     static constexpr int RP = ROWS / 2;                  // row pairs; <= 32
-    static constexpr int MID_P = TW + 4;                 // row-pass result pitch (16-byte aligned rows, skewed banks)
+    static constexpr int MID_P = TW + 2;                 // row-pass result pitch: 8-byte aligned rows (b64 accesses). With + 4 and
+                                                         // b128 stores the R = 10 tile was 96 bytes over 160 KB / 5 and R = 7 over / 6
     static constexpr int OFF = RA - R;                   // first staged column the taps touch (for output column 0)
     static constexpr int W0 = OFF & ~1;                  // even start of the b128 window
     static constexpr int D = OFF - W0;
@@ -406,12 +407,13 @@ __device__ __forceinline__ void pk_row_task(const float *s_in, float *s_mid, con
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = pk_fma_s(win[D + i + t], w[2 * R - t], o[i]);
     }
-    float4 *qa = reinterpret_cast<float4 *>(&s_mid[(2 * p) * G::MID_P + cg * 8]);
-    float4 *qb = reinterpret_cast<float4 *>(&s_mid[(2 * p + 1) * G::MID_P + cg * 8]);
-    qa[0] = make_float4(o[0].x, o[1].x, o[2].x, o[3].x);
-    qa[1] = make_float4(o[4].x, o[5].x, o[6].x, o[7].x);
-    qb[0] = make_float4(o[0].y, o[1].y, o[2].y, o[3].y);
-    qb[1] = make_float4(o[4].y, o[5].y, o[6].y, o[7].y);
+    float2 *qa = reinterpret_cast<float2 *>(&s_mid[(2 * p) * G::MID_P + cg * 8]);
+    float2 *qb = reinterpret_cast<float2 *>(&s_mid[(2 * p + 1) * G::MID_P + cg * 8]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        qa[i] = make_float2(o[2 * i].x, o[2 * i + 1].x);
+        qb[i] = make_float2(o[2 * i].y, o[2 * i + 1].y);
+    }
     if (WRITE_BUF) {     // API path: the row pass of the tile's own rows is the caller's `buffer` (convolution.cu:141-159)
         const int gx = x0 + cg * 8;
 #pragma unroll
