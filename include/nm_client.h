@@ -20,6 +20,10 @@ __attribute__((visibility("default"))) int nm_client_detect_describe(const float
 __attribute__((visibility("default"))) double nm_client_pair_loop(const float *gray0, const float *gray1, int width,
                                                                  int height, int capacity, int reps, int with_distance,
                                                                  int *n_out);
+/* Copies, assignments, moves and std::vector growth of PyramidData / SiftData, each checked by running the frame through the
+ * object. gray: width*height fp32 (host). Returns the descriptor count when all variants agree, -2 on a mismatch, -1 on an
+ * exception (a double free aborts the process). */
+__attribute__((visibility("default"))) int nm_client_copy_semantics(const float *gray, int width, int height, int capacity);
 /* A: nA*128, B: nB*128 (host). distance: nA*nB (host) or NULL. result: nA ints, pre-filled by the caller. */
 __attribute__((visibility("default"))) int nm_client_match(const float *A, int nA, const float *B, int nB,
                                                           float *distance, int *result, float ambiguity);

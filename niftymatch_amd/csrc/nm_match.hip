@@ -698,6 +698,11 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
         if (BF16) {
             dma_tile(t0, 0);
             if (tid < TILE_C) *reinterpret_cast<uint4 *>(ldsb + SLOT0 + tid * 16) = sts;
+            // A wave's LDS-DMA rows are read by all 8 waves after the barrier: every wave must have drained ITS transfers
+            // before it arrives. hipcc emits this wait today, but the workgroup-scope fence model does not oblige it to
+            // (LDS-DMA is tracked per wave): a half-landed tile would make the screen miss a true neighbour and the finalize
+            // pass would then "prove" a wrong row. Explicit, so that no toolchain change can move it.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             stage_write(lds);
         }
@@ -740,6 +745,7 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
                 mfma_half_bf16<true>(b0, b1, a0, a1, tb + 64 * (DIM * 4), foff, sp + 64 * 16, qw, qslot, g1, g2, g3);
                 fold(g1, g2, g3, 2 * n);
                 if (n + 1 < ntiles && tid < TILE_C) *reinterpret_cast<uint4 *>(ldsb + SLOT0 + (b ^ 1) * SLOTB + tid * 16) = sts;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile n + 1 has landed (this wave's share): see the prologue
                 __syncthreads();
             }
             asm volatile("s_nop 15\n\ts_nop 3" : "+v"(b0), "+v"(b1));

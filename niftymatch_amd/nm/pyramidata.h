@@ -13,11 +13,42 @@
 
 #define MAX_KERNEL_LENGTH 91
 
+namespace nm {
+//! Four pinned host ints for the asynchronous read-back of keypoint counts, allocated on first use. A COPY owns nothing
+//! yet (it gets a buffer of its own on first use); a move transfers the buffer. This is what makes PyramidData freely
+//! copyable and movable like the reference's (whose members are thrust vectors, sift/pyramidata.h:60-110): an implicit
+//! member-wise copy of a raw pinned pointer would be freed twice and written to after the first free.
+class pinned_counts {
+public:
+    pinned_counts() : _p(nullptr) {}
+    pinned_counts(const pinned_counts &) : _p(nullptr) {}
+    pinned_counts(pinned_counts &&o) noexcept : _p(o._p) { o._p = nullptr; }
+    pinned_counts &operator=(const pinned_counts &) { return *this; }
+    pinned_counts &operator=(pinned_counts &&o) noexcept
+    {
+        if (this != &o) { release(); _p = o._p; o._p = nullptr; }
+        return *this;
+    }
+    ~pinned_counts() { release(); }
+    int *get()
+    {
+        if (!_p) nm_check((int)hipHostMalloc(reinterpret_cast<void **>(&_p), 4 * sizeof(int), hipHostMallocDefault),
+                          "pinned counter allocation");
+        return _p;
+    }
+    bool allocated() const { return _p != nullptr; }
+
+private:
+    void release() { if (_p) (void)hipHostFree(_p); _p = nullptr; }
+    int *_p;
+};
+}  // namespace nm
+
 class PyramidData {
 public:
     PyramidData() : _base_radius(0), _num_octaves(0), _num_dogs(0), _num_kernels(0) { for (auto &d : _dirty) d = 0; }
     PyramidData(const SiftParams &params);
-    ~PyramidData();
+    // copy / move / destruction: member-wise (every member owns its memory and knows how to copy itself)
 
     void initialize(const SiftParams &params);
     void clear();
@@ -54,7 +85,7 @@ private:
     void create_kernel_for_sigma(float sigma, nm::device_vector<float> &result, int &radius);
     nm::device_vector<int> _count;        // device-side counters + scratch of the compaction
     nm::device_vector<int> _compact_ws;
-    int *_host_counts = nullptr;          // pinned, 4 ints
+    nm::pinned_counts _host_counts;       // pinned, 4 ints
 };
 
 #endif

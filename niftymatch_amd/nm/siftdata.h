@@ -25,6 +25,10 @@ struct SiftData {
     SiftData() : _x_ptr(nullptr), _y_ptr(nullptr), _match_indexes_ptr(nullptr), _num_items(0), _capacity(0) {}
     SiftData(int capacity);      //!< throws std::runtime_error for capacity <= 0
     ~SiftData();
+    //! Copies are deep (copy_from) and re-point _x_ptr / _y_ptr / _match_indexes_ptr at their own vectors; the match
+    //! scratch is NOT copied (a copy allocates its own at its first compute_sift_matches).
+    SiftData(const SiftData &in) : _x_ptr(nullptr), _y_ptr(nullptr), _match_indexes_ptr(nullptr), _num_items(0), _capacity(0) { copy_from(in); }
+    SiftData &operator=(const SiftData &in) { if (this != &in) copy_from(in); return *this; }
 
     void copy_from(const SiftData &in);                   //!< deep copy of all vectors
     void initialize_data(int capacity = MAX_DESCRIPTORS);

@@ -62,6 +62,57 @@ extern "C" int nm_client_detect_describe(const float *gray, int width, int heigh
     }
 }
 
+// Value semantics of the containers, as a client written against the reference may rely on them (thrust vectors are freely
+// copyable): the same frame through (0) the original PyramidData, (1) a copy, (2) an object assigned from a temporary, (3) an
+// element of a std::vector<PyramidData> that has reallocated, (4) a moved-to object; SiftData through its copy constructor and
+// assignment. Returns the number of descriptors when every variant produced identical descriptors, -2 on a mismatch, -1 on an
+// exception. With the raw pinned pointer PyramidData used to hold, (1)-(3) freed that buffer twice.
+extern "C" int nm_client_copy_semantics(const float *gray, int width, int height, int capacity)
+{
+    try {
+        SiftParams params(width, height);
+        const size_t npix = (size_t)width * height;
+        nm::device_vector<float> d_gray(std::vector<float>(gray, gray + npix));
+        auto run = [&](PyramidData &py, std::vector<float> &desc) {
+            SiftData out(capacity);
+            client_frame(params, py, d_gray.data(), out, 0);
+            SiftData copy(out), assigned;                  // deep copies: own vectors, own raw pointers
+            assigned = copy;
+            if (assigned._x_ptr != assigned._x.data() || assigned._x_ptr == out._x_ptr || assigned._num_items != out._num_items)
+                return -2;
+            desc = assigned._desc.to_host();
+            desc.resize((size_t)out._num_items * 128);
+            return out._num_items;
+        };
+        std::vector<float> ref, got;
+        PyramidData original(params);
+        const int n = run(original, ref);
+        if (n < 0) return n;
+        {
+            PyramidData copy(original);                    // (1)
+            if (run(copy, got) != n || got != ref) return -2;
+            PyramidData assigned;
+            assigned = PyramidData(params);                // (2) move-assignment from a temporary
+            if (run(assigned, got) != n || got != ref) return -2;
+            assigned = original;                           // copy-assignment over a live object
+            if (run(assigned, got) != n || got != ref) return -2;
+            std::vector<PyramidData> many;
+            many.push_back(original);
+            many.push_back(original);                      // (3) growth: elements are moved or copied, old ones destroyed
+            many.emplace_back(params);
+            for (PyramidData &py : many)
+                if (run(py, got) != n || got != ref) return -2;
+            PyramidData moved(std::move(many[0]));         // (4)
+            if (run(moved, got) != n || got != ref) return -2;
+        }                                                  // everything is destroyed here: no double free
+        if (run(original, got) != n || got != ref) return -2;
+        return n;
+    } catch (const std::exception &e) {
+        std::cerr << e.what() << std::endl;
+        return -1;
+    }
+}
+
 // Throughput of the drop-in path as an application would drive it: `reps` times { detect+describe both frames with the
 // reference's per-octave client loop, compute_sift_matches(A, B, distance) }. Objects are created once, as a real client
 // does. gray0/gray1 are DEVICE planes. with_distance != 0 passes a caller-allocated N x M `distance` (the reference's

@@ -10,11 +10,6 @@ PyramidData::PyramidData(const SiftParams &params) : _base_radius(0), _num_octav
     initialize(params);
 }
 
-PyramidData::~PyramidData()
-{
-    if (_host_counts) (void)hipHostFree(_host_counts);
-}
-
 void PyramidData::initialize(const SiftParams &params)
 {
     clear();
@@ -35,9 +30,7 @@ void PyramidData::initialize(const SiftParams &params)
     _count = nm::device_vector<int>(4);
     _compact_ws = nm::device_vector<int>(nm_compact3_workspace_bytes((int)num_pixels) / sizeof(int) + 1);
     for (auto &d : _dirty) d = 0;                      // every dense map is all -1 now
-    if (!_host_counts)
-        nm_check((int)hipHostMalloc(reinterpret_cast<void **>(&_host_counts), 4 * sizeof(int), hipHostMallocDefault),
-                 "pinned counter allocation");
+    (void)_host_counts.get();
     generate_kernels(params);
 }
 
@@ -83,10 +76,10 @@ void PyramidData::gpu_collate_keypoints_for_octave(int num_pixels, int counts[3]
     }
     nm_check(nm_compact_keypoints3(dense, num_pixels, out, _count.data(), _compact_ws.data(), stream),
              "Keypoint collation failed");
-    nm_check((int)hipMemcpyAsync(_host_counts, _count.data(), 3 * sizeof(int), hipMemcpyDeviceToHost, stream),
-             "Keypoint count D2H");
+    int *host = _host_counts.get();
+    nm_check((int)hipMemcpyAsync(host, _count.data(), 3 * sizeof(int), hipMemcpyDeviceToHost, stream), "Keypoint count D2H");
     nm_check((int)hipStreamSynchronize(stream), "Keypoint count D2H");
-    for (int l = 0; l < 3; ++l) counts[l] = _host_counts[l];
+    for (int l = 0; l < 3; ++l) counts[l] = host[l];
 }
 
 void PyramidData::generate_kernels(const SiftParams &params)

@@ -2,6 +2,7 @@
 #include "../siftfunctions.h"
 
 #include <cmath>
+#include <cstdlib>
 
 #include "../../../include/nm_abi.h"
 #include "../cudamath.h"
@@ -14,7 +15,19 @@
 
 // The reference transposes A, builds the transposed matrix, transposes it back and scans rows (siftfunctions.cu:21-39).
 // Here one fused MFMA pass finds the candidates and the exact pass decides; `distance` is filled only when asked for.
-// Asynchronous on `stream`: the scratch lives in A (grow-only), nothing is allocated or synchronised per call.
+// The scratch lives in A (grow-only): nothing is allocated per call.
+// Ordering: the reference returns only after the device has drained (its two thrust temporaries are freed on return,
+// which synchronises), so a client may read A->_match_indexes from the host or from another stream right after the
+// call. That is kept by default: the call ends with hipStreamSynchronize(stream). NM_ASYNC_MATCHES=1 in the environment
+// (or nm_set_async_matches(1)) makes it asynchronous on `stream` for clients that order their reads themselves.
+static int g_async_matches = -1;
+extern "C" __attribute__((visibility("default"))) void nm_set_async_matches(int on) { g_async_matches = on ? 1 : 0; }
+static bool async_matches()
+{
+    if (g_async_matches < 0) { const char *e = getenv("NM_ASYNC_MATCHES"); g_async_matches = (e && e[0] == '1') ? 1 : 0; }
+    return g_async_matches == 1;
+}
+
 void compute_sift_matches(SiftData *A, SiftData *B, float *distance, float ambiguity, hipStream_t stream)
 {
     const int A_size = A->_num_items;
@@ -26,11 +39,13 @@ void compute_sift_matches(SiftData *A, SiftData *B, float *distance, float ambig
         const int cap_a = A->_capacity > A_size ? A->_capacity : A_size, cap_b = B->_capacity > B_size ? B->_capacity : B_size;
         nm_check((int)hipStreamSynchronize(stream), "SIFT matching failed");      // an earlier match may still use the old one
         A->_match_workspace = nm::device_vector<int>();
-        A->_match_workspace.resize_uninitialized(nm_sift_match_workspace_bytes(cap_a, cap_b) / sizeof(int) + 1);
+        // exact size (resize_uninitialized would add its 50 % growth headroom to what is already the capacity's bound)
+        A->_match_workspace = nm::device_vector<int>(nm_sift_match_workspace_bytes(cap_a, cap_b) / sizeof(int) + 1);
     }
     nm_check(nm_sift_match_f32(A->_desc.data(), A_size, B->_desc.data(), B_size, distance, A->_match_indexes.data(),
                                ambiguity, A->_match_workspace.data(), stream),
              "SIFT matching failed");
+    if (!async_matches()) nm_check((int)hipStreamSynchronize(stream), "SIFT matching failed");
 }
 
 void compute_dog(PyramidData &pydata, const int octave_width, const int octave_height, hipStream_t stream)

@@ -202,3 +202,27 @@ def test_native_multi_gpu_entry_is_exported_and_sized(nm):
     import subprocess
     out = subprocess.run(["readelf", "-d", nm.LIB_PATH], capture_output=True, text=True).stdout
     assert "rccl" not in out, "libnm_hip.so must not depend on librccl at link time"
+
+
+def test_native_multi_gpu_entry_builds_and_refuses_ranks_without_a_communicator(nm, tmp_path):
+    """the first real N > 1 run must be self-checking. (i) examples/allpairs_rccl.cpp -- the native RCCL
+    client of nm_sift_match_allgather_f32, one host thread per GPU -- compiles and links against libnm_hip.so + librccl here
+    (no GPU needed); (ii) the entry refuses n_ranks > 1 without a communicator instead of merging one shard silently (a pure
+    host-side check: no device is touched), and accepts the degenerate calls that must be no-ops."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "allpairs_rccl")
+    libdir = os.path.dirname(nm.LIB_PATH)
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "allpairs_rccl.cpp"), "-L", libdir, "-lnm_hip", "-lrccl", "-lpthread",
+                        "-Wl,-rpath," + libdir, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert os.path.getsize(exe) > 10000
+    lib = nm.lib()
+    dummy = C.c_void_p(4096)          # never dereferenced: the refusal happens before any device work
+    assert lib.nm_sift_match_allgather_f32(dummy, 100, dummy, 50, 0, 2, dummy, 0.8, dummy, None, None) != 0
+    assert lib.nm_sift_match_allgather_f32(dummy, 100, dummy, 50, 0, 0, dummy, 0.8, dummy, None, None) != 0
+    assert lib.nm_sift_match_allgather_f32(None, 100, dummy, 50, 0, 1, dummy, 0.8, dummy, None, None) != 0
+    assert lib.nm_sift_match_allgather_f32(dummy, 0, dummy, 50, 0, 8, dummy, 0.8, dummy, None, None) == 0     # no queries: no-op
+    assert lib.nm_sift_match_allgather_workspace_bytes(100000, 12500, 8) > lib.nm_sift_match_allgather_workspace_bytes(100000, 12500, 1)

@@ -133,3 +133,14 @@ def test_cpp_api_pair_loop_is_stateless_and_matches(nm, oracle, cuda):
         us = nm.lib().nm_client_pair_loop(f[0].data_ptr(), f[1].data_ptr(), 1920, 1080, 16384, 3, wd, out)
         assert us > 0
         assert (out[0], out[1], out[2]) == (r0["n"], r1["n"], int((m >= 0).sum()))
+
+
+def test_pyramiddata_and_siftdata_value_semantics(nm, oracle, cuda):
+    """PyramidData owned a raw pinned pointer with implicit copy operations (double hipHostFree, writes into freed
+    pinned memory). Copies, assignments, moves and std::vector growth now behave like the reference's thrust-based members
+    (sift/pyramidata.h:60-110, sift/siftdata.h:25-40): every variant runs the frame and must reproduce the oracle's count."""
+    w, h, cap = 320, 240, 4096
+    f = H.blurred_frame(5, w, h)
+    ref = oracle.sift_detect_describe(f, cap)
+    n = nm.lib().nm_client_copy_semantics(np.ascontiguousarray(f).ctypes.data, w, h, cap)
+    assert n == ref["n"] and n > 100
