@@ -621,11 +621,12 @@ def main():
             import ctypes as C
             dropin = {"workload": "drop-in C++ API client loop on the 1080p pair (nm/src/nm_client.cpp: 2 x per-octave "
                                   "detect+describe + compute_sift_matches), single host thread, NULL stream"}
-            for key, wd, reps in (("distance_null", 0, 10), ("distance_materialised", 1, 4)):
+            for key, wd, reps, nstreams in (("distance_null", 0, 10, 1), ("distance_materialised", 1, 4, 1),
+                                            ("distance_null_two_streams", 0, 10, 2), ("distance_materialised_two_streams", 1, 4, 2)):
                 n3 = (C.c_int * 3)()
-                us = nm.lib().nm_client_pair_loop(frames[0].data_ptr(), frames[1].data_ptr(), W, H, CAP, reps, wd, n3)
+                us = nm.lib().nm_client_pair_loop_ex(frames[0].data_ptr(), frames[1].data_ptr(), W, H, CAP, reps, wd, nstreams, n3)
                 dropin[key] = {"us_per_pair": round(us, 1), "pairs_per_s": round(1e6 / us, 1), "reps": reps,
-                               "keypoints": [n3[0], n3[1]], "matches": n3[2]}
+                               "host_threads_and_streams": nstreams, "keypoints": [n3[0], n3[1]], "matches": n3[2]}
         except Exception as exc:
             dropin = {"error": repr(exc)}
 

@@ -20,6 +20,11 @@ __attribute__((visibility("default"))) int nm_client_detect_describe(const float
 __attribute__((visibility("default"))) double nm_client_pair_loop(const float *gray0, const float *gray1, int width,
                                                                  int height, int capacity, int reps, int with_distance,
                                                                  int *n_out);
+/* The same with streams = 2: the two frames of a pair driven concurrently from two host threads on two streams (a
+ * PyramidData each), the match on the first stream once both are described. streams = 1 is nm_client_pair_loop. */
+__attribute__((visibility("default"))) double nm_client_pair_loop_ex(const float *gray0, const float *gray1, int width,
+                                                                    int height, int capacity, int reps, int with_distance,
+                                                                    int streams, int *n_out);
 /* Copies, assignments, moves and std::vector growth of PyramidData / SiftData, each checked by running the frame through the
  * object. gray: width*height fp32 (host). Returns the descriptor count when all variants agree, -2 on a mismatch, -1 on an
  * exception (a double free aborts the process). */

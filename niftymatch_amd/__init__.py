@@ -93,6 +93,7 @@ _SIGNATURES = {
     "nm_client_detect_describe": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "nm_client_match": (_I, [_P, _I, _P, _I, _P, _P, _F]),
     "nm_client_copy_semantics": (_I, [_P, _I, _I, _I]),
+    "nm_client_pair_loop_ex": (C.c_double, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "nm_client_pair_loop": (C.c_double, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "nm_client_ransac": (_I, [_I, _P, _P, _P, _P, _I, _F, _I, C.c_uint, _P]),
 }

@@ -1243,6 +1243,19 @@ __global__ __launch_bounds__(256) void transpose_kernel(float *__restrict__ odat
     }
 }
 
+// t = x - y and acc = fma(t, t, acc) for TWO column elements per instruction (v_pk_add_f32 with the x element broadcast by
+// op_sel and y negated by neg_lo / neg_hi, then v_pk_fma_f32): the same IEEE operations per element as the scalar pair, in
+// the same order -- half the VALU instructions, so one wave alone keeps its SIMD's vector pipe busy (a wave issues one
+// vector instruction per ~4 cycles whatever its width).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void xd_step(v2f &acc, v2f xpair, v2f y, bool hi)
+{
+    v2f t;
+    if (hi) asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(xpair), "v"(y));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(xpair), "v"(y));
+    asm("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(acc) : "v"(t));
+}
+
 template <bool X_KMAJOR, bool Y_KMAJOR>
 __global__ __launch_bounds__(256) void exact_distance_kernel(const float *__restrict__ X, int nX,
                                                             const float *__restrict__ Y, int nY,
@@ -1253,11 +1266,11 @@ __global__ __launch_bounds__(256) void exact_distance_kernel(const float *__rest
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;                 // 16 x 16 threads, 8 x 8 outputs each
     const int c0 = blockIdx.x * XD_TILE, r0 = blockIdx.y * XD_TILE;
-    float acc[8][8];
+    v2f acc[8][4];                                          // [row][column pair]
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+        for (int j = 0; j < 4; ++j) acc[i][j] = (v2f){0.f, 0.f};
     for (int kc = 0; kc < DIM; kc += XD_KC) {
         __syncthreads();
         xd_stage<X_KMAJOR>(sX, X, nX, r0, kc, tid);
@@ -1269,15 +1282,12 @@ __global__ __launch_bounds__(256) void exact_distance_kernel(const float *__rest
             const float4 xb = *reinterpret_cast<const float4 *>(&sX[k * XD_PITCH + ty * 8 + 4]);
             const float4 ya = *reinterpret_cast<const float4 *>(&sY[k * XD_PITCH + tx * 8]);
             const float4 yb = *reinterpret_cast<const float4 *>(&sY[k * XD_PITCH + tx * 8 + 4]);
-            const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-            const float yv[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+            const v2f xp[4] = {{xa.x, xa.y}, {xa.z, xa.w}, {xb.x, xb.y}, {xb.z, xb.w}};
+            const v2f yp[4] = {{ya.x, ya.y}, {ya.z, ya.w}, {yb.x, yb.y}, {yb.z, yb.w}};
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float t = xv[i] - yv[j];
-                    acc[i][j] = __builtin_fmaf(t, t, acc[i][j]);
-                }
+                for (int j = 0; j < 4; ++j) xd_step(acc[i][j], xp[i >> 1], yp[j], (i & 1) != 0);
         }
     }
     const int col = c0 + tx * 8;
@@ -1287,12 +1297,12 @@ __global__ __launch_bounds__(256) void exact_distance_kernel(const float *__rest
         if (row >= nX) continue;
         float *o = out + (size_t)row * ld + col;
         if (col + 7 < nY && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
-            *reinterpret_cast<float4 *>(o) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
-            *reinterpret_cast<float4 *>(o + 4) = make_float4(acc[i][4], acc[i][5], acc[i][6], acc[i][7]);
+            *reinterpret_cast<float4 *>(o) = make_float4(acc[i][0].x, acc[i][0].y, acc[i][1].x, acc[i][1].y);
+            *reinterpret_cast<float4 *>(o + 4) = make_float4(acc[i][2].x, acc[i][2].y, acc[i][3].x, acc[i][3].y);
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (col + j < nY) o[j] = acc[i][j];
+                if (col + j < nY) o[j] = (j & 1) ? acc[i][j >> 1].y : acc[i][j >> 1].x;
         }
     }
 }

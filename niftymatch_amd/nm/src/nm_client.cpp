@@ -6,7 +6,11 @@
 #include <cmath>
 #include <cstring>
 #include <exception>
+#include <condition_variable>
 #include <iostream>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../convolution.h"
@@ -118,27 +122,81 @@ extern "C" int nm_client_copy_semantics(const float *gray, int width, int height
 // does. gray0/gray1 are DEVICE planes. with_distance != 0 passes a caller-allocated N x M `distance` (the reference's
 // mandatory argument); 0 passes NULL (the extension). Returns the wall-clock microseconds per pair (host clock around
 // the loop, device drained), or a negative value on error; n_out receives the two keypoint counts and the match count.
-extern "C" double nm_client_pair_loop(const float *gray0, const float *gray1, int width, int height, int capacity, int reps,
-                                      int with_distance, int *n_out)
+// streams = 1: the loop above on one stream from one host thread (what round 2 measured). streams = 2: the two frames of a
+// pair are independent until the match, so a client may drive them from two host threads on two streams with a PyramidData
+// each (the per-octave API costs ~110 launches and 6 count read-backs per frame: one host thread is the bottleneck, not
+// the GPU); the match follows on the first stream once both frames are described.
+extern "C" double nm_client_pair_loop_ex(const float *gray0, const float *gray1, int width, int height, int capacity, int reps,
+                                         int with_distance, int streams, int *n_out)
 {
     try {
         SiftParams params(width, height);
         PyramidData py(params);
         SiftData a(capacity), b(capacity);
         nm::device_vector<float> dist(with_distance ? (size_t)capacity * capacity : 0);
-        hipStream_t st = nullptr;
+        hipStream_t st = nullptr, st1 = nullptr;
+        int device = 0;
+        nm_check((int)hipGetDevice(&device), "hipGetDevice");
+        // second frame's worker: one persistent host thread, woken per pair
+        std::unique_ptr<PyramidData> py1;
+        std::thread worker;
+        std::mutex mu;
+        std::condition_variable cv;
+        int posted = 0, done = 0;
+        bool quit = false, failed = false;
+        if (streams >= 2) {
+            py1.reset(new PyramidData(params));
+            nm_check((int)hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "stream");
+            nm_check((int)hipStreamCreateWithFlags(&st1, hipStreamNonBlocking), "stream");
+            worker = std::thread([&]() {
+                if (hipSetDevice(device) != hipSuccess) failed = true;
+                int seen = 0;
+                for (;;) {
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return quit || posted > seen; });
+                        if (quit) return;
+                        seen = posted;
+                    }
+                    try {
+                        client_frame(params, *py1, gray1, b, st1);
+                        if (hipStreamSynchronize(st1) != hipSuccess) failed = true;
+                    } catch (...) { failed = true; }
+                    { std::lock_guard<std::mutex> lk(mu); done = seen; }
+                    cv.notify_all();
+                }
+            });
+        }
         auto pair = [&]() {
-            client_frame(params, py, gray0, a, st);
-            client_frame(params, py, gray1, b, st);
+            if (streams >= 2) {
+                { std::lock_guard<std::mutex> lk(mu); ++posted; }
+                cv.notify_all();
+                client_frame(params, py, gray0, a, st);
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return done == posted; });
+            } else {
+                client_frame(params, py, gray0, a, st);
+                client_frame(params, py, gray1, b, st);
+            }
             compute_sift_matches(&a, &b, with_distance ? dist.data() : nullptr, 0.8f, st);
         };
+        double us = -1.0;
         pair();                                                       // warm-up (workspace growth, code loading)
-        if (hipDeviceSynchronize() != hipSuccess) return -1.0;
-        const auto t0 = std::chrono::steady_clock::now();
-        for (int r = 0; r < reps; ++r) pair();
-        if (hipDeviceSynchronize() != hipSuccess) return -1.0;
-        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
-        if (n_out) {
+        if (hipDeviceSynchronize() == hipSuccess) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int r = 0; r < reps; ++r) pair();
+            if (hipDeviceSynchronize() == hipSuccess)
+                us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+        }
+        if (worker.joinable()) {
+            { std::lock_guard<std::mutex> lk(mu); quit = true; }
+            cv.notify_all();
+            worker.join();
+        }
+        if (st) (void)hipStreamDestroy(st);
+        if (st1) (void)hipStreamDestroy(st1);
+        if (failed) return -1.0;
+        if (n_out && us >= 0) {
             n_out[0] = a._num_items; n_out[1] = b._num_items;
             std::vector<int> m = a._match_indexes.to_host();
             int cnt = 0;
@@ -150,6 +208,12 @@ extern "C" double nm_client_pair_loop(const float *gray0, const float *gray1, in
         std::cerr << e.what() << std::endl;
         return -1.0;
     }
+}
+
+extern "C" double nm_client_pair_loop(const float *gray0, const float *gray1, int width, int height, int capacity, int reps,
+                                      int with_distance, int *n_out)
+{
+    return nm_client_pair_loop_ex(gray0, gray1, width, height, capacity, reps, with_distance, 1, n_out);
 }
 
 extern "C" int nm_client_match(const float *A, int nA, const float *B, int nB, float *distance, int *result,
