@@ -402,11 +402,11 @@ __global__ __launch_bounds__(256) void frame_orient_kernel(NmDescribeArgs a)
     const int wave = threadIdx.x >> 6;
     const int frame = blockIdx.y;
     const NmFrameBook *book = a.book[frame];
-    const int n = book->num_items;
+    const int n = book->oct_base[a.o_end];            // keypoints of octaves [o_begin, o_end): output slots [oct_base[o_begin], n)
     const float4 *kpts = reinterpret_cast<const float4 *>(a.kpts[frame]);
     float2 *orients = reinterpret_cast<float2 *>(a.orients[frame]);
     const int stride = gridDim.x * 4;
-    int pt = blockIdx.x * 4 + wave;
+    int pt = book->oct_base[a.o_begin] + blockIdx.x * 4 + wave;
     OriSamples cur, nxt;
     auto fetch = [&](int p, OriSamples &o) {
         const int oc = octave_of(book, a.num_octaves, p);
@@ -432,10 +432,10 @@ __global__ __launch_bounds__(64) void frame_desc_kernel(NmDescribeArgs a)
     __shared__ __attribute__((aligned(16))) float part[DESC_LDS];
     const int frame = blockIdx.y;
     const NmFrameBook *book = a.book[frame];
-    const int n = book->num_items;
+    const int n = book->oct_base[a.o_end];
     const float4 *kpts = reinterpret_cast<const float4 *>(a.kpts[frame]);
     const float2 *orients = reinterpret_cast<const float2 *>(a.orients[frame]);
-    for (int pt = blockIdx.x; pt < n; pt += gridDim.x) {
+    for (int pt = book->oct_base[a.o_begin] + blockIdx.x; pt < n; pt += gridDim.x) {
         const int o = octave_of(book, a.num_octaves, pt);
         describe_wave(kpts[pt], orients[pt].x, reinterpret_cast<const float2 *>(a.grad[frame][o]), a.geom[o].ow,
                       a.geom[o].oh, a.num_dogs, a.geom[o].xper, a.desc[frame] + (size_t)pt * 128, a.x[frame] + pt,
@@ -451,10 +451,12 @@ constexpr int NM_DESC_BLOCKS = 4096;      // one keypoint-wave each
 
 int nm_launch_frame_describe(const NmDescribeArgs &a, hipStream_t stream)
 {
-    if (a.n <= 0) return 0;
-    hipLaunchKernelGGL(frame_orient_kernel, dim3(NM_ORIENT_BLOCKS, a.n), dim3(256), 0, stream, a);
+    if (a.n <= 0 || a.o_end <= a.o_begin) return 0;
+    // the small octaves hold a few hundred keypoints at most: a grid sized for octave 0 would be thousands of empty workgroups
+    const int ob = a.o_begin >= 2 ? 64 : NM_ORIENT_BLOCKS, db = a.o_begin >= 2 ? 512 : NM_DESC_BLOCKS;
+    hipLaunchKernelGGL(frame_orient_kernel, dim3(ob, a.n), dim3(256), 0, stream, a);
     NM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(frame_desc_kernel, dim3(NM_DESC_BLOCKS, a.n), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(frame_desc_kernel, dim3(db, a.n), dim3(64), 0, stream, a);
     NM_LAUNCH_CHECK();
     return 0;
 }

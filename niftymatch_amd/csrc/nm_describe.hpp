@@ -14,6 +14,7 @@ struct NmDescribeArgs {
     const float *grad[NM_MAX_BATCH][20];         // float2 planes of gradient levels 0..2 of octave o, stride ow*oh
     int num_octaves;
     int num_dogs;
+    int o_begin, o_end;                          // this launch covers the keypoints of octaves [o_begin, o_end)
     const NmFrameBook *book[NM_MAX_BATCH];
     const float *kpts[NM_MAX_BATCH];   // float4, output order
     float *orients[NM_MAX_BATCH];      // float2, output order

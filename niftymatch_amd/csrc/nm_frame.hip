@@ -39,7 +39,8 @@ struct nm_sift_arena {
                                // pyramid is being computed, so the octaves cannot share planes
     float *dog[20][5];         // DoG planes PER OCTAVE: detection of octave o overlaps the pyramid of octave o+1
     hipStream_t side;          // detection / compaction stream forked off the caller's stream
-    hipEvent_t ev_pyr[20], ev_join;
+    hipStream_t desc;          // orientation + descriptors of the large octaves, beside the small octaves' pyramids / detection
+    hipEvent_t ev_pyr[20], ev_join, ev_det, ev_desc;
     float *grad[20];           // per octave: 3 float2 planes
     float *staging; size_t stage_stride;
     int *counts, *offsets; int max_blocks;
@@ -122,6 +123,7 @@ int nm_sift_arena_create(int width, int height, int capacity, nm_sift_arena **ou
     if (!a) return (int)hipErrorOutOfMemory;
     a->width = width; a->height = height; a->capacity = capacity;
     a->side = nullptr; a->ev_join = nullptr;
+    a->desc = nullptr; a->ev_det = nullptr; a->ev_desc = nullptr;
     a->mask = nullptr;
     a->device = -1;
     (void)hipGetDevice(&a->device);
@@ -153,7 +155,10 @@ int nm_sift_arena_create(int width, int height, int capacity, nm_sift_arena **ou
         if (!rc) rc = (int)hipEventCreateWithFlags(&a->ev_pyr[o], hipEventDisableTiming);
     }
     if (!rc) rc = (int)hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming);
+    if (!rc) rc = (int)hipEventCreateWithFlags(&a->ev_det, hipEventDisableTiming);
+    if (!rc) rc = (int)hipEventCreateWithFlags(&a->ev_desc, hipEventDisableTiming);
     if (!rc) rc = (int)hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking);
+    if (!rc) rc = (int)hipStreamCreateWithFlags(&a->desc, hipStreamNonBlocking);
     a->max_blocks = height * nm_divup(width, 256);
     a->stage_stride = (size_t)a->max_blocks * 256;
     if (!rc) rc = a->alloc(&a->staging, 3 * a->stage_stride * 4);
@@ -173,6 +178,9 @@ void nm_sift_arena_destroy(nm_sift_arena *a)
 {
     if (!a) return;
     if (a->side) { (void)hipStreamSynchronize(a->side); (void)hipStreamDestroy(a->side); }
+    if (a->desc) { (void)hipStreamSynchronize(a->desc); (void)hipStreamDestroy(a->desc); }
+    if (a->ev_det) (void)hipEventDestroy(a->ev_det);
+    if (a->ev_desc) (void)hipEventDestroy(a->ev_desc);
     for (int o = 0; o < 20; ++o)
         if (a->ev_pyr[o]) (void)hipEventDestroy(a->ev_pyr[o]);
     if (a->ev_join) (void)hipEventDestroy(a->ev_join);
@@ -301,8 +309,19 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
         da.desc[f] = desc[f]; da.x[f] = x[f]; da.y[f] = y[f];
     }
     hipStream_t side = as[0]->side;          // every detection / description launch covers all frames of the call
-    bool forked = false;
+    hipStream_t dstr = as[0]->desc;
+    bool forked = false, forked_desc = false;
     const bool dogs = frame_driver_writes_dog();
+    // NM_FRAME_SPLIT_DESCRIBE=2 (experiment, off by default): octaves 0 and 1 hold ~98 % of a frame's keypoints; their
+    // orientation + descriptor pass then starts as soon as octave 1 has been detected, on a stream of its own, beside the
+    // pyramids and detections of the small octaves, and the few keypoints of the small octaves are described at the end
+    // (output slots are octave-major: the passes write [oct_base[0], oct_base[2]) and [oct_base[2], num_items)). Measured
+    // (MI355X, round 3): throughput unchanged (2 260 vs 2 250 frame-pairs/s), a captured graph replays in the same 445 us per
+    // frame (this runtime executes a graph's branches one after the other), and eager single-frame calls, which are bound
+    // by the HOST's ~55 launches on the slower boxes, got 40 us slower (545 vs 507 us): two more launches and four more
+    // event operations. Not the default.
+    static const int split_cfg = [] { const char *e = getenv("NM_FRAME_SPLIT_DESCRIBE"); return e ? atoi(e) : 0; }();
+    const int split = (split_cfg > 0 && split_cfg < P._num_octaves) ? split_cfg : 0;
     auto body = [&]() -> int {
         for (int o = 0; o < P._num_octaves; ++o) {
             const int ow = W >> o, oh = H >> o;
@@ -342,10 +361,27 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
             e = nm_launch_detect_octave(d, s, g, side);
             if (e) return e;
             da.geom[o].ow = ow; da.geom[o].oh = oh; da.geom[o].xper = xper;
+            if (split && o + 1 == split) {
+                NM_RETURN_IF(hipEventRecord(as[0]->ev_det, side));
+                NM_RETURN_IF(hipStreamWaitEvent(dstr, as[0]->ev_det, 0));
+                forked_desc = true;
+                da.o_begin = 0; da.o_end = split;
+                e = nm_launch_frame_describe(da, dstr);
+                if (e) return e;
+            }
         }
+        da.o_begin = split; da.o_end = P._num_octaves;
         return nm_launch_frame_describe(da, side);
     };
     rc = body();
+    if (forked_desc) {
+        // the description stream joins the CALLER's stream directly (also on an error path, like the side stream below).
+        // Joining it into the side stream it was forked from -- an equivalent DAG -- makes this ROCm's stream capture
+        // segfault (tools/capture_shapes.py: fork s2 -> s3, join s3 -> s2 -> s1 crashes, s3 -> s1 and s2 -> s1 works).
+        const hipError_t e1 = hipEventRecord(as[0]->ev_desc, dstr);
+        const hipError_t e2 = (e1 == hipSuccess) ? hipStreamWaitEvent(st, as[0]->ev_desc, 0) : e1;
+        if (!rc && e2 != hipSuccess) rc = (int)e2;
+    }
     if (forked) {
         // also on an error path: the side stream must always be joined back, or a stream capture would be left with an
         // unjoined fork and the next call on these arenas could overtake side-stream work still in flight
