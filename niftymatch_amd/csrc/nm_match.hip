@@ -849,6 +849,7 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(MatchBatch bt)
     const float *__restrict__ A = c.A, *__restrict__ B = c.B;
     const int nA = pair_nA(c), S = pair_S(c), mode = c.mode, index_offset = c.index_offset;
     if (nA <= 0 || pair_nB(c) <= 0) return;              // device-sized call with an empty set: nothing was screened
+    if ((int)blockIdx.x * 64 >= nA) return;              // grids are sized for the batch's largest set (or the capacity)
     const float4 *__restrict__ partial = c.partial;
     const float *__restrict__ partial3 = c.partial3;
     const float *__restrict__ na = c.na;
@@ -892,6 +893,10 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(MatchBatch bt)
     }
     rest = __builtin_fminf(rest, __builtin_fminf(__shfl_xor(rest, 1), __shfl_xor(rest, 2)));
     rest = __builtin_fminf(rest, __builtin_fminf(__shfl_xor(rest, 1), __shfl_xor(rest, 2)));
+    // (Round 3: staging the four candidate rows of every query through LDS -- half a wave per 512-byte row, whole cache lines,
+    // then each lane walks its row at the conflict-free pitch -- was built and measured: 155 us per 16-pair call instead of
+    // 146. The kernel moves ~500 MB of scattered 512-byte rows per call, ~3.3 TB/s out of L2 / Infinity Cache: it is bound by
+    // that gather, not by the shape of its load instructions.)
     const int mine = (sub == 0) ? ci[0] : (sub == 1) ? ci[1] : (sub == 2) ? ci[2] : ci[3];
     float d = 0.f;
     if (mine >= 0)
