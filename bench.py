@@ -275,6 +275,11 @@ def parse_args(argv=None):
                          "one match under the next match's MFMA kernel (+7 %% frame-pairs/s), but the MFMA kernels of the "
                          "two streams then also contend for CUs and each reads ~20 %% longer: default 1 keeps the "
                          "event-timed matcher launches the isolated-kernel figure")
+    ap.add_argument("--match-pipeline", action="store_true",
+                    help="pipeline the match calls of a step by phase: norms / split images (PREP) and the exact finalize + "
+                         "fallback (FINISH) of neighbouring calls run on a helper stream beside the MFMA launches (SCREEN), which "
+                         "stay back to back on one stream. Measured (round 3): no gain -- 2 199 vs 2 196 frame-pairs/s, the MFMA "
+                         "launches read 7 us longer each, exactly what the hidden helpers took -- so not the default.")
     ap.add_argument("--overlap", action="store_true",
                     help="pipeline the matches of a detect call with the next call's detection (higher throughput; the "
                          "matcher then shares the chip, so its roofline reading drops -- not the default)")
@@ -417,7 +422,12 @@ def main():
     MB = max(1, min(args.match_batch, nm.MATCH_MAX_BATCH, P))
     MS = max(1, args.match_streams)
     mstreams = [mstream] + [torch.cuda.Stream(device=dev) for _ in range(MS - 1)]
-    bwss = [nm.MatchBatchDevWorkspace(MB, CAP, CAP, dev) for _ in range(MS)]
+    NCALLS = (P + MB - 1) // MB
+    pipeline = args.match_pipeline and MS == 1 and not args.overlap
+    bwss = [nm.MatchBatchDevWorkspace(MB, CAP, CAP, dev) for _ in range(NCALLS if pipeline else MS)]
+    hstream = torch.cuda.Stream(device=dev)             # helper stream of the phase pipeline
+    ev_prep = [torch.cuda.Event() for _ in range(NCALLS)]
+    ev_screen = [torch.cuda.Event() for _ in range(NCALLS)]
     results = [torch.full((CAP,), -1, dtype=torch.int32, device=dev) for _ in range(P)]
     EV_STEPS = min(args.steps, 64)                    # steps whose match launches are event-timed
     hist = torch.zeros((max(1, args.steps), 2 * P), dtype=torch.int32, device=dev)    # the counts of every timed step
@@ -437,15 +447,16 @@ def main():
     pool = ThreadPoolExecutor(T) if T > 1 else None
     call_done = [torch.cuda.Event() for _ in range(NB)]
 
-    def match_call(idx, evs, stream, ws, out):
-        """One nm_sift_match_batch_dev_f32 call for the pairs idx: the set sizes are the frame driver's d_num_items, read
-        on the device (no host read-back anywhere in a step)."""
+    def match_call(idx, evs, stream, ws, out, phases=7):
+        """One nm_sift_match_batch_dev_f32 call (or some of its phases) for the pairs idx: the set sizes are the frame
+        driver's d_num_items, read on the device (no host read-back anywhere in a step)."""
         with torch.cuda.stream(stream):
-            keep = nm.profile_event_pairs(nm.PROF_MATCH_TOP2, [evs[i] for i in idx]) if evs else None
+            timed = evs and (phases & nm.MATCH_PHASE_SCREEN)
+            keep = nm.profile_event_pairs(nm.PROF_MATCH_TOP2, [evs[i] for i in idx]) if timed else None
             nm.sift_match_batch_dev([arenas[2 * i].desc for i in idx], [arenas[2 * i].num_items for i in idx],
                                     [arenas[2 * i + 1].desc for i in idx], [arenas[2 * i + 1].num_items for i in idx],
-                                    [out[i] for i in idx], 0.8, workspace=ws, capA=CAP, capB=CAP)
-            if evs:
+                                    [out[i] for i in idx], 0.8, workspace=ws, capA=CAP, capB=CAP, phases=phases)
+            if timed:
                 nm.profile_event_pairs(nm.PROF_MATCH_TOP2, [])
             del keep
 
@@ -482,12 +493,29 @@ def main():
             for s in range(S):
                 done[s].record(streams[s])
                 mstream.wait_event(done[s])
-            for q in range(1, MS):
-                mstreams[q].wait_stream(mstream)        # the matches start when the last detect call has finished
-            for ci, i0 in enumerate(range(0, P, MB)):
-                match_call(list(range(i0, min(i0 + MB, P))), evs, mstreams[ci % MS], bwss[ci % MS], results)
-            for q in range(1, MS):
-                mstream.wait_stream(mstreams[q])
+            calls = [list(range(i0, min(i0 + MB, P))) for i0 in range(0, P, MB)]
+            if pipeline:
+                # phase pipeline: PREP of every call up front on the helper stream, the MFMA launches back to back on the
+                # match stream (each call's behind its PREP), FINISH of call c on the helper stream beside SCREEN of c + 1
+                hstream.wait_stream(mstream)
+                for ci, idx in enumerate(calls):
+                    match_call(idx, None, hstream, bwss[ci], results, nm.MATCH_PHASE_PREP)
+                    ev_prep[ci].record(hstream)
+                for ci, idx in enumerate(calls):
+                    mstream.wait_event(ev_prep[ci])
+                    match_call(idx, evs, mstream, bwss[ci], results, nm.MATCH_PHASE_SCREEN)
+                    ev_screen[ci].record(mstream)
+                for ci, idx in enumerate(calls):
+                    hstream.wait_event(ev_screen[ci])
+                    match_call(idx, None, hstream, bwss[ci], results, nm.MATCH_PHASE_FINISH)
+                mstream.wait_stream(hstream)
+            else:
+                for q in range(1, MS):
+                    mstreams[q].wait_stream(mstream)        # the matches start when the last detect call has finished
+                for ci, idx in enumerate(calls):
+                    match_call(idx, evs, mstreams[ci % MS], bwss[ci % MS], results)
+                for q in range(1, MS):
+                    mstream.wait_stream(mstreams[q])
         if hist_row is not None:
             with torch.cuda.stream(mstream):
                 hist_row.copy_(counts_all)
@@ -697,6 +725,8 @@ def main():
                        "pairs_per_gpu_per_step": P, "detect_streams": S, "frames_per_detect_call": B,
                        "host_enqueue_threads": T, "match_streams": MS, "pairs_per_match_call": MB,
                        "phases": "overlapped" if (args.overlap and B % 2 == 0) else "detect then match",
+                       "match_pipeline": ("PREP / FINISH of neighbouring calls on a helper stream beside the MFMA launches" if pipeline
+                                          else "whole calls on %d stream(s)" % MS),
                        "keypoints_pair0_last_step": [nA, nB], "capacity": CAP,
                        "parallelism": "frame-pair sharding, %d rank(s), no data-path collective" % world},
             "keypoints_per_s": round(kp_all / dt, 1),

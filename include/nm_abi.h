@@ -205,6 +205,18 @@ NM_API size_t nm_sift_match_batch_dev_workspace_bytes(int n, int capA, int capB)
 NM_API int nm_sift_match_batch_dev_f32(int n, const float *const *A, const int *const *d_nA, const float *const *B,
                                        const int *const *d_nB, int capA, int capB, int *const *result, float ambiguity,
                                        void *workspace, void *stream);
+/* The same call cut into its three dependent phases, for clients that pipeline several calls over streams of their own:
+ * PREP (norms, split operand images, the device-side work plan: streaming, ~5 us per pair), SCREEN (the MFMA kernel, one
+ * launch per pair: it fills the chip by itself) and FINISH (exact finalize, fallback, merge: latency-bound gathers that
+ * leave most of the chip idle). The phases of one call must run in this order on the same workspace -- the CLIENT orders
+ * them with its events -- but PREP of call k + 1 and FINISH of call k - 1 may run on a second stream beside SCREEN of call k
+ * (bench.py does that: the MFMA launches stay back to back on one stream). phases = 7 is nm_sift_match_batch_dev_f32. */
+#define NM_MATCH_PHASE_PREP 1
+#define NM_MATCH_PHASE_SCREEN 2
+#define NM_MATCH_PHASE_FINISH 4
+NM_API int nm_sift_match_batch_dev_phases_f32(int phases, int n, const float *const *A, const int *const *d_nA,
+                                              const float *const *B, const int *const *d_nB, int capA, int capB,
+                                              int *const *result, float ambiguity, void *workspace, void *stream);
 /* HOST functions (no device access; on a box without a GPU the MI355X geometry of 256 CUs / 8 XCDs is assumed): the work
  * distribution the matcher uses for (nA, nB). plan[0..9] = query blocks of 256 rows, candidate tiles of 128 rows, persistent
  * workgroups G, partial lists per query S (<= 64, what the workspace bound assumes), XCD groups X, workgroups per group,

@@ -53,6 +53,7 @@ _SIGNATURES = {
     "nm_sift_match_batch_f32": (_I, [_I, _P, _P, _P, _P, _P, _F, _P, _P]),
     "nm_sift_match_batch_dev_workspace_bytes": (_SZ, [_I, _I, _I]),
     "nm_sift_match_batch_dev_f32": (_I, [_I, _P, _P, _P, _P, _I, _I, _P, _F, _P, _P]),
+    "nm_sift_match_batch_dev_phases_f32": (_I, [_I, _I, _P, _P, _P, _P, _I, _I, _P, _F, _P, _P]),
     "nm_sift_match_workspace_bytes": (_SZ, [_I, _I]),
     "nm_sift_match_set_screen": (_I, [_I]),
     "nm_sift_match_get_screen": (_I, []),
@@ -353,7 +354,10 @@ class MatchBatchDevWorkspace:
         self.buf = torch.empty(n * self.pair_bytes, dtype=torch.uint8, device=device)
 
 
-def sift_match_batch_dev(As, d_nAs, Bs, d_nBs, results, ambiguity=0.8, workspace=None, capA=None, capB=None):
+MATCH_PHASE_PREP, MATCH_PHASE_SCREEN, MATCH_PHASE_FINISH = 1, 2, 4
+
+
+def sift_match_batch_dev(As, d_nAs, Bs, d_nBs, results, ambiguity=0.8, workspace=None, capA=None, capB=None, phases=7):
     """len(As) <= MATCH_MAX_BATCH matches whose set sizes are int32 DEVICE tensors (e.g. SiftArena.num_items): no host
     read-back between detect and match. capA / capB default to the rows of the descriptor tensors."""
     torch = _torch()
@@ -369,12 +373,12 @@ def sift_match_batch_dev(As, d_nAs, Bs, d_nBs, results, ambiguity=0.8, workspace
     if workspace.buf.numel() < lib().nm_sift_match_batch_dev_workspace_bytes(n, capA, capB):
         raise NmError("batch workspace too small")
     arr = lambda vals: (C.c_void_p * n)(*vals)
-    _check(lib().nm_sift_match_batch_dev_f32(n, arr([_dev(a, torch.float32) for a in As]),
-                                             arr([_dev(c, torch.int32) for c in d_nAs]),
-                                             arr([_dev(b, torch.float32) for b in Bs]),
-                                             arr([_dev(c, torch.int32) for c in d_nBs]), capA, capB,
-                                             arr([_dev(r, torch.int32) for r in results]), ambiguity,
-                                             _dev(workspace.buf), _stream()), "nm_sift_match_batch_dev_f32")
+    _check(lib().nm_sift_match_batch_dev_phases_f32(phases, n, arr([_dev(a, torch.float32) for a in As]),
+                                                    arr([_dev(c, torch.int32) for c in d_nAs]),
+                                                    arr([_dev(b, torch.float32) for b in Bs]),
+                                                    arr([_dev(c, torch.int32) for c in d_nBs]), capA, capB,
+                                                    arr([_dev(r, torch.int32) for r in results]), ambiguity,
+                                                    _dev(workspace.buf), _stream()), "nm_sift_match_batch_dev_phases_f32")
     return workspace
 
 

@@ -1406,7 +1406,7 @@ struct MatchJob {                 // host-side description of one pair of a (pos
 };
 
 // norms (1 launch for all pairs) -> MFMA top-2 (1 launch per pair) -> finalize, fallback, merge (1 launch each)
-static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStream_t st)
+static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStream_t st, int phases = 7)
 {
     if (n <= 0) return 0;
     if (n > MATCH_MAX_BATCH) return (int)hipErrorInvalidValue;
@@ -1441,17 +1441,19 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
     if (bt.n == 0) return 0;
     const int n_cu = nm_cu_count();
     bt.n_cu = n_cu; bt.n_xcd = nm_xcd_count();
-    if (screen) hipLaunchKernelGGL(prep_kernel<true>, dim3(nm_divup(max_rows, PREP_ROWS), bt.n), dim3(256), 0, st, bt);
-    else hipLaunchKernelGGL(prep_kernel<false>, dim3(nm_divup(max_rows, PREP_ROWS), bt.n), dim3(256), 0, st, bt);
-    NM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nbmax_kernel, dim3(bt.n), dim3(1024), 0, st, bt);
-    NM_LAUNCH_CHECK();
+    if (phases & NM_MATCH_PHASE_PREP) {
+        if (screen) hipLaunchKernelGGL(prep_kernel<true>, dim3(nm_divup(max_rows, PREP_ROWS), bt.n), dim3(256), 0, st, bt);
+        else hipLaunchKernelGGL(prep_kernel<false>, dim3(nm_divup(max_rows, PREP_ROWS), bt.n), dim3(256), 0, st, bt);
+        NM_LAUNCH_CHECK();
+        hipLaunchKernelGGL(nbmax_kernel, dim3(bt.n), dim3(1024), 0, st, bt);
+        NM_LAUNCH_CHECK();
+    }
     const size_t lds_bytes = (size_t)2 * TILE_C * KP * sizeof(float);
     // per call: the attribute is per device, and a process may drive several (cheap host-side call, not a stream op)
     NM_RETURN_IF(hipFuncSetAttribute(screen ? reinterpret_cast<const void *>(match_top2_kernel<true>)
                                             : reinterpret_cast<const void *>(match_top2_kernel<false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    for (int q = 0; q < bt.n; ++q) {
+    for (int q = 0; (phases & NM_MATCH_PHASE_SCREEN) && q < bt.n; ++q) {
         const MatchPair &c = bt.p[q];
         // device-sized: one workgroup per CU, of which the first plan.G (decided on the device) work
         const int grid = dev_sized ? n_cu : plans[q].G;
@@ -1467,6 +1469,7 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
         nm_prof_end(NM_PROF_MATCH_TOP2, st);
         NM_LAUNCH_CHECK();
     }
+    if (!(phases & NM_MATCH_PHASE_FINISH)) return 0;
     hipLaunchKernelGGL(match_finalize_kernel, dim3(nm_divup(4 * max_a, 256), bt.n), dim3(256), 0, st, bt);
     NM_LAUNCH_CHECK();
     static_assert(FB_SPLIT <= MAX_CHUNKS, "fallback slices reuse the partial area");
@@ -1571,7 +1574,16 @@ int nm_sift_match_batch_dev_f32(int n, const float *const *A, const int *const *
                                 const int *const *d_nB, int capA, int capB, int *const *result, float ambiguity,
                                 void *workspace, void *stream)
 {
+    return nm_sift_match_batch_dev_phases_f32(NM_MATCH_PHASE_PREP | NM_MATCH_PHASE_SCREEN | NM_MATCH_PHASE_FINISH, n, A, d_nA, B,
+                                              d_nB, capA, capB, result, ambiguity, workspace, stream);
+}
+
+int nm_sift_match_batch_dev_phases_f32(int phases, int n, const float *const *A, const int *const *d_nA, const float *const *B,
+                                       const int *const *d_nB, int capA, int capB, int *const *result, float ambiguity,
+                                       void *workspace, void *stream)
+{
     if (n <= 0) return 0;
+    if (phases <= 0 || phases > 7) return (int)hipErrorInvalidValue;
     if (n > MATCH_MAX_BATCH || !A || !d_nA || !B || !d_nB || !result || !workspace || capA <= 0 || capB <= 0)
         return (int)hipErrorInvalidValue;
     MatchJob jobs[MATCH_MAX_BATCH];
@@ -1581,7 +1593,7 @@ int nm_sift_match_batch_dev_f32(int n, const float *const *A, const int *const *
         jobs[k] = MatchJob{A[k], B[k], capA, capB, 0, 0, result[k], nullptr, nullptr, nullptr, ws, d_nA[k], d_nB[k]};
         ws += pair_workspace_bytes(capA, capB);
     }
-    return run_fused_batch(jobs, n, ambiguity, nm_stream(stream));
+    return run_fused_batch(jobs, n, ambiguity, nm_stream(stream), phases);
 }
 
 int nm_sift_match_plan(int nA, int nB, int plan[10])

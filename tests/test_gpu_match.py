@@ -513,3 +513,28 @@ def test_nonfinite_pair_does_not_disturb_its_batch(nm, oracle, cuda):
     torch.cuda.synchronize()
     for k in range(3):
         assert np.array_equal(results[k].cpu().numpy(), refs[k]), k
+
+
+def test_match_phases_equal_the_whole_call(nm, oracle, cuda):
+    """nm_sift_match_batch_dev_phases_f32: PREP, SCREEN and FINISH issued as three calls (on one stream here) give what the
+    whole call gives; a phase mask outside 1..7 is refused."""
+    import torch
+    A = [_t(H.synth.descriptors(900 + k, 800), cuda) for k in range(2)]
+    B = [_t(H.synth.descriptors(950 + k, 1100), cuda) for k in range(2)]
+    nA = _t(np.array([800, 333], np.int32), cuda); nB = _t(np.array([1100, 999], np.int32), cuda)
+    args = (A, [nA[k:k + 1] for k in range(2)], B, [nB[k:k + 1] for k in range(2)])
+    whole = [torch.full((800,), -3, dtype=torch.int32, device=cuda) for _ in range(2)]
+    ws = nm.MatchBatchDevWorkspace(2, 800, 1100, cuda)
+    nm.sift_match_batch_dev(*args, whole, 0.8, workspace=ws)
+    parts = [torch.full((800,), -3, dtype=torch.int32, device=cuda) for _ in range(2)]
+    ws2 = nm.MatchBatchDevWorkspace(2, 800, 1100, cuda)
+    for ph in (nm.MATCH_PHASE_PREP, nm.MATCH_PHASE_SCREEN, nm.MATCH_PHASE_FINISH):
+        nm.sift_match_batch_dev(*args, parts, 0.8, workspace=ws2, phases=ph)
+    torch.cuda.synchronize()
+    for k, (na, nb) in enumerate(((800, 1100), (333, 999))):
+        assert torch.equal(whole[k], parts[k])
+        ref, _, _ = oracle.sift_matches(A[k][:na].cpu().numpy(), B[k][:nb].cpu().numpy(), 0.8, want_distance=False,
+                                        prior=np.full(na, -3, np.int32))
+        assert np.array_equal(whole[k][:na].cpu().numpy(), ref)
+    with pytest.raises(nm.NmError):
+        nm.sift_match_batch_dev(*args, parts, 0.8, workspace=ws2, phases=8)
