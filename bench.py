@@ -223,6 +223,9 @@ def roofline_pyramid(B, o0_ms, all_ms, traffic, nodog_ms=None, dogonly_ms=None):
                                   "avg_ms": round(dogonly_ms, 4), "us_per_frame": round(1e3 * dogonly_ms / B, 2),
                                   "achieved": round(alg108 / (dogonly_ms * 1e-3) / 1e9, 1),
                                   "frac": round(alg108 / (dogonly_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        t_do = traffic.get("pyramid_levels_dog_only", {}).get("hbm_bytes_per_frame")
+        if t_do:
+            out["levels_dog_only"].update({"traffic": t_do * B, "physical_GBps": round(t_do * B / (dogonly_ms * 1e-3) / 1e9, 1)})
     if nodog_ms:
         # what nm_sift_detect_describe_batch itself runs since round 2: the same chain WITHOUT materialised DoG planes (its
         # detection kernel subtracts consecutive levels): 48 B/px of Gaussian levels (+ 4 for level 5) + 36 of gradients

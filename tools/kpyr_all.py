@@ -2,8 +2,8 @@
 device: event-timed average, and -- under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` -- the dispatches that
 tools/pmc_traffic_total.py sums into HBM bytes per frame.   usage (the interpreter itself after `--`, never this file or env:
 the profiler initialises the GPU before the program starts, so any exec hop is forbidden on this pool):
-    rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_f --output-format csv -- python3 tools/kpyr_all.py 16 4 [nodog]
-    rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_w --output-format csv -- python3 tools/kpyr_all.py 16 4 [nodog]
+    rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_f --output-format csv -- python3 tools/kpyr_all.py 16 4 [nodog|dogonly]
+    rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_w --output-format csv -- python3 tools/kpyr_all.py 16 4 [nodog|dogonly]
 and, unprofiled:  python3 tools/kpyr_all.py [B=16] [reps=10]"""
 import os
 import sys
@@ -19,14 +19,16 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 frames = bench.make_frames(nm, torch, dev, list(range(B)))
 arenas = [nm.SiftArena(bench.W, bench.H, bench.CAP, device=dev) for _ in range(B)]
-dog = not (len(sys.argv) > 3 and sys.argv[3] == "nodog")       # third argument "nodog": the chain the frame driver runs
+mode = sys.argv[3] if len(sys.argv) > 3 else "all"             # "nodog": the chain the frame driver runs; "dogonly": levels + DoG
+dog = mode != "nodog"                                          # planes without the fused gradient planes (108 B/px workload)
+grad = mode != "dogonly"
 for _ in range(2):
-    nm.scale_space_batch(arenas, frames, write_dog=dog)
+    nm.scale_space_batch(arenas, frames, write_dog=dog, write_grad=grad)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(reps):
-    nm.scale_space_batch(arenas, frames, write_dog=dog)
+    nm.scale_space_batch(arenas, frames, write_dog=dog, write_grad=grad)
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
