@@ -25,6 +25,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA (~2.5 PF
 # MFMA flops the bf16x3 screen EXECUTES per algorithmic flop: 3 products per (a_k, b_k) + one 16-deep k-slot step for
 # the norms = (3 * 128 + 16) / 128
 BF16X3_EXECUTED_PER_ALGORITHMIC = (3 * 128 + 16) / 128.0
+F16_EXECUTED_PER_ALGORITHMIC = (128 + 16) / 128.0      # coarse pass of the two-stage screen: one product + the norm k-slot step
 # what a bare v_mfma_f32_32x32x16_bf16 loop sustains on this device (1.8 GHz under dense bf16 MFMA load):
 # profiles/r02_k_mfma_bf16_peak_microbench.txt. Reported beside the nominal peak, never instead of it.
 MFMA_BF16_SUSTAINED_MEASURED_TFLOPS = 1850.0
@@ -697,6 +698,20 @@ def main():
                 r = {"kernel": "match_top2_kernel<f32>", "bound": "mfma", "achieved": round(ach, 3),
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
                      "traffic": t_match}
+            elif scr == "f16":
+                # two-stage screen: the timed kernel is its coarse pass, ONE fp16 product per k (+ one 16-deep k-slot step for
+                # the norms: 1.125 executed flops per algorithmic flop) against the dense fp16 peak. The bf16x3 second pass
+                # over the ~1 % of the rows the coarse pass cannot prove is one launch per CALL and is in `value`, not here.
+                r = {"kernel": "match_top2_kernel<f16 coarse pass>", "bound": "mfma", "achieved": round(ach, 3),
+                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                     "executed_TFLOPs": round(ach * F16_EXECUTED_PER_ALGORITHMIC, 3),
+                     "frac_executed": round(ach * F16_EXECUTED_PER_ALGORITHMIC / MFMA_BF16_PEAK_TFLOPS, 4),
+                     "vs_f32_mfma_peak": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                     "traffic": traffic.get("match_top2_kernel_f16", {}).get("hbm_bytes_per_launch"),
+                     "note": "coarse pass on fp16 images (a_h.b_h, v_mfma_f32_32x32x16_f16); rows whose coarse result the "
+                             "residual-norm bound cannot prove are screened again on split bf16 operands; match decisions are "
+                             "made on distances recomputed exactly in fp32 (results bit-identical to the other screens and "
+                             "the oracle)"}
             else:
                 # against the dense peak of the dtype the MFMAs run in (bf16). The screen executes 3.125 bf16 flops per
                 # algorithmic flop, so the pipe is `frac_executed` busy; against the fp32-MFMA roofline the path's

@@ -233,6 +233,9 @@ NM_API int nm_sift_match_f32(const float *A, int nA, const float *B, int nB, flo
 /* Diagnostics: number of query rows of the LAST nm_sift_match_f32 / _shard_f32 call on `workspace` (same nA, nB) that took
  * the exact full-scan fallback because the MFMA candidate pass could not prove its top-2. Synchronises the stream. */
 NM_API int nm_sift_match_fallback_count(const void *workspace, int nA, int nB, int *host_count, void *stream);
+/* The same for the two-stage screen: rows whose coarse (fp16) result could not be proven and that the bf16x3 pass screened
+ * again. Meaningful after a call under screen 2 only (the counter is reset by such calls). Synchronises the stream. */
+NM_API int nm_sift_match_second_pass_count(const void *workspace, int nA, int nB, int *host_count, void *stream);
 /* Multi-GPU building blocks (no reference counterpart: the reference is single-GPU). A shard call scans the local
  * rows [0,nB_shard) of B and emits, per query row: min1 = the smallest non-NaN distance of the shard, index1 +
  * index_offset = its lowest index (-1 if the shard has no distance below +inf), min2 = the smallest of the shard's OTHER

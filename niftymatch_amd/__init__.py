@@ -59,6 +59,7 @@ _SIGNATURES = {
     "nm_sift_match_get_screen": (_I, []),
     "nm_sift_match_f32": (_I, [_P, _I, _P, _I, _P, _P, _F, _P, _P]),
     "nm_sift_match_fallback_count": (_I, [_P, _I, _I, _P, _P]),
+    "nm_sift_match_second_pass_count": (_I, [_P, _I, _I, _P, _P]),
     "nm_sift_match_shard_f32": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
     "nm_sift_match_merge_f32": (_I, [_P, _P, _P, _I, _I, _P, _F, _P]),
     "nm_sift_match_merge_packed_f32": (_I, [_P, _I, _I, _P, _F, _P]),
@@ -382,11 +383,12 @@ def sift_match_batch_dev(As, d_nAs, Bs, d_nBs, results, ambiguity=0.8, workspace
     return workspace
 
 
-MATCH_SCREENS = {"f32": 0, "bf16x3": 1}
+MATCH_SCREENS = {"f32": 0, "bf16x3": 1, "f16": 2}
 
 
 def set_match_screen(name):
-    """Select the MFMA screen of the fused matcher ("f32" or "bf16x3"; results are identical, see nm_abi.h)."""
+    """Select the MFMA screen of the fused matcher ("f32", "bf16x3" or the two-stage "f16"; results are identical, see
+    nm_abi.h)."""
     _check(lib().nm_sift_match_set_screen(MATCH_SCREENS[name]), "nm_sift_match_set_screen")
 
 
@@ -400,6 +402,14 @@ def match_fallback_count(workspace, nA, nB):
     n = C.c_int(0)
     _check(lib().nm_sift_match_fallback_count(_dev(workspace.buf), nA, nB, C.byref(n), _stream()),
            "nm_sift_match_fallback_count")
+    return n.value
+
+
+def match_second_pass_count(workspace, nA, nB):
+    """Two-stage screen: rows of the last match call on `workspace` (same sizes) that the bf16x3 pass screened again."""
+    n = C.c_int(0)
+    _check(lib().nm_sift_match_second_pass_count(_dev(workspace.buf), nA, nB, C.byref(n), _stream()),
+           "nm_sift_match_second_pass_count")
     return n.value
 
 

@@ -38,6 +38,8 @@ constexpr int MAX_CHUNKS = 64;     // upper bound of the number S of segments (p
 // <= 4e37). A query row outside it, or ANY candidate outside it, is matched by the exact fallback alone -- the reference's
 // scan, whose behaviour on NaN / inf distances (match.cu:91-116: comparisons with a NaN are false) is reproduced there.
 constexpr float NORM_LIMIT = 1.0e37f;
+// The fp16 coarse pass of the two-stage screen needs |2 x| <= 65504 for every element: squared norms below 1e9 (|x| < 31623).
+constexpr float F16_NORM_LIMIT = 1.0e9f;
 
 // Work = qblocks x T units, a unit being (256 queries) x (one 128-candidate tile). The grid is G persistent workgroups
 // (one per CU: the kernel owns the LDS), each taking a contiguous range of `base` or `base+1` units of a linear order:
@@ -215,6 +217,13 @@ struct MatchPair {
     int *idx1;
     unsigned *As, *Bs;         // bf16x3 screen: split images of A (scaled by -2) and B, 512 B per row (hi | lo)
     uint4 *nbslot;             // bf16x3 screen: the candidates' norm k-slots, padded to whole tiles
+    // two-stage screen (f16 coarse pass, then bf16x3 on the rows it could not prove): fp16 images of A (scaled by -2) and B,
+    // 256 B per row; the 2-norms of their rounding residuals a - a_h, b - b_h (rounded up); the list of unproven rows
+    // (its counter, the max of rb and the second work plan live in the pair's 256-byte counter block, see pair_f1_count)
+    // and the norms of the listed rows in list order. As above holds the split images of the LISTED rows in this mode.
+    unsigned *Ah, *Bh;
+    float *ra, *rb, *na2;
+    int *f1_list;
     int nA, nB, S, mode, index_offset;
     // Device-sized call (nm_sift_match_batch_dev_f32): the real sizes are read from device memory (what the frame driver
     // left in d_num_items), nA / nB above are the CAPACITIES every grid and the workspace are laid out for, and the work
@@ -226,12 +235,18 @@ struct MatchPair {
 __device__ __forceinline__ int pair_nA(const MatchPair &c) { return c.d_nA ? min(max(*c.d_nA, 0), c.nA) : c.nA; }
 __device__ __forceinline__ int pair_nB(const MatchPair &c) { return c.d_nB ? min(max(*c.d_nB, 0), c.nB) : c.nB; }
 __device__ __forceinline__ int pair_S(const MatchPair &c) { return c.d_plan ? c.d_plan->S : c.S; }
+// the pair's 256-byte counter block: [0] fallback count, [4] count of the rows the coarse pass left to the bf16x3 pass,
+// [16] max candidate norm, [17] max candidate residual norm, [32..41] device-side plan, [44..53] plan of the bf16x3 pass
+__device__ __forceinline__ int *pair_f1_count(const MatchPair &c) { return c.fb_count + 4; }
+__device__ __forceinline__ MatchPlan *pair_plan2(const MatchPair &c) { return reinterpret_cast<MatchPlan *>(c.fb_count + 44); }
 constexpr int MATCH_MAX_BATCH = 16;
 struct MatchBatch {
     MatchPair p[MATCH_MAX_BATCH];
     int n;
     float ambiguity;
     float err_coeff;           // |screen value - exact d| <= err_coeff (sqrt na + sqrt nb)^2 for the screen in use
+    float err_coeff2;          // two-stage screen: the same for its second (bf16x3) pass; err_coeff then covers the fp32
+                               // accumulation of the coarse pass only, the fp16 rounding enters through ra / rb
     int n_cu, n_xcd;           // device-sized calls: the geometry the device-side plan is made for
 };
 static_assert(sizeof(MatchBatch) <= 4096, "kernel arguments are limited to 4 KB");
@@ -266,16 +281,31 @@ constexpr unsigned BF16_BIG = 0x7F7Fu;      // largest finite bf16: the "norm" o
 // rows per wave in flight (a lane holds one float4 of two rows):
 //   * ||x||^2 as RN32 of a binary64 sum of exact squares (error <= 2^-24 relative: the screens' bounds count on it);
 //     rows past nB get +inf (fp32 screen) -- the MFMA kernels stage whole tiles;
-//   * SPLIT (bf16x3 screen): the row's split image [128 x bf16 hi | 128 x bf16 lo] (A is scaled by -2 first: exact), and
-//     for candidates the 16-byte k-slot (nb_h, nb_m, nb_l, 1, 1, 1, 0, 0) that adds the norms inside the MFMA chain.
+//   * MODE 1 (bf16x3 screen): the row's split image [128 x bf16 hi | 128 x bf16 lo] (A is scaled by -2 first: exact), and
+//     for candidates the 16-byte k-slot (nb_h, nb_m, nb_l, 1, 1, 1, 0, 0) that adds the norms inside the MFMA chain;
+//   * MODE 2 (two-stage screen): the same for the candidates only (the rows of A that need the bf16x3 pass are split
+//     later, fine_rows_kernel), plus the fp16 images [128 x fp16] of -2 A and of B (round to nearest even) and an upper
+//     bound of the 2-norm of each row's rounding residual x - x_h (x_h = what the image holds, unscaled).
 constexpr int PREP_ROWS = 16;       // rows per 256-thread workgroup
-template <bool SPLIT>
+__device__ __forceinline__ unsigned f16_bits(float x)
+{
+    const _Float16 h = (_Float16)x;                      // v_cvt_f16_f32: round to nearest even (the kernels never change the mode)
+    return (unsigned)__builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float f16_value(unsigned bits)
+{
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)bits);
+}
+template <int MODE>
 __global__ __launch_bounds__(256) void prep_kernel(MatchBatch bt)
 {
     const MatchPair &c = bt.p[blockIdx.y];
     const int nA = pair_nA(c), nB = pair_nB(c), lane = threadIdx.x & 63, k4 = lane & 31;
     const int padded = nm_divup_dev(nB, TILE_C) * TILE_C;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && c.fb_count) *c.fb_count = 0;   // first launch of a match call: resets the fallback list
+    if (blockIdx.x == 0 && threadIdx.x == 0 && c.fb_count) {     // first launch of a match call: resets the row lists
+        *c.fb_count = 0;
+        if (MODE == 2) *pair_f1_count(c) = 0;
+    }
     const int r0 = blockIdx.x * PREP_ROWS + (threadIdx.x >> 6) * 4 + (lane >> 5);    // this lane's rows: r0 and r0 + 2
     float4 v[2];
     int row[2]; bool isA[2], live[2];
@@ -295,7 +325,7 @@ __global__ __launch_bounds__(256) void prep_kernel(MatchBatch bt)
         if (!live[q]) {                                   // uniform per half wave
             if (i < padded && k4 == 0) {
                 c.nb[i] = __builtin_inff();
-                if (SPLIT) c.nbslot[i] = make_uint4(BF16_BIG, BF16_ONE << 16, BF16_ONE | (BF16_ONE << 16), 0u);
+                if (MODE) c.nbslot[i] = make_uint4(BF16_BIG, BF16_ONE << 16, BF16_ONE | (BF16_ONE << 16), 0u);
             }
             continue;
         }
@@ -304,8 +334,8 @@ __global__ __launch_bounds__(256) void prep_kernel(MatchBatch bt)
 #pragma unroll
         for (int d = 16; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
         const float nrm = (float)acc;
-        if (SPLIT) {
-            const float sc = isA[q] ? -2.0f : 1.0f;
+        const float sc = isA[q] ? -2.0f : 1.0f;
+        if (MODE == 1 || (MODE == 2 && !isA[q])) {
             unsigned h0, l0, h1, l1, h2, l2, h3, l3;
             bf16_split(sc * x.x, h0, l0); bf16_split(sc * x.y, h1, l1);
             bf16_split(sc * x.z, h2, l2); bf16_split(sc * x.w, h3, l3);
@@ -313,9 +343,28 @@ __global__ __launch_bounds__(256) void prep_kernel(MatchBatch bt)
             reinterpret_cast<uint2 *>(dst)[k4] = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
             reinterpret_cast<uint2 *>(dst + 64)[k4] = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
         }
+        float res = 0.f;
+        if (MODE == 2) {
+            const unsigned b0 = f16_bits(sc * x.x), b1 = f16_bits(sc * x.y), b2 = f16_bits(sc * x.z), b3 = f16_bits(sc * x.w);
+            unsigned *dst = (isA[q] ? c.Ah : c.Bh) + (size_t)i * (DIM / 2);
+            reinterpret_cast<uint2 *>(dst)[k4] = make_uint2(b0 | (b1 << 16), b2 | (b3 << 16));
+            // residual of what the image holds: x - x_h is exact in binary32 (x_h is x rounded to fewer bits; the scaling
+            // by -2 and back is exact). An infinite x_h (|2 x| beyond the fp16 range) gives an infinite residual: such
+            // rows lie outside the coarse pass's domain anyway (F16_NORM_LIMIT) and go to the bf16x3 pass.
+            const float inv = isA[q] ? -0.5f : 1.0f;
+            const float e0 = x.x - inv * f16_value(b0), e1 = x.y - inv * f16_value(b1);
+            const float e2 = x.z - inv * f16_value(b2), e3 = x.w - inv * f16_value(b3);
+            res = (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) res += __shfl_xor(res, d);
+            // upper bound of the residual's 2-norm: the 131 binary32 roundings above cost < 1e-5 relative, squares that
+            // underflow < 1e-18 absolute
+            res = __builtin_sqrtf(res) * 1.00002f + 1e-18f;
+        }
         if (k4 == 0) {
             (isA[q] ? c.na : c.nb)[i] = nrm;
-            if (SPLIT && !isA[q]) {
+            if (MODE == 2) (isA[q] ? c.ra : c.rb)[i] = res;
+            if (MODE && !isA[q]) {
                 unsigned h, m, l;
                 bf16_three(nrm, h, m, l);
                 c.nbslot[i] = (nrm < 3.0e38f) ? make_uint4(h | (m << 16), l | (BF16_ONE << 16), BF16_ONE | (BF16_ONE << 16), 0u)
@@ -325,10 +374,11 @@ __global__ __launch_bounds__(256) void prep_kernel(MatchBatch bt)
     }
 }
 
-// max_j ||b_j||^2 of every pair (one workgroup per pair): tightens the error bound of match_finalize_kernel.
+// max_j ||b_j||^2 of every pair (one workgroup per pair): tightens the error bound of match_finalize_kernel. Two-stage
+// screen (c.rb set): also the largest candidate residual norm, into the next float.
 __global__ __launch_bounds__(1024) void nbmax_kernel(MatchBatch bt)
 {
-    __shared__ float s[16];
+    __shared__ float s[32];
     const MatchPair &c = bt.p[blockIdx.x];
     const int nB = pair_nB(c);
     if (c.d_plan && threadIdx.x >= 960) {
@@ -344,15 +394,20 @@ __global__ __launch_bounds__(1024) void nbmax_kernel(MatchBatch bt)
     }
     // +inf as soon as one candidate norm is not a finite number below NORM_LIMIT (fmax would drop a NaN): the finalize
     // pass then sends EVERY row of the pair to the exact fallback, which is the reference's own scan
-    float m = 0.f;
-    for (int i = threadIdx.x; i < nB; i += 1024) { const float v = c.nb[i]; m = (v < NORM_LIMIT) ? __builtin_fmaxf(m, v) : __builtin_inff(); }
+    float m = 0.f, mr = 0.f;
+    for (int i = threadIdx.x; i < nB; i += 1024) {
+        const float v = c.nb[i];
+        m = (v < NORM_LIMIT) ? __builtin_fmaxf(m, v) : __builtin_inff();
+        if (c.rb) { const float e = c.rb[i]; mr = (e < NORM_LIMIT) ? __builtin_fmaxf(mr, e) : __builtin_inff(); }
+    }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, d));
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
+    for (int d = 32; d >= 1; d >>= 1) { m = __builtin_fmaxf(m, __shfl_xor(m, d)); mr = __builtin_fmaxf(mr, __shfl_xor(mr, d)); }
+    if ((threadIdx.x & 63) == 0) { s[threadIdx.x >> 6] = m; s[16 + (threadIdx.x >> 6)] = mr; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; ++w) m = __builtin_fmaxf(m, s[w]);
-        *c.nbmax = m;
+        for (int w = 1; w < 16; ++w) { m = __builtin_fmaxf(m, s[w]); mr = __builtin_fmaxf(mr, s[16 + w]); }
+        c.nbmax[0] = m;
+        c.nbmax[1] = mr;
     }
 }
 
@@ -572,20 +627,93 @@ __device__ __forceinline__ void mfma_half_bf16(f32x16 &acc0, f32x16 &acc1, const
 }
 #undef NM_MFMA
 
-// BF16 = false: A, B are the fp32 descriptor rows. BF16 = true: A, B are the split images written by prep_kernel<true>
-// (same 512-byte rows, so the staging is identical) and nbslot replaces nb.
+// The coarse pass of the two-stage screen: ONE product per k (v_mfma_f32_32x32x16_f16 on the fp16 images of -2 A and B:
+// 8 + 1 MFMAs per accumulator and 64-candidate group instead of 24 + 1), norms through the same bf16 k-slot instruction.
+// Its value differs from the exact distance by the fp16 rounding of the operands, which match_finalize_kernel<1> bounds
+// per row from the residual norms (prep_kernel<2>); the rows it cannot prove are screened again by the bf16x3 kernel.
+// tb = this lane's candidate row of group 0 in the tile image (256-byte rows, 16-byte chunks XOR-swizzled by row & 15);
+// foff[t] = byte offset of the lane's chunk of k-step t; group 1 = + 32 rows. qf[s] = the query's k-step s (k = 16 s + 8 h ..+7).
+#define NM_MFMA_H "v_mfma_f32_32x32x16_f16 "
+template <bool SELECT, int E0>
+__device__ __forceinline__ void f16_kstep(f32x16 &acc0, f32x16 &acc1, const u32x4 h0, const u32x4 h1, const u32x4 qh,
+                                          float p0, float p1, float p2, float p3, int &g1, int &g2, int &g3)
+{
+    if (SELECT) {
+        int k;
+        const int mask = ~((1 << KEY_SLOT_BITS) - 1);
+        asm volatile(NM_MFMA_H "%0, %6, %8, %0\n\t"
+                     "v_and_or_b32 %5, %9, %13, %14\n\t"
+                     "v_med3_i32 %4, %3, %4, %5\n\t"
+                     "v_med3_i32 %3, %2, %3, %5\n\t"
+                     "v_min_i32 %2, %2, %5\n\t"
+                     "v_and_or_b32 %5, %10, %13, %15\n\t"
+                     "v_med3_i32 %4, %3, %4, %5\n\t"
+                     "v_med3_i32 %3, %2, %3, %5\n\t"
+                     "v_min_i32 %2, %2, %5\n\t"
+                     NM_MFMA_H "%1, %7, %8, %1\n\t"
+                     "v_and_or_b32 %5, %11, %13, %16\n\t"
+                     "v_med3_i32 %4, %3, %4, %5\n\t"
+                     "v_med3_i32 %3, %2, %3, %5\n\t"
+                     "v_min_i32 %2, %2, %5\n\t"
+                     "v_and_or_b32 %5, %12, %13, %17\n\t"
+                     "v_med3_i32 %4, %3, %4, %5\n\t"
+                     "v_med3_i32 %3, %2, %3, %5\n\t"
+                     "v_min_i32 %2, %2, %5"
+                     : "+v"(acc0), "+v"(acc1), "+v"(g1), "+v"(g2), "+v"(g3), "=&v"(k)
+                     : "v"(h0), "v"(h1), "v"(qh), "v"(p0), "v"(p1), "v"(p2), "v"(p3), "s"(mask),
+                       "n"(E0), "n"(E0 + 1), "n"(E0 + 2), "n"(E0 + 3)
+                     : "memory");
+    } else {
+        asm volatile(NM_MFMA_H "%0, %2, %4, %0\n\t" NM_MFMA_H "%1, %3, %4, %1"
+                     : "+v"(acc0), "+v"(acc1) : "v"(h0), "v"(h1), "v"(qh) : "memory");
+    }
+}
+
+template <bool SELECT>
+__device__ __forceinline__ void mfma_half_f16(f32x16 &acc0, f32x16 &acc1, const f32x16 &prev0, const f32x16 &prev1,
+                                              const char *tb, const unsigned (&foff)[8], const char *slotp,
+                                              const u32x4 (&qf)[16], const u32x4 qslot, int &g1, int &g2, int &g3)
+{
+    constexpr int G1 = 32 * 256;
+    u32x4 h0 = *reinterpret_cast<const u32x4 *>(tb + foff[0]), h1 = *reinterpret_cast<const u32x4 *>(tb + G1 + foff[0]);
+    const u32x4 s0 = *reinterpret_cast<const u32x4 *>(slotp), s1 = *reinterpret_cast<const u32x4 *>(slotp + 32 * 16);
+    // the norms (bf16 k-slots, as in the bf16x3 kernel); the wait states also separate the two MFMA types on one accumulator
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %4, 0\n\tv_mfma_f32_32x32x16_bf16 %1, %3, %4, 0\n\ts_nop 15\n\ts_nop 3"
+                 : "=&v"(acc0), "=&v"(acc1) : "v"(s0), "v"(s1), "v"(qslot) : "memory");
+#define NM_KSTEP(T)                                                                                                      \
+    {                                                                                                                    \
+        u32x4 nh0 = h0, nh1 = h1;                                                                                        \
+        if (T + 1 < 8) { /* next k-step's fragments fly during this step's MFMAs */                                      \
+            nh0 = *reinterpret_cast<const u32x4 *>(tb + foff[(T + 1) & 7]);                                              \
+            nh1 = *reinterpret_cast<const u32x4 *>(tb + G1 + foff[(T + 1) & 7]);                                         \
+        }                                                                                                                \
+        const f32x16 &pv = (T < 4) ? prev0 : prev1;                                                                      \
+        f16_kstep<SELECT, 4 * T>(acc0, acc1, h0, h1, qf[T], pv[(4 * T) & 15], pv[(4 * T + 1) & 15],                        \
+                                 pv[(4 * T + 2) & 15], pv[(4 * T + 3) & 15], g1, g2, g3);                                 \
+        h0 = nh0; h1 = nh1;                                                                                              \
+    }
+    NM_KSTEP(0) NM_KSTEP(1) NM_KSTEP(2) NM_KSTEP(3) NM_KSTEP(4) NM_KSTEP(5) NM_KSTEP(6) NM_KSTEP(7)
+#undef NM_KSTEP
+}
+#undef NM_MFMA_H
+
+// SCR 0 (fp32 screen): A, B are the fp32 descriptor rows. SCR 1 (bf16x3): A, B are the split images written by prep_kernel
+// (same 512-byte rows) and nbslot replaces nb. SCR 2 (coarse pass of the two-stage screen): A, B are the fp16 images
+// (256-byte rows), nbslot as for bf16x3.
 // Device-sized launches (d_plan != NULL): nA_arg / nB_arg are the capacities, the real sizes and the plan made for them
 // (nbmax_kernel) are read from device memory, and the grid is one workgroup per CU of which the first plan.G work.
-template <bool BF16>
-__global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restrict__ A, int nA_arg,
-                                                           const float *__restrict__ B, int nB_arg,
-                                                           const float *__restrict__ na, const float *__restrict__ nb,
-                                                           const uint4 *__restrict__ nbslot,
-                                                           MatchPlan plan_arg, float4 *__restrict__ partial,
-                                                           float *__restrict__ partial3,
-                                                           const int *__restrict__ d_nA, const int *__restrict__ d_nB,
-                                                           const MatchPlan *__restrict__ d_plan)
+template <int SCR>
+__device__ __forceinline__ void match_top2_body(const float *__restrict__ A, int nA_arg,
+                                                const float *__restrict__ B, int nB_arg,
+                                                const float *__restrict__ na, const float *__restrict__ nb,
+                                                const uint4 *__restrict__ nbslot,
+                                                MatchPlan plan_arg, float4 *__restrict__ partial,
+                                                float *__restrict__ partial3,
+                                                const int *__restrict__ d_nA, const int *__restrict__ d_nB,
+                                                const MatchPlan *__restrict__ d_plan)
 {
+    constexpr bool BF16 = SCR == 1, F16 = SCR == 2, DMA = SCR != 0;
+    constexpr int ROWB = F16 ? DIM * 2 : DIM * 4;         // bytes per row of the A / B images this screen reads
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -594,7 +722,8 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
     int nA = nA_arg, nB = nB_arg;
     MatchPlan plan = plan_arg;
     if (d_plan) {                                         // uniform: scalar loads
-        nA = min(max(*d_nA, 0), nA_arg); nB = min(max(*d_nB, 0), nB_arg);
+        if (d_nA) nA = min(max(*d_nA, 0), nA_arg);
+        if (d_nB) nB = min(max(*d_nB, 0), nB_arg);
         plan = *d_plan;
         if (nA <= 0 || nB <= 0 || wg >= plan.G) return;   // an empty set is a no-op for the pair, as in the reference
     }
@@ -606,8 +735,8 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
     it.init(u_begin, u_end);
 
     // range-checked views: rows >= nB / nA read as zeros (the host refuses sets of 2^22 rows or more)
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, nB * (DIM * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, nA * (DIM * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, nB * ROWB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, nA * ROWB, 0x00020000);
     const int voff = (srow * DIM + scol) * 4;
 
     u32x4 st[8];
@@ -618,7 +747,7 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
 #pragma unroll
         for (int it = 0; it < 8; ++it) st[it] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voff, (jb + 16 * it) * (DIM * 4), 0);
         if (tid < TILE_C) {                               // padded up to T * 128 by prep_kernel
-            if (BF16) sts = nbslot[jb + tid];
+            if (DMA) sts = nbslot[jb + tid];
             else stn = nb[jb + tid];
         }
     };
@@ -626,7 +755,7 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
 #pragma unroll
         for (int it = 0; it < 8; ++it) *reinterpret_cast<u32x4 *>(&buf[(srow + 16 * it) * KP + scol]) = st[it];
         if (tid < TILE_C) {                               // augmented k-pair / k-slot
-            if (BF16) *reinterpret_cast<uint4 *>(&buf[tid * KP + DIM]) = sts;
+            if (DMA) *reinterpret_cast<uint4 *>(&buf[tid * KP + DIM]) = sts;
             else *reinterpret_cast<float2 *>(&buf[tid * KP + DIM]) = make_float2(stn, 1.0f);
         }
     };
@@ -636,22 +765,30 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
     // padding; bank conflicts are avoided by XOR-swizzling the 16-byte chunks of a row with (row & 15) -- applied to the
     // per-lane SOURCE address here and to the fragment reads' offsets (foff), the same involution on both sides. The
     // 16-byte norm slots live in their own 2 KiB per buffer behind the two 64 KiB images (same total as the padded layout).
-    constexpr int IMG = TILE_C * DIM * 4, SLOT0 = 2 * IMG, SLOTB = TILE_C * 16;
+    // The coarse pass (fp16 images, 256-byte rows) does the same with four rows per wave-instruction and a 32 KiB image.
+    constexpr int IMG = TILE_C * ROWB, SLOT0 = 2 * IMG, SLOTB = TILE_C * 16;
+    constexpr int DMA_N = IMG / (8 * 1024);               // wave-instructions per wave and tile: 8 (512-byte rows) or 4
     char *const ldsb = reinterpret_cast<char *>(lds);
     unsigned foff[8], dvoff[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         foff[t] = (unsigned)(((2 * t + h) ^ (r & 15)) << 4);
-        const int p = lane & 31, key = (2 * t + (lane >> 5)) & 15;        // wave-instruction t of a wave covers rows 2 (8 wave + t) + (lane >> 5)
-        dvoff[t] = (unsigned)((lane >> 5) * (DIM * 4) + (((p & 16) | ((p & 15) ^ key)) << 4));
+        if (F16) {                                        // wave-instruction t of a wave covers rows 4 (4 wave + t) + (lane >> 4)
+            const int p = lane & 15, key = (4 * t + (lane >> 4)) & 15;
+            dvoff[t] = (unsigned)((lane >> 4) * ROWB + ((p ^ key) << 4));
+        } else {
+            const int p = lane & 31, key = (2 * t + (lane >> 5)) & 15;    // wave-instruction t of a wave covers rows 2 (8 wave + t) + (lane >> 5)
+            dvoff[t] = (unsigned)((lane >> 5) * (DIM * 4) + (((p & 16) | ((p & 15) ^ key)) << 4));
+        }
     }
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // scalar for the compiler: M0 and the scalar offset depend on it
     auto dma_tile = [&](int tile, int b) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
+        for (int t = 0; t < DMA_N; ++t) {
             typedef __attribute__((address_space(3))) void lds_void;
-            lds_void *dst = (lds_void *)(ldsb + b * IMG + (wave_u * 8 + t) * 1024);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, dst, 16, (int)dvoff[t], (tile * TILE_C + 2 * (wave_u * 8 + t)) * (DIM * 4), 0, 0);
+            lds_void *dst = (lds_void *)(ldsb + b * IMG + (wave_u * DMA_N + t) * 1024);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, dst, 16, (int)dvoff[t],
+                                                     (tile * TILE_C + (1024 / ROWB) * (wave_u * DMA_N + t)) * ROWB, 0, 0);
         }
     };
 
@@ -666,12 +803,21 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
 
         // ---- segment prologue: the first candidate tile is requested first (its latency hides behind the query staging),
         //      queries -> LDS (coalesced) -> per-lane MFMA fragments in VGPRs ----
-        if (BF16) { if (tid < TILE_C) sts = nbslot[t0 * TILE_C + tid]; }
+        if (DMA) { if (tid < TILE_C) sts = nbslot[t0 * TILE_C + tid]; }
         else stage_load(t0);
+        constexpr int QP16 = ROWB + 16;     // coarse pass: LDS pitch of a staged query row (272 B: b128 reads conflict-free)
+        if (F16) {
 #pragma unroll 4
-        for (int it = 0; it < QB / 16; ++it) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff, (i0 + 16 * it) * (DIM * 4), 0);
-            *reinterpret_cast<u32x4 *>(&lds[(srow + 16 * it) * KP + scol]) = v;
+            for (int it = 0; it < QB / 32; ++it) {       // 32 rows x 16 chunks of 16 B per pass
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsA, ((tid >> 4) * ROWB + (tid & 15) * 16), (i0 + 32 * it) * ROWB, 0);
+                *reinterpret_cast<u32x4 *>(ldsb + ((tid >> 4) + 32 * it) * QP16 + (tid & 15) * 16) = v;
+            }
+        } else {
+#pragma unroll 4
+            for (int it = 0; it < QB / 16; ++it) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff, (i0 + 16 * it) * (DIM * 4), 0);
+                *reinterpret_cast<u32x4 *>(&lds[(srow + 16 * it) * KP + scol]) = v;
+            }
         }
         __syncthreads();
         float4 qf[16];
@@ -679,7 +825,9 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
         const int qi = i0 + wave * 32 + r;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {      // the -2 of  |a|^2 + |b|^2 - 2 a.b  rides on the query fragments (once per segment)
-            if (BF16) {                     // hi pieces of k-steps 0..7, then the lo pieces (prep_kernel applied the -2)
+            if (F16) {                      // k-steps 0..7 (prep_kernel applied the -2); the upper half of qw is unused
+                if (t < 8) qw[t] = *reinterpret_cast<const u32x4 *>(ldsb + (wave * 32 + r) * QP16 + 32 * t + 16 * h);
+            } else if (BF16) {              // hi pieces of k-steps 0..7, then the lo pieces (prep_kernel applied the -2)
                 qw[t] = *reinterpret_cast<const u32x4 *>(&lds[(wave * 32 + r) * KP + 8 * t + 4 * h]);
             } else {
                 const float4 v = *reinterpret_cast<const float4 *>(&lds[(wave * 32 + r) * KP + 8 * t + 4 * h]);
@@ -689,13 +837,13 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
         const float nav = (qi < nA) ? na[qi] : 0.f;
         const float nq = (h == 0) ? 1.0f : nav;
         u32x4 qslot = {0u, 0u, 0u, 0u};     // k-slots (1, 1, 1, na_h, na_m, na_l, 0, 0) on the lanes that hold k = 0..7
-        if (BF16 && h == 0) {
+        if (DMA && h == 0) {
             unsigned nh, nm, nl;
             bf16_three(nav, nh, nm, nl);
             qslot = (u32x4){BF16_ONE | (BF16_ONE << 16), BF16_ONE | (nh << 16), nm | (nl << 16), 0u};
         }
         __syncthreads();
-        if (BF16) {
+        if (DMA) {
             dma_tile(t0, 0);
             if (tid < TILE_C) *reinterpret_cast<uint4 *>(ldsb + SLOT0 + tid * 16) = sts;
             // A wave's LDS-DMA rows are read by all 8 waves after the barrier: every wave must have drained ITS transfers
@@ -714,7 +862,7 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
         // A wave multiplies its 32 queries with 64 candidates at a time (two 32 x 32 accumulators), then folds the 32
         // values each lane holds into its running triple. Within a lane the candidate index increases with (tile, half, g, e).
         f32x16 a0, a1;
-        if (BF16) {
+        if (DMA) {
             // software pipeline over the 64-candidate groups: the MFMAs of group i run while group i - 1 is selected
             f32x16 b0, b1;
             auto fold = [&](int g1, int g2, int g3, int tag) {
@@ -728,7 +876,7 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
             // last barrier); the barrier at the end of tile n waits for it (vmcnt(0), emitted by the compiler)
             for (int n = 0; n < ntiles; ++n) {
                 const int b = n & 1;
-                const char *tb = ldsb + b * IMG + r * (DIM * 4);
+                const char *tb = ldsb + b * IMG + r * ROWB;
                 const char *sp = ldsb + SLOT0 + b * SLOTB + r * 16;
                 if (n + 1 < ntiles) {
                     if (tid < TILE_C) sts = nbslot[(t0 + n + 1) * TILE_C + tid];
@@ -736,13 +884,16 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
                 }
                 int g1 = KEY_INF, g2 = KEY_INF, g3 = KEY_INF;
                 if (n == 0) {
-                    mfma_half_bf16<false>(a0, a1, b0, b1, tb, foff, sp, qw, qslot, g1, g2, g3);
+                    if (F16) mfma_half_f16<false>(a0, a1, b0, b1, tb, foff, sp, qw, qslot, g1, g2, g3);
+                    else mfma_half_bf16<false>(a0, a1, b0, b1, tb, foff, sp, qw, qslot, g1, g2, g3);
                 } else {
-                    mfma_half_bf16<true>(a0, a1, b0, b1, tb, foff, sp, qw, qslot, g1, g2, g3);
+                    if (F16) mfma_half_f16<true>(a0, a1, b0, b1, tb, foff, sp, qw, qslot, g1, g2, g3);
+                    else mfma_half_bf16<true>(a0, a1, b0, b1, tb, foff, sp, qw, qslot, g1, g2, g3);
                     fold(g1, g2, g3, 2 * n - 1);
                 }
                 g1 = g2 = g3 = KEY_INF;
-                mfma_half_bf16<true>(b0, b1, a0, a1, tb + 64 * (DIM * 4), foff, sp + 64 * 16, qw, qslot, g1, g2, g3);
+                if (F16) mfma_half_f16<true>(b0, b1, a0, a1, tb + 64 * ROWB, foff, sp + 64 * 16, qw, qslot, g1, g2, g3);
+                else mfma_half_bf16<true>(b0, b1, a0, a1, tb + 64 * ROWB, foff, sp + 64 * 16, qw, qslot, g1, g2, g3);
                 fold(g1, g2, g3, 2 * n);
                 if (n + 1 < ntiles && tid < TILE_C) *reinterpret_cast<uint4 *>(ldsb + SLOT0 + (b ^ 1) * SLOTB + tid * 16) = sts;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile n + 1 has landed (this wave's share): see the prologue
@@ -800,6 +951,29 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
     }
 }
 
+template <int SCR>
+__global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restrict__ A, int nA_arg,
+                                                           const float *__restrict__ B, int nB_arg,
+                                                           const float *__restrict__ na, const float *__restrict__ nb,
+                                                           const uint4 *__restrict__ nbslot,
+                                                           MatchPlan plan_arg, float4 *__restrict__ partial,
+                                                           float *__restrict__ partial3,
+                                                           const int *__restrict__ d_nA, const int *__restrict__ d_nB,
+                                                           const MatchPlan *__restrict__ d_plan)
+{
+    match_top2_body<SCR>(A, nA_arg, B, nB_arg, na, nb, nbslot, plan_arg, partial, partial3, d_nA, d_nB, d_plan);
+}
+
+// Second pass of the two-stage screen, all pairs of a call in ONE launch (blockIdx.y = pair): the bf16x3 screen on the
+// rows the coarse pass listed (fine_rows_kernel wrote their split images, norms and the work plan for their number).
+// Usually a percent of the rows: most workgroups find plan.G below their index and leave.
+__global__ __launch_bounds__(512, 2) void match_top2_rows_kernel(MatchBatch bt)
+{
+    const MatchPair &c = bt.p[blockIdx.y];
+    match_top2_body<1>(reinterpret_cast<const float *>(c.As), c.nA, reinterpret_cast<const float *>(c.Bs), c.nB, c.na2, c.nb,
+                       c.nbslot, MatchPlan{}, c.partial, c.partial3, pair_f1_count(c), c.d_nB, pair_plan2(c));
+}
+
 __device__ __forceinline__ float exact_dist(const float4 *__restrict__ a, const float4 *__restrict__ b)
 {
     float4 x[DIM / 4], y[DIM / 4];
@@ -843,12 +1017,20 @@ __device__ __forceinline__ void emit_match(int i, float m1, int idx, float m2, i
 // Proof obligation: every candidate NOT recomputed has an approximate distance >= rest (the minimum over the chunks'
 // third-best values and everything that dropped out of a top-4 list). If rest is not safely above the exact min2
 // (margin = bound on the MFMA formulation's error), the query is appended to the fallback list instead of being emitted.
+//
+// STAGE 0: the single-pass screens (fp32, bf16x3). Two-stage screen: STAGE 1 after the fp16 coarse pass -- the same proof
+// with the coarse pass's error bound (below); an unproven row goes to the list of the bf16x3 pass instead of the exact
+// fallback -- and STAGE 2 after the bf16x3 pass over the listed rows: partial lists, norms and the row count are in list
+// order (r), everything else belongs to row i = f1_list[r].
+template <int STAGE>
 __global__ __launch_bounds__(256) void match_finalize_kernel(MatchBatch bt)
 {
     const MatchPair &c = bt.p[blockIdx.y];
     const float *__restrict__ A = c.A, *__restrict__ B = c.B;
-    const int nA = pair_nA(c), S = pair_S(c), mode = c.mode, index_offset = c.index_offset;
-    if (nA <= 0 || pair_nB(c) <= 0) return;              // device-sized call with an empty set: nothing was screened
+    const int mode = c.mode, index_offset = c.index_offset;
+    if (pair_nA(c) <= 0 || pair_nB(c) <= 0) return;      // device-sized call with an empty set: nothing was screened
+    const int nA = (STAGE == 2) ? min(max(*pair_f1_count(c), 0), pair_nA(c)) : pair_nA(c);
+    const int S = (STAGE == 2) ? pair_plan2(c)->S : pair_S(c);
     if ((int)blockIdx.x * 64 >= nA) return;              // grids are sized for the batch's largest set (or the capacity)
     const float4 *__restrict__ partial = c.partial;
     const float *__restrict__ partial3 = c.partial3;
@@ -859,9 +1041,10 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(MatchBatch bt)
     int *__restrict__ idx_out = c.idx1;
     int *__restrict__ fb_count = c.fb_count, *__restrict__ fb_list = c.fb_list;
     const int t = blockIdx.x * 256 + threadIdx.x;
-    const int i = t >> 2, sub = t & 3;
-    const bool live = i < nA;
-    const int iq = live ? i : nA - 1;
+    const int sub = t & 3;
+    const bool live = (t >> 2) < nA;
+    const int iq = live ? (t >> 2) : nA - 1;             // row of the partial lists
+    const int i = (STAGE == 2) ? c.f1_list[iq] : iq;     // row of A / of the outputs
     float cd[4]; int ci[4];
     float rest = __builtin_inff();
 #pragma unroll
@@ -900,14 +1083,22 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(MatchBatch bt)
     const int mine = (sub == 0) ? ci[0] : (sub == 1) ? ci[1] : (sub == 2) ? ci[2] : ci[3];
     float d = 0.f;
     if (mine >= 0)
-        d = exact_dist(reinterpret_cast<const float4 *>(A + (size_t)iq * DIM),
+        d = exact_dist(reinterpret_cast<const float4 *>(A + (size_t)i * DIM),
                        reinterpret_cast<const float4 *>(B + (size_t)mine * DIM));
     float ed[4]; int ei[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { ed[k] = __shfl(d, ((threadIdx.x & 63) & ~3) + k); ei[k] = ci[k]; }
     if (!live || sub != 0) return;
     const float nai = na[i];
-    if (!(nai < NORM_LIMIT) || !(*c.nbmax < NORM_LIMIT)) {           // outside the screens' domain (NaN, inf, huge): exact scan
+    if (STAGE == 1) {
+        // outside the coarse pass's domain (|2 x| must stay inside the fp16 range: squared norms below F16_NORM_LIMIT; NaN and
+        // inf fail the comparison too): the bf16x3 pass decides, or passes the row on to the exact scan
+        if (!(nai < F16_NORM_LIMIT) || !(*c.nbmax < F16_NORM_LIMIT)) {
+            const int pos = atomicAdd(pair_f1_count(c), 1);
+            c.f1_list[pos] = i;
+            return;
+        }
+    } else if (!(nai < NORM_LIMIT) || !(*c.nbmax < NORM_LIMIT)) {    // outside the screens' domain (NaN, inf, huge): exact scan
         const int pos = atomicAdd(fb_count, 1);
         fb_list[pos] = i;
         return;
@@ -934,17 +1125,69 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(MatchBatch bt)
     // sqrt na + sqrt nb_max):  value(j) <= (M + 2 gamma_129 s^2) (1 + 2^-18) =: bound, and rest <= value(j) <= bound.
     // Hence rest > bound proves the row; otherwise the row is re-scanned exactly. Deterministic for every input
     // (2 gamma_129 = 1.5378e-5; the constants below carry the slop of evaluating the bound itself in fp32).
-    const float sq = __builtin_fminf(2.0f * __builtin_sqrtf(nai) + __builtin_sqrtf(m2),
-                                     __builtin_sqrtf(nai) + __builtin_sqrtf(*c.nbmax));
-    const float bound = (m2 * 1.00001f + bt.err_coeff * (sq * sq)) * 1.00001f + 1e-30f;      // 1 + 2^-17 = 1.0000076
-    const float margin = bound - m2;
-    (void)margin;
-    if (rest <= bound && rest < __builtin_inff()) {
-        const int pos = atomicAdd(fb_count, 1);
-        fb_list[pos] = i;
+    const float sna = __builtin_sqrtf(nai);
+    const float sq = __builtin_fminf(2.0f * sna + __builtin_sqrtf(m2), sna + __builtin_sqrtf(*c.nbmax));
+    float bound = (m2 * 1.00001f + (STAGE == 2 ? bt.err_coeff2 : bt.err_coeff) * (sq * sq)) * 1.00001f + 1e-30f;      // 1 + 2^-17 = 1.0000076
+    if (STAGE == 1) {
+        // Coarse pass: the MFMA chain sums the norms and the EXACT products of the fp16 images a_h (= -image / 2) and b_h,
+        // so err_coeff sq^2 above bounds its distance from  na + nb - 2 a_h.b_h  (134 terms instead of 130: the coefficient
+        // carries a factor 2 of slack), and   a.b - a_h.b_h = e_a.b_h + a_h.e_b + e_a.e_b   with e = x - x_h gives
+        //   |d~(j) - d(j)| <= err_coeff sq^2 + 2 (ra |b_h| + |a_h| rb_j + ra rb_j),   ra = |e_a|, rb_j = |e_b_j|  (Cauchy-Schwarz),
+        // ra and rb_j being the upper bounds prep_kernel<2> computed from the images themselves. For a candidate with
+        // d_ref(j) <= m2:  |b_j| <= bn := sq - sqrt na  (the triangle inequality / nb_max, as above),  |b_h| <= bn + rb_j,
+        // |a_h| <= sqrt na + ra,  and  rb_j <= min(rb_max, 2^-11 bn + 7e-4): round-to-nearest fp16 loses at most 2^-11
+        // relative per element, 2^-14 absolute per element of the 128 below the normal range (subnormal or flushed alike).
+        const float bn = (sq - sna) * 1.000001f;
+        const float rbj = __builtin_fminf(c.nbmax[1], 4.8829e-4f * bn + 7e-4f);
+        const float rai = c.ra[i];
+        const float e16 = 2.0f * (rai * (bn + rbj) + (sna * 1.000001f + rai) * rbj + rai * rbj);
+        bound = (bound + e16 * 1.00001f) * 1.00001f;
+    }
+    if (!(rest > bound) && rest < __builtin_inff()) {    // a NaN bound (norms at the edge of the domain) proves nothing
+        if (STAGE == 1) {
+            const int pos = atomicAdd(pair_f1_count(c), 1);
+            c.f1_list[pos] = i;
+        } else {
+            const int pos = atomicAdd(fb_count, 1);
+            fb_list[pos] = i;
+        }
         return;
     }
     emit_match(i, m1, idx + index_offset, m2, mode, ambiguity, result, min1_out, idx_out, min2_out);
+}
+
+// Two-stage screen, between its passes: the rows the coarse pass listed get what the bf16x3 kernel reads -- split images
+// (scaled by -2) and norms in LIST order -- and the first wave of every pair makes the work plan for their number (the
+// same make_plan_on as everywhere). Half a wave per listed row, as in prep_kernel.
+__global__ __launch_bounds__(256) void fine_rows_kernel(MatchBatch bt)
+{
+    const MatchPair &c = bt.p[blockIdx.y];
+    const int nA = pair_nA(c), nB = pair_nB(c), lane = threadIdx.x & 63, k4 = lane & 31;
+    const int count = (nA > 0 && nB > 0) ? min(max(*pair_f1_count(c), 0), nA) : 0;
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        const MatchPlan p = make_plan_on(count, nB, bt.n_cu, bt.n_xcd, lane, 64, [](int v) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d));
+            return v;
+        });
+        MatchPlan q = p;
+        if (count == 0) q.G = 0;                          // nothing listed: every workgroup of the second pass leaves at once
+        if (lane == 0) *pair_plan2(c) = q;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int r = blockIdx.x * PREP_ROWS + (threadIdx.x >> 6) * 4 + (lane >> 5) + 2 * q;
+        if (r >= count) continue;
+        const int i = c.f1_list[r];
+        const float4 x = reinterpret_cast<const float4 *>(c.A + (size_t)i * DIM)[k4];
+        unsigned h0, l0, h1, l1, h2, l2, h3, l3;
+        bf16_split(-2.0f * x.x, h0, l0); bf16_split(-2.0f * x.y, h1, l1);
+        bf16_split(-2.0f * x.z, h2, l2); bf16_split(-2.0f * x.w, h3, l3);
+        unsigned *dst = c.As + (size_t)r * DIM;
+        reinterpret_cast<uint2 *>(dst)[k4] = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+        reinterpret_cast<uint2 *>(dst + 64)[k4] = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+        if (k4 == 0) c.na2[r] = c.na[i];
+    }
 }
 
 // Exact squared distances, the reference's own arithmetic (match.cu:36-42): for every (row vector x, column vector y)
@@ -1346,25 +1589,28 @@ __global__ __launch_bounds__(256) void set_matches_kernel(int *__restrict__ resu
     }
 }
 
-struct MatchWs { float *na, *nb; float4 *partial; float *partial3; int *fb_count, *fb_list; unsigned *As, *Bs; uint4 *nbslot; };
+struct MatchWs { float *na, *nb; float4 *partial; float *partial3; int *fb_count, *fb_list; unsigned *As, *Bs; uint4 *nbslot;
+                 unsigned *Ah, *Bh; float *ra, *rb, *na2; int *f1_list; };
 
 // Which MFMA screen match_top2 runs: 0 = fp32 (v_mfma_f32_32x32x2_f32, K = 128 exact products), 1 = bf16x3 (split
-// operands on v_mfma_f32_32x32x16_bf16). Both feed the same exact finalize / fallback, so the results are identical;
-// the bf16x3 screen is ~3x faster and sends a few more rows to the exact fallback. NM_MATCH_SCREEN=f32|bf16x3 or
-// nm_sift_match_set_screen() select it (process-wide).
+// operands on v_mfma_f32_32x32x16_bf16), 2 = two-stage (a coarse pass with ONE fp16 product per k on
+// v_mfma_f32_32x32x16_f16, then the bf16x3 screen on the rows -- about a percent on SIFT data -- whose coarse result
+// cannot be proven). All feed the same exact finalize / fallback, so the results are identical; only the time differs.
+// NM_MATCH_SCREEN=f32|bf16x3|f16 or nm_sift_match_set_screen() select it (process-wide).
 static std::atomic<int> g_screen{-1};
 static int match_screen()
 {
     int v = g_screen.load(std::memory_order_relaxed);
     if (v < 0) {
         const char *e = getenv("NM_MATCH_SCREEN");
-        v = (e && (!strcmp(e, "f32") || !strcmp(e, "0"))) ? 0 : 1;
+        v = (e && (!strcmp(e, "f32") || !strcmp(e, "0"))) ? 0 : (e && (!strcmp(e, "bf16x3") || !strcmp(e, "1"))) ? 1 : 2;
         g_screen.store(v, std::memory_order_relaxed);
     }
     return v;
 }
 // |screen value - exact squared distance| <= coeff (sqrt na + sqrt nb)^2  
-static float screen_err_coeff(int screen) { return screen ? 2.75e-5f : 1.56e-5f; }
+// (two-stage screen: the coarse pass's fp32 accumulation only -- 134 terms, with a factor 2 of slack -- see match_finalize_kernel<1>)
+static float screen_err_coeff(int screen) { return screen == 2 ? 3.2e-5f : screen ? 2.75e-5f : 1.56e-5f; }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -1382,7 +1628,13 @@ static MatchWs carve(void *workspace, int nA, int nB)
     w.partial3 = reinterpret_cast<float *>(base); base += align256((size_t)nA * MAX_CHUNKS * sizeof(float));
     w.As = reinterpret_cast<unsigned *>(base); base += align256((size_t)nA * DIM * 4);
     w.Bs = reinterpret_cast<unsigned *>(base); base += align256((size_t)nB * DIM * 4);
-    w.nbslot = reinterpret_cast<uint4 *>(base);
+    w.nbslot = reinterpret_cast<uint4 *>(base); base += align256(((size_t)nB + TILE_C) * sizeof(uint4));
+    w.Ah = reinterpret_cast<unsigned *>(base); base += align256((size_t)nA * DIM * 2);
+    w.Bh = reinterpret_cast<unsigned *>(base); base += align256((size_t)nB * DIM * 2);
+    w.ra = reinterpret_cast<float *>(base); base += align256((size_t)nA * 4);
+    w.rb = reinterpret_cast<float *>(base); base += align256((size_t)nB * 4);
+    w.na2 = reinterpret_cast<float *>(base); base += align256((size_t)nA * 4);
+    w.f1_list = reinterpret_cast<int *>(base);
     return w;
 }
 
@@ -1392,7 +1644,8 @@ static size_t pair_workspace_bytes(int nA, int nB)
     if (nB < 0) nB = 0;
     return align256((size_t)nA * 4) + align256(((size_t)nB + TILE_C) * 4) + align256((size_t)nA * MAX_CHUNKS * sizeof(float4)) +
            align256((size_t)nA * MAX_CHUNKS * sizeof(float)) + 256 + align256((size_t)nA * 4) + 256 +
-           align256((size_t)nA * DIM * 4) + align256((size_t)nB * DIM * 4) + align256(((size_t)nB + TILE_C) * sizeof(uint4));
+           align256((size_t)nA * DIM * 4) + align256((size_t)nB * DIM * 4) + align256(((size_t)nB + TILE_C) * sizeof(uint4)) +
+           align256((size_t)nA * DIM * 2) + align256((size_t)nB * DIM * 2) + 3 * align256((size_t)nA * 4) + align256((size_t)nB * 4);
 }
 
 struct MatchJob {                 // host-side description of one pair of a (possibly batched) call
@@ -1415,6 +1668,7 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
     const int screen = match_screen();
     bt.ambiguity = ambiguity;
     bt.err_coeff = screen_err_coeff(screen);
+    bt.err_coeff2 = screen_err_coeff(1);
     int max_rows = 0, max_a = 0;
     bool dev_sized = false;
     for (int k = 0; k < n; ++k) {
@@ -1432,6 +1686,7 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
         c.S = dev ? MAX_CHUNKS : plans[q].S; c.mode = j.mode;
         c.index_offset = j.index_offset; c.result = j.result; c.min1 = j.min1; c.min2 = j.min2; c.idx1 = j.idx1;
         c.As = w.As; c.Bs = w.Bs; c.nbslot = w.nbslot;
+        if (screen == 2) { c.Ah = w.Ah; c.Bh = w.Bh; c.ra = w.ra; c.rb = w.rb; c.na2 = w.na2; c.f1_list = w.f1_list; }
         c.d_nA = j.d_nA; c.d_nB = j.d_nB;
         c.d_plan = dev ? reinterpret_cast<MatchPlan *>(w.fb_count + 32) : nullptr;      // inside the 256-byte counter block
         if (j.nA >= (1 << 22) || j.nB >= (1 << 22)) return (int)hipErrorInvalidValue;   // 32-bit byte ranges of the SRDs
@@ -1442,35 +1697,61 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
     const int n_cu = nm_cu_count();
     bt.n_cu = n_cu; bt.n_xcd = nm_xcd_count();
     if (phases & NM_MATCH_PHASE_PREP) {
-        if (screen) hipLaunchKernelGGL(prep_kernel<true>, dim3(nm_divup(max_rows, PREP_ROWS), bt.n), dim3(256), 0, st, bt);
-        else hipLaunchKernelGGL(prep_kernel<false>, dim3(nm_divup(max_rows, PREP_ROWS), bt.n), dim3(256), 0, st, bt);
+        const dim3 pg(nm_divup(max_rows, PREP_ROWS), bt.n);
+        if (screen == 2) hipLaunchKernelGGL(prep_kernel<2>, pg, dim3(256), 0, st, bt);
+        else if (screen) hipLaunchKernelGGL(prep_kernel<1>, pg, dim3(256), 0, st, bt);
+        else hipLaunchKernelGGL(prep_kernel<0>, pg, dim3(256), 0, st, bt);
         NM_LAUNCH_CHECK();
         hipLaunchKernelGGL(nbmax_kernel, dim3(bt.n), dim3(1024), 0, st, bt);
         NM_LAUNCH_CHECK();
     }
-    const size_t lds_bytes = (size_t)2 * TILE_C * KP * sizeof(float);
+    const size_t lds_full = (size_t)2 * TILE_C * KP * sizeof(float);
+    // coarse pass: two 32 KiB images + the norm slots; the staged query block (256 rows at a 272-byte pitch) is as large
+    const size_t lds_bytes = screen == 2 ? (size_t)2 * TILE_C * (DIM * 2) + 2 * TILE_C * 16 : lds_full;
+    static_assert(2 * TILE_C * (DIM * 2) + 2 * TILE_C * 16 == QB * (DIM * 2 + 16), "coarse pass: query staging fills the tile buffers exactly");
     // per call: the attribute is per device, and a process may drive several (cheap host-side call, not a stream op)
-    NM_RETURN_IF(hipFuncSetAttribute(screen ? reinterpret_cast<const void *>(match_top2_kernel<true>)
-                                            : reinterpret_cast<const void *>(match_top2_kernel<false>),
+    NM_RETURN_IF(hipFuncSetAttribute(screen == 2 ? reinterpret_cast<const void *>(match_top2_kernel<2>)
+                                     : screen ? reinterpret_cast<const void *>(match_top2_kernel<1>)
+                                              : reinterpret_cast<const void *>(match_top2_kernel<0>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (screen == 2)
+        NM_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_rows_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full));
     for (int q = 0; (phases & NM_MATCH_PHASE_SCREEN) && q < bt.n; ++q) {
         const MatchPair &c = bt.p[q];
         // device-sized: one workgroup per CU, of which the first plan.G (decided on the device) work
         const int grid = dev_sized ? n_cu : plans[q].G;
         const MatchPlan plan_arg = dev_sized ? MatchPlan{} : plans[q];
         nm_prof_begin(NM_PROF_MATCH_TOP2, st);
-        if (screen)
-            hipLaunchKernelGGL(match_top2_kernel<true>, dim3(grid), dim3(512), lds_bytes, st,
+        if (screen == 2)
+            hipLaunchKernelGGL(match_top2_kernel<2>, dim3(grid), dim3(512), lds_bytes, st,
+                               reinterpret_cast<const float *>(c.Ah), c.nA, reinterpret_cast<const float *>(c.Bh), c.nB,
+                               c.na, c.nb, c.nbslot, plan_arg, c.partial, c.partial3, c.d_nA, c.d_nB, c.d_plan);
+        else if (screen)
+            hipLaunchKernelGGL(match_top2_kernel<1>, dim3(grid), dim3(512), lds_bytes, st,
                                reinterpret_cast<const float *>(c.As), c.nA, reinterpret_cast<const float *>(c.Bs), c.nB,
                                c.na, c.nb, c.nbslot, plan_arg, c.partial, c.partial3, c.d_nA, c.d_nB, c.d_plan);
         else
-            hipLaunchKernelGGL(match_top2_kernel<false>, dim3(grid), dim3(512), lds_bytes, st, c.A, c.nA, c.B, c.nB,
+            hipLaunchKernelGGL(match_top2_kernel<0>, dim3(grid), dim3(512), lds_bytes, st, c.A, c.nA, c.B, c.nB,
                                c.na, c.nb, c.nbslot, plan_arg, c.partial, c.partial3, c.d_nA, c.d_nB, c.d_plan);
         nm_prof_end(NM_PROF_MATCH_TOP2, st);
         NM_LAUNCH_CHECK();
     }
     if (!(phases & NM_MATCH_PHASE_FINISH)) return 0;
-    hipLaunchKernelGGL(match_finalize_kernel, dim3(nm_divup(4 * max_a, 256), bt.n), dim3(256), 0, st, bt);
+    const dim3 fg(nm_divup(4 * max_a, 256), bt.n);
+    if (screen == 2) {
+        // coarse result proven -> emitted; the others are listed, split, screened by the bf16x3 kernel (all pairs in one
+        // launch, its plan made on the device for the number listed) and finalized as the single-pass screens are
+        hipLaunchKernelGGL(match_finalize_kernel<1>, fg, dim3(256), 0, st, bt);
+        NM_LAUNCH_CHECK();
+        hipLaunchKernelGGL(fine_rows_kernel, dim3(nm_divup(max_a, PREP_ROWS), bt.n), dim3(256), 0, st, bt);
+        NM_LAUNCH_CHECK();
+        hipLaunchKernelGGL(match_top2_rows_kernel, dim3(n_cu, bt.n), dim3(512), lds_full, st, bt);
+        NM_LAUNCH_CHECK();
+        hipLaunchKernelGGL(match_finalize_kernel<2>, fg, dim3(256), 0, st, bt);
+    } else {
+        hipLaunchKernelGGL(match_finalize_kernel<0>, fg, dim3(256), 0, st, bt);
+    }
     NM_LAUNCH_CHECK();
     static_assert(FB_SPLIT <= MAX_CHUNKS, "fallback slices reuse the partial area");
     // few rows are ever listed (0-2 of 12k on SIFT data): a small grid drains fastest when the list is empty, and its
@@ -1533,7 +1814,7 @@ size_t nm_sift_match_workspace_bytes(int nA, int nB) { return pair_workspace_byt
 
 int nm_sift_match_set_screen(int screen)
 {
-    if (screen != 0 && screen != 1) return (int)hipErrorInvalidValue;
+    if (screen < 0 || screen > 2) return (int)hipErrorInvalidValue;
     g_screen.store(screen, std::memory_order_relaxed);
     return 0;
 }
@@ -1638,6 +1919,14 @@ int nm_sift_match_fallback_count(const void *workspace, int nA, int nB, int *hos
     if (!workspace || !host_count || nA <= 0 || nB <= 0) return (int)hipErrorInvalidValue;
     MatchWs w = carve(const_cast<void *>(workspace), nA, nB);
     NM_RETURN_IF(hipMemcpyAsync(host_count, w.fb_count, sizeof(int), hipMemcpyDeviceToHost, nm_stream(stream)));
+    return (int)hipStreamSynchronize(nm_stream(stream));
+}
+
+int nm_sift_match_second_pass_count(const void *workspace, int nA, int nB, int *host_count, void *stream)
+{
+    if (!workspace || !host_count || nA <= 0 || nB <= 0) return (int)hipErrorInvalidValue;
+    MatchWs w = carve(const_cast<void *>(workspace), nA, nB);
+    NM_RETURN_IF(hipMemcpyAsync(host_count, w.fb_count + 4, sizeof(int), hipMemcpyDeviceToHost, nm_stream(stream)));
     return (int)hipStreamSynchronize(nm_stream(stream));
 }
 

@@ -125,7 +125,7 @@ def test_match_batch_dev_16_pairs_on_real_descriptors(nm, oracle, cuda, bench16)
     before = nm.get_match_screen()
     ws = nm.MatchBatchDevWorkspace(16, CAP, CAP, cuda)
     try:
-        for screen in ("bf16x3", "f32"):
+        for screen in ("f16", "bf16x3", "f32"):
             nm.set_match_screen(screen)
             dev = [torch.full((CAP,), -5, dtype=torch.int32, device=cuda) for _ in pairs]
             nm.sift_match_batch_dev([arenas[a].desc for a, _ in pairs], [arenas[a].num_items for a, _ in pairs],

@@ -8,10 +8,11 @@ from test_gpu_stages import _eq, _t
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["bf16x3", "f32"])
+@pytest.fixture(autouse=True, params=["f16", "bf16x3", "f32"])
 def screen(request, nm):
-    """Every test of this module runs with both MFMA screens of the fused matcher (nm_sift_match_set_screen): the
-    split-bf16 one (default) and the fp32 one. The expected results are the same -- the oracle's."""
+    """Every test of this module runs with all MFMA screens of the fused matcher (nm_sift_match_set_screen): the two-stage
+    one (fp16 coarse pass + split-bf16 second pass, default), the split-bf16 one and the fp32 one. The expected results are
+    the same -- the oracle's."""
     before = nm.get_match_screen()
     nm.set_match_screen(request.param)
     yield request.param

@@ -21,6 +21,7 @@ for i in range(12):
     ts.append(e0.elapsed_time(e1))
 ts = sorted(ts[2:])
 med = ts[len(ts) // 2]
-print("fallback rows", nm.match_fallback_count(ws, nA, nB), "of", nA)
+print("screen", nm.get_match_screen(), "fallback rows", nm.match_fallback_count(ws, nA, nB), "of", nA,
+      "second-pass rows", nm.match_second_pass_count(ws, nA, nB) if nm.get_match_screen() == "f16" else "-")
 print("top2 kernel median %.1f us  min %.1f us  -> %.1f TFLOP/s (2NM128)" % (
     med * 1e3, ts[0] * 1e3, 256.0 * nA * nB / (med * 1e-3) / 1e12))
