@@ -66,6 +66,8 @@ for it in range(n_match):
     elif kind == "clustered":
         c = rng.uniform(0, 1, (8, 128)).astype(np.float32)
         A = (c[rng.integers(0, 8, na)] + 1e-3 * A).astype(np.float32); B = (c[rng.integers(0, 8, nb)] + 1e-3 * B).astype(np.float32)
+    if rng.random() < 0.4:                                            # magnitudes around the edges of the fp16 coarse pass
+        A = A * np.float32(rng.choice([1e-7, 1e-4, 30.0, 2.0e4, 1.0e6])); B = B * np.float32(rng.choice([1e-7, 1e-4, 30.0, 2.0e4, 1.0e6]))
     for _ in range(int(rng.integers(0, 6))):                          # planted duplicates
         B[int(rng.integers(0, nb))] = A[int(rng.integers(0, na))]
     amb = float(rng.choice([0.8, 0.6, 1.0, 1.5]))

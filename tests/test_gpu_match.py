@@ -330,6 +330,26 @@ def test_match_adversarial_rounding(nm, oracle, cuda):
     for j in range(B7.shape[0]):
         B7[j, (3 * j) % 128] += np.float32((1 + j % 4) * 2.0 ** -11)
     cases["aligned bf16 split residuals"] = (A7, np.concatenate([B7, (bad * 2.0 ** rng.integers(-1, 2, (300, 128))).astype(np.float32)]))
+    # 7. two-stage screen: every element is 2^e (1 + 2^-11 - 2^-23), the value just below the midpoint of two fp16 numbers:
+    #    the fp16 images lose ~2^-11 relative in EVERY element, all in the same direction, so the coarse pass's dot
+    #    products are off by ~1e-3 relative while the candidates of a query differ by ~1e-7: only the residual-norm bound
+    #    (-> second pass) can get these rows right
+    bad16 = np.float32(1.0 + 2.0 ** -11 - 2.0 ** -23)
+    A8 = (bad16 * 2.0 ** rng.integers(-1, 2, (200, 128))).astype(np.float32)
+    B8 = np.repeat(A8, 4, 0)
+    for j in range(B8.shape[0]):
+        B8[j, (3 * j) % 128] += np.float32((1 + j % 4) * 2.0 ** -12)
+    cases["aligned fp16 rounding residuals"] = (A8, np.concatenate([B8, (bad16 * 2.0 ** rng.integers(-1, 2, (300, 128))).astype(np.float32)]))
+    # 8. magnitudes at and beyond the edges of the fp16 range: elements below its smallest subnormal (the images are all
+    #    zeros), in its subnormal range, and beyond its largest number (2 |x| > 65504: outside the coarse pass's domain)
+    D8a, D8b = H.synth.descriptors(21, 300), H.synth.descriptors(22, 700)
+    for nm_, sc in (("below fp16 subnormals", 1e-9), ("fp16 subnormal range", 3e-6), ("beyond the fp16 range", 4.0e4),
+                    ("mixed magnitudes", None)):
+        if sc is None:
+            sa = (10.0 ** rng.uniform(-7, 4.7, (300, 1))).astype(np.float32); sb = (10.0 ** rng.uniform(-7, 4.7, (700, 1))).astype(np.float32)
+            cases[nm_] = (D8a * sa, D8b * sb)
+        else:
+            cases[nm_] = (D8a * np.float32(sc), D8b * np.float32(sc))
     for name, (A, B) in cases.items():
         A = np.ascontiguousarray(A, np.float32); B = np.ascontiguousarray(B, np.float32)
         prior = np.full(len(A), -7, np.int32)
@@ -345,6 +365,8 @@ def test_match_adversarial_rounding(nm, oracle, cuda):
         assert np.array_equal(m2.cpu().numpy().view(np.uint32), m2r.view(np.uint32)), name
         if name == "large offset, tiny distances":        # the bound must refuse to trust the MFMA pass here
             assert nm.match_fallback_count(ws, len(A), len(B)) == len(A)
+        if nm.get_match_screen() == "f16" and name in ("aligned fp16 rounding residuals", "beyond the fp16 range"):
+            assert nm.match_second_pass_count(ws, len(A), len(B)) == len(A), name     # the coarse pass must not be trusted
 
 
 def test_shard_with_empty_candidate_shard(nm, oracle, cuda):
