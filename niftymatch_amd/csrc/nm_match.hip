@@ -55,6 +55,10 @@ constexpr float F16_NORM_LIMIT = 1.0e9f;
 // serves them once instead of every query block re-streaming the candidate set from the Infinity Cache. With X = 1 and
 // C = 1 this is the plain query-block-major order (used for small problems and single-XCD partitions).
 struct MatchPlan { int qblocks, T, G, S, X, Gx, Tc, C, q_base, q_rem; };
+// Unit indices: qblocks x T <= 2^14 x 2^15 (the entries refuse sets of 2^22 rows or more), so 32 bits hold them. (They were
+// 64-bit until round 3: the ~20 integer divisions a workgroup makes per segment to find its way through the plan were
+// expanded to 64-bit software division on the vector unit -- ~7 us per segment of the coarse pass.)
+typedef int unit_t;
 struct PlanGroup { int nq, q0, base, rem; };
 
 #define NM_HD __host__ __device__ __forceinline__
@@ -63,23 +67,23 @@ NM_HD PlanGroup plan_group(const MatchPlan &p, int x)
     PlanGroup g;
     g.nq = p.q_base + (x < p.q_rem ? 1 : 0);
     g.q0 = x * p.q_base + (x < p.q_rem ? x : p.q_rem);
-    const long U = (long)g.nq * p.T;
+    const unit_t U = (unit_t)g.nq * p.T;
     g.base = (int)(U / p.Gx);
     g.rem = (int)(U % p.Gx);
     return g;
 }
-NM_HD long group_begin(const PlanGroup &g, int v) { return (long)v * g.base + (v < g.rem ? v : g.rem); }
-NM_HD int group_owner(const PlanGroup &g, long ul)            // local workgroup whose range holds local unit ul
+NM_HD unit_t group_begin(const PlanGroup &g, int v) { return (unit_t)v * g.base + (v < g.rem ? v : g.rem); }
+NM_HD int group_owner(const PlanGroup &g, unit_t ul)            // local workgroup whose range holds local unit ul
 {
-    const long cut = (long)g.rem * (g.base + 1);
+    const unit_t cut = (unit_t)g.rem * (g.base + 1);
     return (ul < cut) ? (int)(ul / (g.base + 1)) : g.rem + (int)((ul - cut) / g.base);
 }
 // local unit ul -> chunk c, local query block qbl, tile offset tt inside the piece, piece length Lc
-NM_HD void plan_locate(const MatchPlan &p, const PlanGroup &g, long ul, int &c, int &qbl, int &tt, int &Lc)
+NM_HD void plan_locate(const MatchPlan &p, const PlanGroup &g, unit_t ul, int &c, int &qbl, int &tt, int &Lc)
 {
-    const long per_chunk = (long)g.nq * p.Tc;
+    const unit_t per_chunk = (unit_t)g.nq * p.Tc;
     c = (int)(ul / per_chunk);
-    const int r = (int)(ul - (long)c * per_chunk);
+    const int r = (int)(ul - (unit_t)c * per_chunk);
     Lc = p.T - c * p.Tc < p.Tc ? p.T - c * p.Tc : p.Tc;
     qbl = r / Lc;
     tt = r - qbl * Lc;
@@ -88,7 +92,7 @@ NM_HD void plan_locate(const MatchPlan &p, const PlanGroup &g, long ul, int &c, 
 NM_HD void piece_owners(const MatchPlan &p, const PlanGroup &g, int c, int qbl, int &first, int &last)
 {
     const int Lc = p.T - c * p.Tc < p.Tc ? p.T - c * p.Tc : p.Tc;
-    const long P = (long)g.nq * c * p.Tc + (long)qbl * Lc;
+    const unit_t P = (unit_t)g.nq * c * p.Tc + (unit_t)qbl * Lc;
     first = group_owner(g, P);
     last = group_owner(g, P + Lc - 1);
 }
@@ -107,12 +111,12 @@ NM_HD int plan_slot(const MatchPlan &p, const PlanGroup &g, int c, int qbl, int 
 // tile, in step with the other workgroups of its XCD on the same chunk -- the first reader of a candidate tile misses in
 // L2, the others hit. (Slots and results do not depend on the processing order.)
 struct SegIter {
-    long u, u_end, u0;
+    unit_t u, u_end, u0;
     bool have_def;
-    long def_u;
-    NM_HD void init(long b, long e) { u = b; u0 = b; u_end = e; have_def = false; def_u = 0; }
+    unit_t def_u;
+    NM_HD void init(unit_t b, unit_t e) { u = b; u0 = b; u_end = e; have_def = false; def_u = 0; }
     // next segment: local unit where it starts (its length follows from plan_locate); false when done
-    NM_HD bool next(const MatchPlan &p, const PlanGroup &g, long &seg_u)
+    NM_HD bool next(const MatchPlan &p, const PlanGroup &g, unit_t &seg_u)
     {
         for (;;) {
             if (u >= u_end) {
@@ -121,7 +125,7 @@ struct SegIter {
             }
             int c, qbl, tt, Lc;
             plan_locate(p, g, u, c, qbl, tt, Lc);
-            const long n = (Lc - tt) < (u_end - u) ? (Lc - tt) : (u_end - u);
+            const unit_t n = (Lc - tt) < (u_end - u) ? (Lc - tt) : (u_end - u);
             if (have_def) {
                 int dc, dq, dt, dl;
                 plan_locate(p, g, def_u, dc, dq, dt, dl);
@@ -168,14 +172,14 @@ NM_HD MatchPlan make_plan_on(int nA, int nB, int n_cu, int n_xcd, int lane, int 
     MatchPlan p;
     p.qblocks = hd_divup(nA > 0 ? nA : 1, QB);
     p.T = hd_divup(nB > 0 ? nB : 1, TILE_C);
-    const long U = (long)p.qblocks * p.T;
+    const unit_t U = (unit_t)p.qblocks * p.T;
     // XCD-grouped order: the whole chip is used, the query blocks split over the XCDs to within 3 %, and every XCD has a
     // few query blocks to share tiles between
     if (n_xcd > 1 && n_cu % n_xcd == 0 && U >= 4L * n_cu && p.qblocks >= 2 * n_xcd &&
-        (long)hd_divup(p.qblocks, n_xcd) * n_xcd * 100 <= (long)p.qblocks * 103) {
+        (unit_t)hd_divup(p.qblocks, n_xcd) * n_xcd * 100 <= (unit_t)p.qblocks * 103) {
         p.G = n_cu; p.X = n_xcd; p.Gx = n_cu / n_xcd;
         p.q_base = p.qblocks / n_xcd; p.q_rem = p.qblocks % n_xcd;
-        const long upw = U / n_cu;                                   // units per workgroup
+        const unit_t upw = U / n_cu;                                   // units per workgroup
         int C = (int)((p.T + upw / 2) / (upw > 0 ? upw : 1));       // chunks ~ T / units-per-workgroup
         if (C < 1) C = 1;
         if (C > p.T) C = p.T;
@@ -186,7 +190,7 @@ NM_HD MatchPlan make_plan_on(int nA, int nB, int n_cu, int n_xcd, int lane, int 
     }
     // plain query-block-major order over one group
     const int min_len = hd_divup(p.T, MAX_CHUNKS - 2);            // a block spans <= MAX_CHUNKS - 2 whole ranges + 2 ends
-    long G = U / min_len;
+    unit_t G = U / min_len;
     if (G > n_cu) G = n_cu;
     if (G < 1) G = 1;
     p.G = (int)G; p.X = 1; p.Gx = p.G;
@@ -196,10 +200,11 @@ NM_HD MatchPlan make_plan_on(int nA, int nB, int n_cu, int n_xcd, int lane, int 
     return p;
 }
 
-static MatchPlan make_plan(int nA, int nB)
+static MatchPlan make_plan(int nA, int nB, int wg_per_cu = 1)
 {
-    // one persistent workgroup per CU of the current device (256 on MI355X SPX)
-    return make_plan_on(nA, nB, nm_cu_count(), nm_xcd_count(), 0, 1, [](int s) { return s; });
+    // one persistent workgroup per CU of the current device (256 on MI355X SPX); two for the coarse pass of the two-stage
+    // screen, whose 68 KiB of LDS let two workgroups share a CU (four waves per SIMD instead of two)
+    return make_plan_on(nA, nB, nm_cu_count() * wg_per_cu, nm_xcd_count(), 0, 1, [](int s) { return s; });
 }
 
 // Everything the small launches around the MFMA kernel need for one (A, B) pair. A batched call (nm_sift_match_batch_f32)
@@ -247,7 +252,8 @@ struct MatchBatch {
     float err_coeff;           // |screen value - exact d| <= err_coeff (sqrt na + sqrt nb)^2 for the screen in use
     float err_coeff2;          // two-stage screen: the same for its second (bf16x3) pass; err_coeff then covers the fp32
                                // accumulation of the coarse pass only, the fp16 rounding enters through ra / rb
-    int n_cu, n_xcd;           // device-sized calls: the geometry the device-side plan is made for
+    int n_cu, n_xcd;           // device-sized calls: the geometry the device-side plan is made for (n_cu = persistent workgroups)
+    int n_cu2;                 // two-stage screen: workgroups of the second pass (one per CU), for the plan fine_rows_kernel makes
 };
 static_assert(sizeof(MatchBatch) <= 4096, "kernel arguments are limited to 4 KB");
 
@@ -669,37 +675,82 @@ __device__ __forceinline__ void f16_kstep(f32x16 &acc0, f32x16 &acc1, const u32x
     }
 }
 
-template <bool SELECT>
-__device__ __forceinline__ void mfma_half_f16(f32x16 &acc0, f32x16 &acc1, const f32x16 &prev0, const f32x16 &prev1,
-                                              const char *tb, const unsigned (&foff)[8], const char *slotp,
-                                              const u32x4 (&qf)[16], const u32x4 qslot, int &g1, int &g2, int &g3)
+// The coarse pass is software-pipelined over HALF groups (4 k-steps of both accumulators): with two MFMAs per k-step a
+// k-step lasts ~64-128 cycles, less than an LDS read under load, so the fragments of a whole half group (8 x 16 bytes per
+// lane) are requested while the previous half group is multiplied.
+// fr[2 t], fr[2 t + 1] = the lane's chunks of k-step KS0 + t for the two accumulators.
+template <int KS0>
+__device__ __forceinline__ void f16_fetch(u32x4 (&fr)[8], const char *tb, const unsigned (&foff)[8])
 {
     constexpr int G1 = 32 * 256;
-    u32x4 h0 = *reinterpret_cast<const u32x4 *>(tb + foff[0]), h1 = *reinterpret_cast<const u32x4 *>(tb + G1 + foff[0]);
-    const u32x4 s0 = *reinterpret_cast<const u32x4 *>(slotp), s1 = *reinterpret_cast<const u32x4 *>(slotp + 32 * 16);
-    // the norms (bf16 k-slots, as in the bf16x3 kernel); the wait states also separate the two MFMA types on one accumulator
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %4, 0\n\tv_mfma_f32_32x32x16_bf16 %1, %3, %4, 0\n\ts_nop 15\n\ts_nop 3"
-                 : "=&v"(acc0), "=&v"(acc1) : "v"(s0), "v"(s1), "v"(qslot) : "memory");
-#define NM_KSTEP(T)                                                                                                      \
-    {                                                                                                                    \
-        u32x4 nh0 = h0, nh1 = h1;                                                                                        \
-        if (T + 1 < 8) { /* next k-step's fragments fly during this step's MFMAs */                                      \
-            nh0 = *reinterpret_cast<const u32x4 *>(tb + foff[(T + 1) & 7]);                                              \
-            nh1 = *reinterpret_cast<const u32x4 *>(tb + G1 + foff[(T + 1) & 7]);                                         \
-        }                                                                                                                \
-        const f32x16 &pv = (T < 4) ? prev0 : prev1;                                                                      \
-        f16_kstep<SELECT, 4 * T>(acc0, acc1, h0, h1, qf[T], pv[(4 * T) & 15], pv[(4 * T + 1) & 15],                        \
-                                 pv[(4 * T + 2) & 15], pv[(4 * T + 3) & 15], g1, g2, g3);                                 \
-        h0 = nh0; h1 = nh1;                                                                                              \
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        fr[2 * t] = *reinterpret_cast<const u32x4 *>(tb + foff[KS0 + t]);
+        fr[2 * t + 1] = *reinterpret_cast<const u32x4 *>(tb + G1 + foff[KS0 + t]);
     }
-    NM_KSTEP(0) NM_KSTEP(1) NM_KSTEP(2) NM_KSTEP(3) NM_KSTEP(4) NM_KSTEP(5) NM_KSTEP(6) NM_KSTEP(7)
-#undef NM_KSTEP
+}
+// the norms of a 64-candidate group start its two accumulators (bf16 k-slots, as in the bf16x3 kernel)
+__device__ __forceinline__ void f16_slots(f32x16 &acc0, f32x16 &acc1, const char *slotp, const u32x4 qslot)
+{
+    const u32x4 s0 = *reinterpret_cast<const u32x4 *>(slotp), s1 = *reinterpret_cast<const u32x4 *>(slotp + 32 * 16);
+    // No wait states behind them: the next instruction on acc0 is an MFMA that accumulates into exactly the registers this
+    // one writes (the XDL pipe interlocks that case, whatever the operand type), and the first VALU instruction that reads
+    // an accumulator reads one of the PREVIOUS group, whose last MFMA is more than 16 instructions back.
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %4, 0\n\tv_mfma_f32_32x32x16_bf16 %1, %3, %4, 0"
+                 : "=&v"(acc0), "=&v"(acc1) : "v"(s0), "v"(s1), "v"(qslot) : "memory");
+}
+// k-steps KS0 .. KS0 + 3 of (acc0, acc1); SELECT: the 16 values of pv (one accumulator of the PREVIOUS group; slots
+// 4 KS0 .. 4 KS0 + 15 of that group) are folded into the key triple meanwhile
+template <bool SELECT, int KS0>
+__device__ __forceinline__ void f16_half(f32x16 &acc0, f32x16 &acc1, const f32x16 &pv, const u32x4 (&fr)[8],
+                                         const u32x4 (&qf)[16], int &g1, int &g2, int &g3)
+{
+    f16_kstep<SELECT, 4 * KS0>(acc0, acc1, fr[0], fr[1], qf[KS0], pv[0], pv[1], pv[2], pv[3], g1, g2, g3);
+    f16_kstep<SELECT, 4 * KS0 + 4>(acc0, acc1, fr[2], fr[3], qf[KS0 + 1], pv[4], pv[5], pv[6], pv[7], g1, g2, g3);
+    f16_kstep<SELECT, 4 * KS0 + 8>(acc0, acc1, fr[4], fr[5], qf[KS0 + 2], pv[8], pv[9], pv[10], pv[11], g1, g2, g3);
+    f16_kstep<SELECT, 4 * KS0 + 12>(acc0, acc1, fr[6], fr[7], qf[KS0 + 3], pv[12], pv[13], pv[14], pv[15], g1, g2, g3);
 }
 #undef NM_MFMA_H
 
+// End of a segment: decode (value, candidate index) of the two best, merge the two lane halves (same query, disjoint
+// candidates), publish into this segment's slot of the query block. c0 = first candidate of the segment.
+__device__ __forceinline__ void segment_publish(const Top3 &best, const MatchPlan &plan, const PlanGroup &grp, int pc, int qbl,
+                                                int vg, bool ends_piece, int c0, int h, int qi, int nA, int S,
+                                                float4 *__restrict__ partial, float *__restrict__ partial3)
+{
+    auto index_of = [&](int k, int tag) {
+        const int slot = k & ((1 << KEY_SLOT_BITS) - 1), g = slot >> 4, e = slot & 15;
+        return c0 + tag * 64 + 32 * g + (e & 3) + 8 * (e >> 2) + 4 * h;
+    };
+    Top2 m;
+    m.m1 = key_value(best.k1); m.m2 = key_value(best.k2); m.m3 = key_value(best.k3);
+    m.i1 = (best.k1 != KEY_INF) ? index_of(best.k1, best.t1) : -1;
+    m.i2 = (best.k2 != KEY_INF) ? index_of(best.k2, best.t2) : -1;
+    if (best.k1 == KEY_INF) m.m1 = __builtin_inff();
+    if (best.k2 == KEY_INF) m.m2 = __builtin_inff();
+    if (best.k3 == KEY_INF) m.m3 = __builtin_inff();
+    Top2 o;
+    o.m1 = __shfl_xor(m.m1, 32); o.m2 = __shfl_xor(m.m2, 32); o.m3 = __shfl_xor(m.m3, 32);
+    o.i1 = __shfl_xor(m.i1, 32); o.i2 = __shfl_xor(m.i2, 32);
+    if (o.i1 >= 0) top2_insert(m, o.m1, o.i1);
+    if (o.i2 >= 0) top2_insert(m, o.m2, o.i2);
+    m.m3 = __builtin_fminf(m.m3, o.m3);         // o.m3 >= o.m2 >= the merged m2: only the third value can change
+    // slot = how many segments of this query block come before this one in the plan's order
+    const int slot = plan_slot(plan, grp, pc, qbl, vg);
+    if (h == 0 && qi < nA) {
+        partial[(size_t)qi * S + slot] = make_float4(m.m1, __int_as_float(m.i1), m.m2, __int_as_float(m.i2));
+        partial3[(size_t)qi * S + slot] = m.m3;
+        if (pc == plan.C - 1 && ends_piece) {     // this segment ends the block: blank the slots nobody writes
+            for (int k = slot + 1; k < S; ++k) {
+                partial[(size_t)qi * S + k] = make_float4(__builtin_inff(), __int_as_float(-1), __builtin_inff(), __int_as_float(-1));
+                partial3[(size_t)qi * S + k] = __builtin_inff();
+            }
+        }
+    }
+}
+
 // SCR 0 (fp32 screen): A, B are the fp32 descriptor rows. SCR 1 (bf16x3): A, B are the split images written by prep_kernel
-// (same 512-byte rows) and nbslot replaces nb. SCR 2 (coarse pass of the two-stage screen): A, B are the fp16 images
-// (256-byte rows), nbslot as for bf16x3.
+// (same 512-byte rows) and nbslot replaces nb.
 // Device-sized launches (d_plan != NULL): nA_arg / nB_arg are the capacities, the real sizes and the plan made for them
 // (nbmax_kernel) are read from device memory, and the grid is one workgroup per CU of which the first plan.G work.
 template <int SCR>
@@ -712,8 +763,9 @@ __device__ __forceinline__ void match_top2_body(const float *__restrict__ A, int
                                                 const int *__restrict__ d_nA, const int *__restrict__ d_nB,
                                                 const MatchPlan *__restrict__ d_plan)
 {
-    constexpr bool BF16 = SCR == 1, F16 = SCR == 2, DMA = SCR != 0;
-    constexpr int ROWB = F16 ? DIM * 2 : DIM * 4;         // bytes per row of the A / B images this screen reads
+    static_assert(SCR == 0 || SCR == 1, "the coarse pass of the two-stage screen has its own kernel (match_coarse_kernel)");
+    constexpr bool BF16 = SCR == 1, DMA = SCR != 0;
+    constexpr int ROWB = DIM * 4;                         // bytes per row of the A / B images these screens read
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -730,7 +782,7 @@ __device__ __forceinline__ void match_top2_body(const float *__restrict__ A, int
     const int S = plan.S;
     const int xg = wg % plan.X, vg = wg / plan.X;         // XCD group (blocks b, b + X share an XCD) and position in it
     const PlanGroup grp = plan_group(plan, xg);
-    const long u_begin = group_begin(grp, vg), u_end = group_begin(grp, vg + 1);
+    const unit_t u_begin = group_begin(grp, vg), u_end = group_begin(grp, vg + 1);
     SegIter it;
     it.init(u_begin, u_end);
 
@@ -765,21 +817,15 @@ __device__ __forceinline__ void match_top2_body(const float *__restrict__ A, int
     // padding; bank conflicts are avoided by XOR-swizzling the 16-byte chunks of a row with (row & 15) -- applied to the
     // per-lane SOURCE address here and to the fragment reads' offsets (foff), the same involution on both sides. The
     // 16-byte norm slots live in their own 2 KiB per buffer behind the two 64 KiB images (same total as the padded layout).
-    // The coarse pass (fp16 images, 256-byte rows) does the same with four rows per wave-instruction and a 32 KiB image.
     constexpr int IMG = TILE_C * ROWB, SLOT0 = 2 * IMG, SLOTB = TILE_C * 16;
-    constexpr int DMA_N = IMG / (8 * 1024);               // wave-instructions per wave and tile: 8 (512-byte rows) or 4
+    constexpr int DMA_N = IMG / (8 * 1024);               // wave-instructions per wave and tile
     char *const ldsb = reinterpret_cast<char *>(lds);
     unsigned foff[8], dvoff[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         foff[t] = (unsigned)(((2 * t + h) ^ (r & 15)) << 4);
-        if (F16) {                                        // wave-instruction t of a wave covers rows 4 (4 wave + t) + (lane >> 4)
-            const int p = lane & 15, key = (4 * t + (lane >> 4)) & 15;
-            dvoff[t] = (unsigned)((lane >> 4) * ROWB + ((p ^ key) << 4));
-        } else {
-            const int p = lane & 31, key = (2 * t + (lane >> 5)) & 15;    // wave-instruction t of a wave covers rows 2 (8 wave + t) + (lane >> 5)
-            dvoff[t] = (unsigned)((lane >> 5) * (DIM * 4) + (((p & 16) | ((p & 15) ^ key)) << 4));
-        }
+        const int p = lane & 31, key = (2 * t + (lane >> 5)) & 15;        // wave-instruction t of a wave covers rows 2 (8 wave + t) + (lane >> 5)
+        dvoff[t] = (unsigned)((lane >> 5) * (DIM * 4) + (((p & 16) | ((p & 15) ^ key)) << 4));
     }
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // scalar for the compiler: M0 and the scalar offset depend on it
     auto dma_tile = [&](int tile, int b) {
@@ -792,7 +838,7 @@ __device__ __forceinline__ void match_top2_body(const float *__restrict__ A, int
         }
     };
 
-    long u;
+    unit_t u;
     while (it.next(plan, grp, u)) {
         int pc, qbl, tt, Lc;
         plan_locate(plan, grp, u, pc, qbl, tt, Lc);
@@ -805,19 +851,10 @@ __device__ __forceinline__ void match_top2_body(const float *__restrict__ A, int
         //      queries -> LDS (coalesced) -> per-lane MFMA fragments in VGPRs ----
         if (DMA) { if (tid < TILE_C) sts = nbslot[t0 * TILE_C + tid]; }
         else stage_load(t0);
-        constexpr int QP16 = ROWB + 16;     // coarse pass: LDS pitch of a staged query row (272 B: b128 reads conflict-free)
-        if (F16) {
 #pragma unroll 4
-            for (int it = 0; it < QB / 32; ++it) {       // 32 rows x 16 chunks of 16 B per pass
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsA, ((tid >> 4) * ROWB + (tid & 15) * 16), (i0 + 32 * it) * ROWB, 0);
-                *reinterpret_cast<u32x4 *>(ldsb + ((tid >> 4) + 32 * it) * QP16 + (tid & 15) * 16) = v;
-            }
-        } else {
-#pragma unroll 4
-            for (int it = 0; it < QB / 16; ++it) {
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff, (i0 + 16 * it) * (DIM * 4), 0);
-                *reinterpret_cast<u32x4 *>(&lds[(srow + 16 * it) * KP + scol]) = v;
-            }
+        for (int it = 0; it < QB / 16; ++it) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff, (i0 + 16 * it) * (DIM * 4), 0);
+            *reinterpret_cast<u32x4 *>(&lds[(srow + 16 * it) * KP + scol]) = v;
         }
         __syncthreads();
         float4 qf[16];
@@ -825,9 +862,7 @@ __device__ __forceinline__ void match_top2_body(const float *__restrict__ A, int
         const int qi = i0 + wave * 32 + r;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {      // the -2 of  |a|^2 + |b|^2 - 2 a.b  rides on the query fragments (once per segment)
-            if (F16) {                      // k-steps 0..7 (prep_kernel applied the -2); the upper half of qw is unused
-                if (t < 8) qw[t] = *reinterpret_cast<const u32x4 *>(ldsb + (wave * 32 + r) * QP16 + 32 * t + 16 * h);
-            } else if (BF16) {              // hi pieces of k-steps 0..7, then the lo pieces (prep_kernel applied the -2)
+            if (BF16) {              // hi pieces of k-steps 0..7, then the lo pieces (prep_kernel applied the -2)
                 qw[t] = *reinterpret_cast<const u32x4 *>(&lds[(wave * 32 + r) * KP + 8 * t + 4 * h]);
             } else {
                 const float4 v = *reinterpret_cast<const float4 *>(&lds[(wave * 32 + r) * KP + 8 * t + 4 * h]);
@@ -884,16 +919,13 @@ __device__ __forceinline__ void match_top2_body(const float *__restrict__ A, int
                 }
                 int g1 = KEY_INF, g2 = KEY_INF, g3 = KEY_INF;
                 if (n == 0) {
-                    if (F16) mfma_half_f16<false>(a0, a1, b0, b1, tb, foff, sp, qw, qslot, g1, g2, g3);
-                    else mfma_half_bf16<false>(a0, a1, b0, b1, tb, foff, sp, qw, qslot, g1, g2, g3);
+                    mfma_half_bf16<false>(a0, a1, b0, b1, tb, foff, sp, qw, qslot, g1, g2, g3);
                 } else {
-                    if (F16) mfma_half_f16<true>(a0, a1, b0, b1, tb, foff, sp, qw, qslot, g1, g2, g3);
-                    else mfma_half_bf16<true>(a0, a1, b0, b1, tb, foff, sp, qw, qslot, g1, g2, g3);
+                    mfma_half_bf16<true>(a0, a1, b0, b1, tb, foff, sp, qw, qslot, g1, g2, g3);
                     fold(g1, g2, g3, 2 * n - 1);
                 }
                 g1 = g2 = g3 = KEY_INF;
-                if (F16) mfma_half_f16<true>(b0, b1, a0, a1, tb + 64 * ROWB, foff, sp + 64 * 16, qw, qslot, g1, g2, g3);
-                else mfma_half_bf16<true>(b0, b1, a0, a1, tb + 64 * ROWB, foff, sp + 64 * 16, qw, qslot, g1, g2, g3);
+                mfma_half_bf16<true>(b0, b1, a0, a1, tb + 64 * ROWB, foff, sp + 64 * 16, qw, qslot, g1, g2, g3);
                 fold(g1, g2, g3, 2 * n);
                 if (n + 1 < ntiles && tid < TILE_C) *reinterpret_cast<uint4 *>(ldsb + SLOT0 + (b ^ 1) * SLOTB + tid * 16) = sts;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile n + 1 has landed (this wave's share): see the prologue
@@ -914,40 +946,192 @@ __device__ __forceinline__ void match_top2_body(const float *__restrict__ A, int
             __syncthreads();
         }
 
-        // decode (value, candidate index) of the two best, merge the two lane halves (same query, disjoint candidates),
-        // publish into this segment's slot of the query block
-        {
-            auto index_of = [&](int k, int tag) {
-                const int slot = k & ((1 << KEY_SLOT_BITS) - 1), g = slot >> 4, e = slot & 15;
-                return c0 + tag * 64 + 32 * g + (e & 3) + 8 * (e >> 2) + 4 * h;
-            };
-            Top2 m;
-            m.m1 = key_value(best.k1); m.m2 = key_value(best.k2); m.m3 = key_value(best.k3);
-            m.i1 = (best.k1 != KEY_INF) ? index_of(best.k1, best.t1) : -1;
-            m.i2 = (best.k2 != KEY_INF) ? index_of(best.k2, best.t2) : -1;
-            if (best.k1 == KEY_INF) m.m1 = __builtin_inff();
-            if (best.k2 == KEY_INF) m.m2 = __builtin_inff();
-            if (best.k3 == KEY_INF) m.m3 = __builtin_inff();
-            Top2 o;
-            o.m1 = __shfl_xor(m.m1, 32); o.m2 = __shfl_xor(m.m2, 32); o.m3 = __shfl_xor(m.m3, 32);
-            o.i1 = __shfl_xor(m.i1, 32); o.i2 = __shfl_xor(m.i2, 32);
-            if (o.i1 >= 0) top2_insert(m, o.m1, o.i1);
-            if (o.i2 >= 0) top2_insert(m, o.m2, o.i2);
-            m.m3 = __builtin_fminf(m.m3, o.m3);         // o.m3 >= o.m2 >= the merged m2: only the third value can change
-            // slot = how many segments of this query block come before this one in the plan's order
-            const int slot = plan_slot(plan, grp, pc, qbl, vg);
-            if (h == 0 && qi < nA) {
-                partial[(size_t)qi * S + slot] = make_float4(m.m1, __int_as_float(m.i1), m.m2, __int_as_float(m.i2));
-                partial3[(size_t)qi * S + slot] = m.m3;
-                if (pc == plan.C - 1 && tt + ntiles == Lc) {     // this segment ends the block: blank the slots nobody writes
-                    for (int k = slot + 1; k < S; ++k) {
-                        partial[(size_t)qi * S + k] = make_float4(__builtin_inff(), __int_as_float(-1), __builtin_inff(), __int_as_float(-1));
-                        partial3[(size_t)qi * S + k] = __builtin_inff();
-                    }
-                }
-            }
-        }
+        segment_publish(best, plan, grp, pc, qbl, vg, tt + ntiles == Lc, c0, h, qi, nA, S, partial, partial3);
         __syncthreads();                                  // the next segment's prologue reuses the LDS
+    }
+}
+
+// The coarse pass of the two-stage screen as ONE stream of candidate tiles per workgroup. A workgroup's range is 2-3
+// segments of ~8 tiles, and with one product per k a tile lasts ~2 us: the segment prologue of the kernels above (query
+// rows, their norms and the first candidate tile requested one after the other, each global-memory latency exposed to all
+// eight waves) cost as much as four tiles. Here
+//   * the query block has its own 64 KiB LDS region, filled by LDS-DMA in the same swizzled row layout as the tiles;
+//   * the NEXT segment's queries are requested as soon as every wave holds the current fragments (after the first barrier
+//     of the segment), its first two candidate tiles as stream tiles g + 1, g + 2 of the ring below, its norms into
+//     registers: a segment change is a barrier that is taken anyway, eight LDS reads and the publication of the previous
+//     segment's result;
+//   * the tile ring runs across segments: after the barrier of stream tile g (taken once every wave holds its last
+//     fragments of g, after the third of the four half groups) tile g + 2 is requested into the buffer g just left.
+// A segment that follows a one-tile segment (or starts the range) cannot have been requested ahead and takes the slow
+// path: request, wait, barrier. LDS: 2 x 32 KiB tiles | 2 x 2 KiB norm slots | 64 KiB queries = 135 168 B.
+__global__ __launch_bounds__(512, 1) void match_coarse_kernel(const unsigned *__restrict__ Ah, int nA_arg,
+                                                              const unsigned *__restrict__ Bh, int nB_arg,
+                                                              const float *__restrict__ na, const uint4 *__restrict__ nbslot,
+                                                              MatchPlan plan_arg, float4 *__restrict__ partial,
+                                                              float *__restrict__ partial3, const int *__restrict__ d_nA,
+                                                              const int *__restrict__ d_nB, const MatchPlan *__restrict__ d_plan)
+{
+    constexpr int ROWB = DIM * 2, IMG = TILE_C * ROWB, SLOT0 = 2 * IMG, SLOTB = TILE_C * 16, QREG = SLOT0 + 2 * SLOTB;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char *const ldsb = reinterpret_cast<char *>(lds);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wg = blockIdx.x;
+    int nA = nA_arg, nB = nB_arg;
+    MatchPlan plan = plan_arg;
+    if (d_plan) {                                         // uniform: scalar loads
+        if (d_nA) nA = min(max(*d_nA, 0), nA_arg);
+        if (d_nB) nB = min(max(*d_nB, 0), nB_arg);
+        plan = *d_plan;
+        if (nA <= 0 || nB <= 0 || wg >= plan.G) return;
+    }
+    const int S = plan.S;
+    const int xg = wg % plan.X, vg = wg / plan.X;
+    const PlanGroup grp = plan_group(plan, xg);
+    const unit_t u_begin = group_begin(grp, vg), u_end = group_begin(grp, vg + 1);
+    SegIter it;
+    it.init(u_begin, u_end);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(Bh), 0, nB * ROWB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(Ah), 0, nA * ROWB, 0x00020000);
+
+    // LDS-DMA: one wave-instruction lands 1 KiB = four 256-byte rows, lane-linear; the 16-byte chunks of a row are XOR-swizzled
+    // with (row & 15) on the SOURCE side here and in the fragment reads' offsets (foff). Wave-instruction t of a wave covers
+    // rows 4 (N wave + t) + (lane >> 4), N = 4 (tile) or 8 (query block): row & 15 = (4 t + (lane >> 4)) & 15 either way.
+    unsigned foff[8], dvoff[4];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) foff[t] = (unsigned)(((2 * t + h) ^ (r & 15)) << 4);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dvoff[t] = (unsigned)((lane >> 4) * ROWB + (((lane & 15) ^ ((4 * t + (lane >> 4)) & 15)) << 4));
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    typedef __attribute__((address_space(3))) void lds_void;
+    auto dma_tile = [&](int tile, int b) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void *)(ldsb + b * IMG + (wave_u * 4 + t) * 1024), 16, (int)dvoff[t],
+                                                     (tile * TILE_C + 4 * (wave_u * 4 + t)) * ROWB, 0, 0);
+    };
+    auto dma_queries = [&](int i0) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void *)(ldsb + QREG + (wave_u * 8 + t) * 1024), 16, (int)dvoff[t & 3],
+                                                     (i0 + 4 * (wave_u * 8 + t)) * ROWB, 0, 0);
+    };
+    struct Seg { int pc, qbl, tt, Lc, qb, t0, ntiles; };
+    auto locate = [&](unit_t u) {
+        Seg sg;
+        plan_locate(plan, grp, u, sg.pc, sg.qbl, sg.tt, sg.Lc);
+        sg.qb = grp.q0 + sg.qbl; sg.t0 = sg.pc * plan.Tc + sg.tt;
+        sg.ntiles = min(sg.Lc - sg.tt, (int)(u_end - u));
+        return sg;
+    };
+    auto norm_of = [&](int qb) { const int qi = qb * QB + wave * 32 + r; return (qi < nA) ? na[qi] : 0.f; };
+
+    unit_t u;
+    if (!it.next(plan, grp, u)) return;
+    Seg cur = locate(u);
+    bool ahead = false;                                   // the current segment's queries and first tile(s) were requested ahead
+    int g = 0;                                            // stream tile index of the current segment's first tile (its parity picks the buffer)
+    float nav = 0.f, nav_next = 0.f;
+    uint4 sts = make_uint4(0u, 0u, 0u, 0u);
+    u32x4 frA[8], frB[8];
+    for (;;) {
+        unit_t u_next = 0;
+        const bool have_next = it.next(plan, grp, u_next);
+        Seg nxt = cur;
+        if (have_next) nxt = locate(u_next);
+        const int ntiles = cur.ntiles, t0 = cur.t0;
+        if (!ahead) {
+            // slow path. Every wave is past the barrier of the previous stream tile (or this is the start): both tile buffers,
+            // the slots and the query region are free
+            dma_queries(cur.qb * QB);
+            nav = norm_of(cur.qb);
+            dma_tile(t0, g & 1);
+            if (tid < TILE_C) *reinterpret_cast<uint4 *>(ldsb + SLOT0 + (g & 1) * SLOTB + tid * 16) = nbslot[t0 * TILE_C + tid];
+            if (ntiles > 1) {                             // stream tile g + 1
+                if (tid < TILE_C) sts = nbslot[(t0 + 1) * TILE_C + tid];
+                dma_tile(t0 + 1, (g + 1) & 1);
+            }
+            // (LDS-DMA is tracked per wave: every wave drains ITS transfers before the barrier -- see match_top2_body)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            f16_fetch<0>(frA, ldsb + (g & 1) * IMG + r * ROWB, foff);
+        } else {
+            nav = nav_next;
+        }
+        // per-lane MFMA fragments of the wave's 32 queries (k-steps 0..7; prep_kernel applied the -2) and the norm k-slot
+        u32x4 qw[16];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) qw[t] = *reinterpret_cast<const u32x4 *>(ldsb + QREG + (wave * 32 + r) * ROWB + foff[t]);
+        u32x4 qslot = {0u, 0u, 0u, 0u};
+        if (h == 0) {
+            unsigned nh, nm, nl;
+            bf16_three(nav, nh, nm, nl);
+            qslot = (u32x4){BF16_ONE | (BF16_ONE << 16), BF16_ONE | (nh << 16), nm | (nl << 16), 0u};
+        }
+        Top3 best;
+        best.k1 = best.k2 = best.k3 = KEY_INF; best.t1 = best.t2 = 0;
+        auto fold = [&](int g1, int g2, int g3, int tag) {
+            if (__any(g1 < best.k3)) {
+                top3_merge(best, g1, tag);
+                top3_merge(best, g2, tag);
+                top3_merge(best, g3, tag);
+            }
+        };
+        bool next_ahead = false;
+        f32x16 a0, a1, b0, b1;
+        for (int n = 0; n < ntiles; ++n) {
+            const int b = (g + n) & 1;
+            const char *tb = ldsb + b * IMG + r * ROWB;
+            const char *sp = ldsb + SLOT0 + b * SLOTB + r * 16;
+            int g1 = KEY_INF, g2 = KEY_INF, g3 = KEY_INF;
+            f16_fetch<4>(frB, tb, foff);
+            f16_slots(a0, a1, sp, qslot);
+            if (n == 0) {
+                f16_half<false, 0>(a0, a1, b0, frA, qw, g1, g2, g3);
+                f16_fetch<0>(frA, tb + 64 * ROWB, foff);
+                f16_half<false, 4>(a0, a1, b1, frB, qw, g1, g2, g3);
+            } else {
+                f16_half<true, 0>(a0, a1, b0, frA, qw, g1, g2, g3);
+                f16_fetch<0>(frA, tb + 64 * ROWB, foff);
+                f16_half<true, 4>(a0, a1, b1, frB, qw, g1, g2, g3);
+                fold(g1, g2, g3, 2 * n - 1);
+            }
+            g1 = g2 = g3 = KEY_INF;
+            f16_fetch<4>(frB, tb + 64 * ROWB, foff);
+            f16_slots(b0, b1, sp + 64 * 16, qslot);
+            f16_half<true, 0>(b0, b1, a0, frA, qw, g1, g2, g3);
+            // stream tiles g + n + 1 (landed by now; its slots are still in registers) and g + n + 2 (to be requested)
+            const bool in1 = n + 1 < ntiles, in2 = n + 2 < ntiles;
+            const bool ex1 = in1 || have_next;
+            if (ex1) {
+                if (tid < TILE_C) *reinterpret_cast<uint4 *>(ldsb + SLOT0 + (b ^ 1) * SLOTB + tid * 16) = sts;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                const int k2 = n + 2 - ntiles;                        // index in the next segment when tile g + n + 2 lies there
+                const bool ex2 = in2 || (have_next && ntiles >= 2 && k2 < nxt.ntiles);
+                if (ex2) {
+                    const int tile2 = in2 ? t0 + n + 2 : nxt.t0 + k2;
+                    if (tid < TILE_C) sts = nbslot[tile2 * TILE_C + tid];
+                    dma_tile(tile2, b);
+                }
+                if (n == 0 && have_next && ntiles >= 2) {             // every wave holds its fragments: the query region is free
+                    dma_queries(nxt.qb * QB);
+                    nav_next = norm_of(nxt.qb);
+                    next_ahead = true;
+                }
+                if (in1 || next_ahead) f16_fetch<0>(frA, ldsb + (b ^ 1) * IMG + r * ROWB, foff);
+            }
+            f16_half<true, 4>(b0, b1, a1, frB, qw, g1, g2, g3);
+            fold(g1, g2, g3, 2 * n);
+        }
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(b0), "+v"(b1));
+        select_half(b0, b1, best, 2 * ntiles - 1);
+        segment_publish(best, plan, grp, cur.pc, cur.qbl, vg, cur.tt + ntiles == cur.Lc, t0 * TILE_C, h, cur.qb * QB + wave * 32 + r,
+                        nA, S, partial, partial3);
+        if (!have_next) break;
+        g += ntiles;
+        ahead = next_ahead;
+        cur = nxt;
     }
 }
 
@@ -1165,7 +1349,7 @@ __global__ __launch_bounds__(256) void fine_rows_kernel(MatchBatch bt)
     const int nA = pair_nA(c), nB = pair_nB(c), lane = threadIdx.x & 63, k4 = lane & 31;
     const int count = (nA > 0 && nB > 0) ? min(max(*pair_f1_count(c), 0), nA) : 0;
     if (blockIdx.x == 0 && threadIdx.x < 64) {
-        const MatchPlan p = make_plan_on(count, nB, bt.n_cu, bt.n_xcd, lane, 64, [](int v) {
+        const MatchPlan p = make_plan_on(count, nB, bt.n_cu2, bt.n_xcd, lane, 64, [](int v) {
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d));
             return v;
@@ -1671,6 +1855,9 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
     bt.err_coeff2 = screen_err_coeff(1);
     int max_rows = 0, max_a = 0;
     bool dev_sized = false;
+    // persistent workgroups per CU of the (first) screening pass. (Two for the coarse pass -- its 68 KiB of LDS would allow
+    // it -- measured 70 us instead of 58: half as many tiles per segment, twice the segment prologues.)
+    const int wg_per_cu = 1;
     for (int k = 0; k < n; ++k) {
         const MatchJob &j = jobs[k];
         if (j.nA <= 0 || j.nB <= 0) continue;                 // empty sets: a no-op for this pair, as in the reference
@@ -1678,7 +1865,7 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
         const bool dev = j.d_nA != nullptr;
         if (q > 0 && dev != dev_sized) return (int)hipErrorInvalidValue;
         dev_sized = dev;
-        if (!dev) plans[q] = make_plan(j.nA, j.nB);
+        if (!dev) plans[q] = make_plan(j.nA, j.nB, wg_per_cu);
         const MatchWs w = carve(j.workspace, j.nA, j.nB);
         MatchPair &c = bt.p[q];
         c.A = j.A; c.B = j.B; c.nA = j.nA; c.nB = j.nB; c.na = w.na; c.nb = w.nb; c.partial = w.partial;
@@ -1695,7 +1882,10 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
     }
     if (bt.n == 0) return 0;
     const int n_cu = nm_cu_count();
-    bt.n_cu = n_cu; bt.n_xcd = nm_xcd_count();
+    // second pass of the two-stage screen: about a percent of the rows, so a quarter of the CUs per pair is plenty and the
+    // launch (one grid row per pair) does not spend its time dispatching workgroups that find nothing to do
+    const int n_wg2 = (n_cu % 4 == 0 && (n_cu / 4) % nm_xcd_count() == 0) ? n_cu / 4 : n_cu;
+    bt.n_cu = n_cu * wg_per_cu; bt.n_cu2 = n_wg2; bt.n_xcd = nm_xcd_count();
     if (phases & NM_MATCH_PHASE_PREP) {
         const dim3 pg(nm_divup(max_rows, PREP_ROWS), bt.n);
         if (screen == 2) hipLaunchKernelGGL(prep_kernel<2>, pg, dim3(256), 0, st, bt);
@@ -1707,10 +1897,11 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
     }
     const size_t lds_full = (size_t)2 * TILE_C * KP * sizeof(float);
     // coarse pass: two 32 KiB images + the norm slots; the staged query block (256 rows at a 272-byte pitch) is as large
-    const size_t lds_bytes = screen == 2 ? (size_t)2 * TILE_C * (DIM * 2) + 2 * TILE_C * 16 : lds_full;
-    static_assert(2 * TILE_C * (DIM * 2) + 2 * TILE_C * 16 == QB * (DIM * 2 + 16), "coarse pass: query staging fills the tile buffers exactly");
+    const size_t lds_bytes = lds_full;
+    static_assert(2 * TILE_C * (DIM * 2) + 2 * TILE_C * 16 + QB * (DIM * 2) == 2 * TILE_C * KP * sizeof(float),
+                  "coarse pass: two tile images, the norm slots and the query region take what the other screens' tiles take");
     // per call: the attribute is per device, and a process may drive several (cheap host-side call, not a stream op)
-    NM_RETURN_IF(hipFuncSetAttribute(screen == 2 ? reinterpret_cast<const void *>(match_top2_kernel<2>)
+    NM_RETURN_IF(hipFuncSetAttribute(screen == 2 ? reinterpret_cast<const void *>(match_coarse_kernel)
                                      : screen ? reinterpret_cast<const void *>(match_top2_kernel<1>)
                                               : reinterpret_cast<const void *>(match_top2_kernel<0>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -1720,13 +1911,12 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
     for (int q = 0; (phases & NM_MATCH_PHASE_SCREEN) && q < bt.n; ++q) {
         const MatchPair &c = bt.p[q];
         // device-sized: one workgroup per CU, of which the first plan.G (decided on the device) work
-        const int grid = dev_sized ? n_cu : plans[q].G;
+        const int grid = dev_sized ? n_cu * wg_per_cu : plans[q].G;
         const MatchPlan plan_arg = dev_sized ? MatchPlan{} : plans[q];
         nm_prof_begin(NM_PROF_MATCH_TOP2, st);
         if (screen == 2)
-            hipLaunchKernelGGL(match_top2_kernel<2>, dim3(grid), dim3(512), lds_bytes, st,
-                               reinterpret_cast<const float *>(c.Ah), c.nA, reinterpret_cast<const float *>(c.Bh), c.nB,
-                               c.na, c.nb, c.nbslot, plan_arg, c.partial, c.partial3, c.d_nA, c.d_nB, c.d_plan);
+            hipLaunchKernelGGL(match_coarse_kernel, dim3(grid), dim3(512), lds_bytes, st, c.Ah, c.nA, c.Bh, c.nB,
+                               c.na, c.nbslot, plan_arg, c.partial, c.partial3, c.d_nA, c.d_nB, c.d_plan);
         else if (screen)
             hipLaunchKernelGGL(match_top2_kernel<1>, dim3(grid), dim3(512), lds_bytes, st,
                                reinterpret_cast<const float *>(c.As), c.nA, reinterpret_cast<const float *>(c.Bs), c.nB,
@@ -1746,7 +1936,7 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
         NM_LAUNCH_CHECK();
         hipLaunchKernelGGL(fine_rows_kernel, dim3(nm_divup(max_a, PREP_ROWS), bt.n), dim3(256), 0, st, bt);
         NM_LAUNCH_CHECK();
-        hipLaunchKernelGGL(match_top2_rows_kernel, dim3(n_cu, bt.n), dim3(512), lds_full, st, bt);
+        hipLaunchKernelGGL(match_top2_rows_kernel, dim3(n_wg2, bt.n), dim3(512), lds_full, st, bt);
         NM_LAUNCH_CHECK();
         hipLaunchKernelGGL(match_finalize_kernel<2>, fg, dim3(256), 0, st, bt);
     } else {
@@ -1895,11 +2085,11 @@ int nm_sift_match_plan_segments(int nA, int nB, int wg, int *segments, int max_s
     if (wg >= p.G) return 0;
     const int xg = wg % p.X, vg = wg / p.X;
     const PlanGroup grp = plan_group(p, xg);
-    const long u_end = group_begin(grp, vg + 1);
+    const unit_t u_end = group_begin(grp, vg + 1);
     SegIter it;
     it.init(group_begin(grp, vg), u_end);
     int n = 0;
-    long u;
+    unit_t u;
     while (it.next(p, grp, u)) {
         int pc, qbl, tt, Lc;
         plan_locate(p, grp, u, pc, qbl, tt, Lc);
