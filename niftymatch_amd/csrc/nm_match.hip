@@ -900,6 +900,7 @@ __device__ __forceinline__ void match_top2_body(const float *__restrict__ A, int
         if (DMA) {
             // software pipeline over the 64-candidate groups: the MFMAs of group i run while group i - 1 is selected
             f32x16 b0, b1;
+            const bool wave_live = __builtin_amdgcn_readfirstlane(i0 + wave * 32) < nA;
             auto fold = [&](int g1, int g2, int g3, int tag) {
                 if (__any(g1 < best.k3)) {
                     top3_merge(best, g1, tag);
@@ -918,21 +919,28 @@ __device__ __forceinline__ void match_top2_body(const float *__restrict__ A, int
                     dma_tile(t0 + n + 1, b ^ 1);
                 }
                 int g1 = KEY_INF, g2 = KEY_INF, g3 = KEY_INF;
-                if (n == 0) {
+                if (!wave_live) {
+                    // none of this wave's 32 queries exists (the second pass of the two-stage screen lists a few dozen rows
+                    // per 256-row block): it only moves its share of the tiles
+                } else if (n == 0) {
                     mfma_half_bf16<false>(a0, a1, b0, b1, tb, foff, sp, qw, qslot, g1, g2, g3);
                 } else {
                     mfma_half_bf16<true>(a0, a1, b0, b1, tb, foff, sp, qw, qslot, g1, g2, g3);
                     fold(g1, g2, g3, 2 * n - 1);
                 }
                 g1 = g2 = g3 = KEY_INF;
-                mfma_half_bf16<true>(b0, b1, a0, a1, tb + 64 * ROWB, foff, sp + 64 * 16, qw, qslot, g1, g2, g3);
-                fold(g1, g2, g3, 2 * n);
+                if (wave_live) {
+                    mfma_half_bf16<true>(b0, b1, a0, a1, tb + 64 * ROWB, foff, sp + 64 * 16, qw, qslot, g1, g2, g3);
+                    fold(g1, g2, g3, 2 * n);
+                }
                 if (n + 1 < ntiles && tid < TILE_C) *reinterpret_cast<uint4 *>(ldsb + SLOT0 + (b ^ 1) * SLOTB + tid * 16) = sts;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile n + 1 has landed (this wave's share): see the prologue
                 __syncthreads();
             }
-            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(b0), "+v"(b1));
-            select_half(b0, b1, best, 2 * ntiles - 1);
+            if (wave_live) {
+                asm volatile("s_nop 15\n\ts_nop 3" : "+v"(b0), "+v"(b1));
+                select_half(b0, b1, best, 2 * ntiles - 1);
+            }
         } else
         for (int n = 0; n < ntiles; ++n) {
             const float *buf = lds + (n & 1) * (TILE_C * KP);
@@ -1264,6 +1272,48 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(MatchBatch bt)
     // then each lane walks its row at the conflict-free pitch -- was built and measured: 155 us per 16-pair call instead of
     // 146. The kernel moves ~500 MB of scattered 512-byte rows per call, ~3.3 TB/s out of L2 / Infinity Cache: it is bound by
     // that gather, not by the shape of its load instructions.)
+    // Ratio test decided by the screen alone (mode 0: only result[i] is wanted). Let E(bn) bound |value(j) - d_ref(j)| for a
+    // candidate of norm |b_j| <= bn (as in the proof below; + 2^-18 for the key truncation and gamma_130 for d_ref against d,
+    // both relative to at most (sqrt na + bn)^2), and Et(X) := E(min(sqrt na + sqrt X, sqrt nb_max)): a candidate with
+    // d_ref(j) <= X has |b_j| <= sqrt na + sqrt X (triangle inequality), so its value is <= X + Et(X). The two smallest
+    // values v1 <= v2 sit at j1, j2, every other candidate has a value >= v2. Hence
+    //   * every d_ref exceeds lo1 := v1 - Et(v1) (a candidate at or below it would have a value below v1), every d_ref
+    //     but j1's exceeds lo2 := v2 - Et(v2), and min2 <= hi2 := max(v1 + E(|b_j1|), v2 + E(|b_j2|)) with the two
+    //     candidates' own norms;
+    //   * lo1 >= ambiguity hi2 (1 + 1e-5) with lo2 > 0 gives min1 / min2 >= ambiguity after its rounding -> -1 (the scan's
+    //     clamp of min2 only lowers min2);
+    //   * with hi1 := v1 + E(|b_j1|):  v2 > hi1 + Et(hi1) makes j1 the unique minimum (any other candidate at or below hi1
+    //     would have a value below v2), min2 > lo2, and hi1 < ambiguity lo2 (1 - 1e-5) gives min1 / min2 < ambiguity -> j1
+    //     (not taken for global index 0, where the scan's clamp of min2 could matter).
+    // Most rows of a SIFT pair are decided here and never gather their candidates' 512-byte rows, which is what this kernel's
+    // time was (3 KB per row; round 3). Any comparison with a NaN fails: the row takes the exact route.
+    const float nai = na[i], nbm = c.nbmax[0];
+    const bool in_domain = (STAGE == 1) ? (nai < F16_NORM_LIMIT && nbm < F16_NORM_LIMIT) : (nai < NORM_LIMIT && nbm < NORM_LIMIT);
+    if (mode == 0 && in_domain && ci[1] >= 0) {
+        const float sna = __builtin_sqrtf(nai), snb = __builtin_sqrtf(nbm);
+        const float coeff = (STAGE == 2 ? bt.err_coeff2 : bt.err_coeff) + 1.2e-5f;
+        const float rai = (STAGE == 1) ? c.ra[i] : 0.f, rbm = (STAGE == 1) ? c.nbmax[1] : 0.f;
+        auto E_of = [&](float bn, float rbj) {            // bn: upper bound of |b_j|, rbj: of its fp16 residual norm
+            float e = coeff * ((sna + bn) * (sna + bn)) * 1.0001f + 1e-30f;
+            if (STAGE == 1) e += 2.0f * (rai * (bn + rbj) + (sna * 1.000001f + rai) * rbj + rai * rbj) * 1.0001f;
+            return e;
+        };
+        auto Et = [&](float X) {
+            const float bn = __builtin_fminf(sna + __builtin_sqrtf(__builtin_fmaxf(X, 0.f)) * 1.00001f, snb);
+            return E_of(bn, __builtin_fminf(rbm, 4.8829e-4f * bn + 7e-4f));
+        };
+        const float v1 = cd[0], v2 = cd[1];
+        const float e1 = E_of(__builtin_sqrtf(c.nb[ci[0]]) * 1.000001f, (STAGE == 1) ? c.rb[ci[0]] : 0.f);
+        const float e2 = E_of(__builtin_sqrtf(c.nb[ci[1]]) * 1.000001f, (STAGE == 1) ? c.rb[ci[1]] : 0.f);
+        const float lo1 = v1 - Et(v1), lo2 = v2 - Et(v2), hi1 = v1 + e1, hi2 = __builtin_fmaxf(hi1, v2 + e2);
+        int quick = 0;
+        if (lo2 > 0.f && lo1 >= ambiguity * hi2 * 1.00001f) quick = 1;
+        else if (lo2 > 0.f && v2 > hi1 + Et(hi1) && ambiguity > 0.f && hi1 < ambiguity * lo2 * 0.99999f && ci[0] + index_offset > 0) quick = 2;
+        if (quick) {                                      // the same for the four lanes of the quad
+            if (live && sub == 0) result[i] = (quick == 1) ? -1 : ci[0] + index_offset;
+            return;
+        }
+    }
     const int mine = (sub == 0) ? ci[0] : (sub == 1) ? ci[1] : (sub == 2) ? ci[2] : ci[3];
     float d = 0.f;
     if (mine >= 0)
@@ -1273,7 +1323,6 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(MatchBatch bt)
 #pragma unroll
     for (int k = 0; k < 4; ++k) { ed[k] = __shfl(d, ((threadIdx.x & 63) & ~3) + k); ei[k] = ci[k]; }
     if (!live || sub != 0) return;
-    const float nai = na[i];
     if (STAGE == 1) {
         // outside the coarse pass's domain (|2 x| must stay inside the fp16 range: squared norms below F16_NORM_LIMIT; NaN and
         // inf fail the comparison too): the bf16x3 pass decides, or passes the row on to the exact scan
