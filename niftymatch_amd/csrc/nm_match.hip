@@ -640,32 +640,33 @@ __device__ __forceinline__ void mfma_half_bf16(f32x16 &acc0, f32x16 &acc1, const
 // tb = this lane's candidate row of group 0 in the tile image (256-byte rows, 16-byte chunks XOR-swizzled by row & 15);
 // foff[t] = byte offset of the lane's chunk of k-step t; group 1 = + 32 rows. qf[s] = the query's k-step s (k = 16 s + 8 h ..+7).
 #define NM_MFMA_H "v_mfma_f32_32x32x16_f16 "
+// Selection in the coarse pass keeps the TWO smallest keys of a 64-candidate group (v_and_or, v_med3, v_min: three
+// instructions per value instead of four -- the selection is this kernel's largest single cost) and hands the second
+// one to the running triple a second time as the group's third: every value of the group it did not keep is >= it, which
+// is all the third key is for (the lower bound `rest` of the finalize pass). The price: a segment whose two best
+// candidates share a group reports third == second and its row goes to the second pass (~0.5 % of the rows more).
 template <bool SELECT, int E0>
 __device__ __forceinline__ void f16_kstep(f32x16 &acc0, f32x16 &acc1, const u32x4 h0, const u32x4 h1, const u32x4 qh,
-                                          float p0, float p1, float p2, float p3, int &g1, int &g2, int &g3)
+                                          float p0, float p1, float p2, float p3, int &g1, int &g2)
 {
     if (SELECT) {
         int k;
         const int mask = ~((1 << KEY_SLOT_BITS) - 1);
-        asm volatile(NM_MFMA_H "%0, %6, %8, %0\n\t"
-                     "v_and_or_b32 %5, %9, %13, %14\n\t"
-                     "v_med3_i32 %4, %3, %4, %5\n\t"
-                     "v_med3_i32 %3, %2, %3, %5\n\t"
-                     "v_min_i32 %2, %2, %5\n\t"
-                     "v_and_or_b32 %5, %10, %13, %15\n\t"
-                     "v_med3_i32 %4, %3, %4, %5\n\t"
-                     "v_med3_i32 %3, %2, %3, %5\n\t"
-                     "v_min_i32 %2, %2, %5\n\t"
-                     NM_MFMA_H "%1, %7, %8, %1\n\t"
-                     "v_and_or_b32 %5, %11, %13, %16\n\t"
-                     "v_med3_i32 %4, %3, %4, %5\n\t"
-                     "v_med3_i32 %3, %2, %3, %5\n\t"
-                     "v_min_i32 %2, %2, %5\n\t"
-                     "v_and_or_b32 %5, %12, %13, %17\n\t"
-                     "v_med3_i32 %4, %3, %4, %5\n\t"
-                     "v_med3_i32 %3, %2, %3, %5\n\t"
-                     "v_min_i32 %2, %2, %5"
-                     : "+v"(acc0), "+v"(acc1), "+v"(g1), "+v"(g2), "+v"(g3), "=&v"(k)
+        asm volatile(NM_MFMA_H "%0, %5, %7, %0\n\t"
+                     "v_and_or_b32 %4, %8, %12, %13\n\t"
+                     "v_med3_i32 %3, %2, %3, %4\n\t"
+                     "v_min_i32 %2, %2, %4\n\t"
+                     "v_and_or_b32 %4, %9, %12, %14\n\t"
+                     "v_med3_i32 %3, %2, %3, %4\n\t"
+                     "v_min_i32 %2, %2, %4\n\t"
+                     NM_MFMA_H "%1, %6, %7, %1\n\t"
+                     "v_and_or_b32 %4, %10, %12, %15\n\t"
+                     "v_med3_i32 %3, %2, %3, %4\n\t"
+                     "v_min_i32 %2, %2, %4\n\t"
+                     "v_and_or_b32 %4, %11, %12, %16\n\t"
+                     "v_med3_i32 %3, %2, %3, %4\n\t"
+                     "v_min_i32 %2, %2, %4"
+                     : "+v"(acc0), "+v"(acc1), "+v"(g1), "+v"(g2), "=&v"(k)
                      : "v"(h0), "v"(h1), "v"(qh), "v"(p0), "v"(p1), "v"(p2), "v"(p3), "s"(mask),
                        "n"(E0), "n"(E0 + 1), "n"(E0 + 2), "n"(E0 + 3)
                      : "memory");
@@ -703,12 +704,12 @@ __device__ __forceinline__ void f16_slots(f32x16 &acc0, f32x16 &acc1, const char
 // 4 KS0 .. 4 KS0 + 15 of that group) are folded into the key triple meanwhile
 template <bool SELECT, int KS0>
 __device__ __forceinline__ void f16_half(f32x16 &acc0, f32x16 &acc1, const f32x16 &pv, const u32x4 (&fr)[8],
-                                         const u32x4 (&qf)[16], int &g1, int &g2, int &g3)
+                                         const u32x4 (&qf)[16], int &g1, int &g2)
 {
-    f16_kstep<SELECT, 4 * KS0>(acc0, acc1, fr[0], fr[1], qf[KS0], pv[0], pv[1], pv[2], pv[3], g1, g2, g3);
-    f16_kstep<SELECT, 4 * KS0 + 4>(acc0, acc1, fr[2], fr[3], qf[KS0 + 1], pv[4], pv[5], pv[6], pv[7], g1, g2, g3);
-    f16_kstep<SELECT, 4 * KS0 + 8>(acc0, acc1, fr[4], fr[5], qf[KS0 + 2], pv[8], pv[9], pv[10], pv[11], g1, g2, g3);
-    f16_kstep<SELECT, 4 * KS0 + 12>(acc0, acc1, fr[6], fr[7], qf[KS0 + 3], pv[12], pv[13], pv[14], pv[15], g1, g2, g3);
+    f16_kstep<SELECT, 4 * KS0>(acc0, acc1, fr[0], fr[1], qf[KS0], pv[0], pv[1], pv[2], pv[3], g1, g2);
+    f16_kstep<SELECT, 4 * KS0 + 4>(acc0, acc1, fr[2], fr[3], qf[KS0 + 1], pv[4], pv[5], pv[6], pv[7], g1, g2);
+    f16_kstep<SELECT, 4 * KS0 + 8>(acc0, acc1, fr[4], fr[5], qf[KS0 + 2], pv[8], pv[9], pv[10], pv[11], g1, g2);
+    f16_kstep<SELECT, 4 * KS0 + 12>(acc0, acc1, fr[6], fr[7], qf[KS0 + 3], pv[12], pv[13], pv[14], pv[15], g1, g2);
 }
 #undef NM_MFMA_H
 
@@ -1091,23 +1092,23 @@ __global__ __launch_bounds__(512, 1) void match_coarse_kernel(const unsigned *__
             const int b = (g + n) & 1;
             const char *tb = ldsb + b * IMG + r * ROWB;
             const char *sp = ldsb + SLOT0 + b * SLOTB + r * 16;
-            int g1 = KEY_INF, g2 = KEY_INF, g3 = KEY_INF;
+            int g1 = KEY_INF, g2 = KEY_INF;
             f16_fetch<4>(frB, tb, foff);
             f16_slots(a0, a1, sp, qslot);
             if (n == 0) {
-                f16_half<false, 0>(a0, a1, b0, frA, qw, g1, g2, g3);
+                f16_half<false, 0>(a0, a1, b0, frA, qw, g1, g2);
                 f16_fetch<0>(frA, tb + 64 * ROWB, foff);
-                f16_half<false, 4>(a0, a1, b1, frB, qw, g1, g2, g3);
+                f16_half<false, 4>(a0, a1, b1, frB, qw, g1, g2);
             } else {
-                f16_half<true, 0>(a0, a1, b0, frA, qw, g1, g2, g3);
+                f16_half<true, 0>(a0, a1, b0, frA, qw, g1, g2);
                 f16_fetch<0>(frA, tb + 64 * ROWB, foff);
-                f16_half<true, 4>(a0, a1, b1, frB, qw, g1, g2, g3);
-                fold(g1, g2, g3, 2 * n - 1);
+                f16_half<true, 4>(a0, a1, b1, frB, qw, g1, g2);
+                fold(g1, g2, g2, 2 * n - 1);
             }
-            g1 = g2 = g3 = KEY_INF;
+            g1 = g2 = KEY_INF;
             f16_fetch<4>(frB, tb + 64 * ROWB, foff);
             f16_slots(b0, b1, sp + 64 * 16, qslot);
-            f16_half<true, 0>(b0, b1, a0, frA, qw, g1, g2, g3);
+            f16_half<true, 0>(b0, b1, a0, frA, qw, g1, g2);
             // stream tiles g + n + 1 (landed by now; its slots are still in registers) and g + n + 2 (to be requested)
             const bool in1 = n + 1 < ntiles, in2 = n + 2 < ntiles;
             const bool ex1 = in1 || have_next;
@@ -1129,8 +1130,8 @@ __global__ __launch_bounds__(512, 1) void match_coarse_kernel(const unsigned *__
                 }
                 if (in1 || next_ahead) f16_fetch<0>(frA, ldsb + (b ^ 1) * IMG + r * ROWB, foff);
             }
-            f16_half<true, 4>(b0, b1, a1, frB, qw, g1, g2, g3);
-            fold(g1, g2, g3, 2 * n);
+            f16_half<true, 4>(b0, b1, a1, frB, qw, g1, g2);
+            fold(g1, g2, g2, 2 * n);
         }
         asm volatile("s_nop 15\n\ts_nop 3" : "+v"(b0), "+v"(b1));
         select_half(b0, b1, best, 2 * ntiles - 1);
