@@ -567,6 +567,10 @@ def main():
                 "kpts": [arenas[k].kpts[:n].cpu().numpy() for k, n in ((0, nA), (1, nB))],
                 "desc": [arenas[k].desc[:n].cpu().numpy() for k, n in ((0, nA), (1, nB))],
                 "match": results[0][:nA].cpu().numpy()}
+        try:                                              # pair 0 of the last call: rows the second pass / the exact fallback took
+            snap["rows"] = bwss[0].row_counts(0)
+        except Exception:
+            snap["rows"] = None
 
     kp_rank = float(sum(sum(row) for row in counts_host[:args.steps]))
     cmp_rank = float(sum(row[2 * i] * row[2 * i + 1] for row in counts_host[:args.steps] for i in range(P)))
@@ -732,11 +736,14 @@ def main():
             return r
         roof = roof_of(screen, match_ms, match_fl)
         roof["launch_shape_last_step_pair0"] = [nA, nB, 128]
+        if snap.get("rows"):
+            roof["rows_second_pass_sample"], roof["rows_exact_fallback_sample"] = snap["rows"]     # first pair of the last match call
         out = {
             "metric": METRIC, "value": round(pairs_total / dt, 3), "unit": "frame-pairs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[2]: SIFT detect+describe x2 + fused BF L2 match per 1920x1080 pair", "match_screen": screen,
+            "config": {"workload": "configs[2]: SIFT detect+describe x2 + fused BF L2 match per 1920x1080 pair",
+                       "match_screen": {"f16": "two-stage: f16 coarse pass + bf16x3 second pass on the unproven rows"}.get(screen, screen),
                        "match_sizes": "device",
                        "frames": "fresh every step: %d distinct sets of %d frames per rank, step k on set k mod %d "
                                  "(warmup + steps = %d)" % (n_sets, 2 * P, n_sets, total_steps),

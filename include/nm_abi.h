@@ -180,8 +180,11 @@ NM_API int nm_get_sift_matches_f32(const float *distance, int rows, int cols, in
 NM_API size_t nm_sift_match_workspace_bytes(int nA, int nB);
 /* Which MFMA screen the fused matcher runs before its exact finalize (process-wide; results are identical):
  * 0 = fp32 (v_mfma_f32_32x32x2_f32 on the descriptors themselves), 1 = bf16x3 (v_mfma_f32_32x32x16_bf16 on operands
- * split into two bf16 pieces: ~3x faster, a few more rows take the exact fallback). Default 1; the environment
- * variable NM_MATCH_SCREEN=f32|bf16x3 sets the initial value. Extension: the reference has one (exact VALU) path. */
+ * split into two bf16 pieces: ~3x faster, a few more rows take the exact fallback), 2 = two-stage (a coarse pass with one
+ * fp16 product per k on v_mfma_f32_32x32x16_f16 whose error is bounded per row from the norms of the fp16 rounding
+ * residuals; rows it cannot prove -- about a percent on SIFT descriptors, every row when a squared norm reaches 1e9 -- are
+ * screened again by the bf16x3 kernel; ~2x faster again). Default 2; the environment variable
+ * NM_MATCH_SCREEN=f32|bf16x3|f16 sets the initial value. Extension: the reference has one (exact VALU) path. */
 NM_API int nm_sift_match_set_screen(int screen);
 NM_API int nm_sift_match_get_screen(void);
 /* n <= 16 independent matches in one call (arrays of n): the norms, finalize and fallback launches cover all pairs at

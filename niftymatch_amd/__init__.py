@@ -354,6 +354,15 @@ class MatchBatchDevWorkspace:
         self.pair_bytes = lib().nm_sift_match_batch_dev_workspace_bytes(1, capA, capB)
         self.buf = torch.empty(n * self.pair_bytes, dtype=torch.uint8, device=device)
 
+    def row_counts(self, k):
+        """(rows of pair k that the bf16x3 second pass screened again, rows that took the exact fallback) in the last call
+        on this workspace; the first is meaningful under the two-stage screen only. Synchronises the stream."""
+        class _View:                                     # the pair's slice, shaped like a single-pair workspace
+            pass
+        v = _View()
+        v.buf = self.buf[k * self.pair_bytes:(k + 1) * self.pair_bytes]
+        return match_second_pass_count(v, self.capA, self.capB), match_fallback_count(v, self.capA, self.capB)
+
 
 MATCH_PHASE_PREP, MATCH_PHASE_SCREEN, MATCH_PHASE_FINISH = 1, 2, 4
 

@@ -1934,7 +1934,8 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
     const int n_cu = nm_cu_count();
     // second pass of the two-stage screen: about a percent of the rows, so a quarter of the CUs per pair is plenty and the
     // launch (one grid row per pair) does not spend its time dispatching workgroups that find nothing to do
-    const int n_wg2 = (n_cu % 4 == 0 && (n_cu / 4) % nm_xcd_count() == 0) ? n_cu / 4 : n_cu;
+    // (calls of a few pairs -- the 100k x 100k all-pairs case lists thousands of rows -- keep the whole chip)
+    const int n_wg2 = (bt.n >= 4 && n_cu % 4 == 0 && (n_cu / 4) % nm_xcd_count() == 0) ? n_cu / 4 : n_cu;
     bt.n_cu = n_cu * wg_per_cu; bt.n_cu2 = n_wg2; bt.n_xcd = nm_xcd_count();
     if (phases & NM_MATCH_PHASE_PREP) {
         const dim3 pg(nm_divup(max_rows, PREP_ROWS), bt.n);
