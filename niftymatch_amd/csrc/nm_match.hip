@@ -62,30 +62,48 @@ typedef int unit_t;
 struct PlanGroup { int nq, q0, base, rem; };
 
 #define NM_HD __host__ __device__ __forceinline__
+// x / d for 0 <= x, 0 < d. On the device an integer division is ~40 vector instructions, and a workgroup makes a few dozen of
+// them per segment on values that are the same for all its lanes: below 2^20 (305 k units at 100k x 100k) the quotient comes
+// from one v_rcp_f32 and a remainder check instead (the estimate is off by at most one there: 2^20 x 2^-22 relative error
+// + the truncation).
+NM_HD int pdiv(int x, int d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (x < (1 << 20)) {
+        int q = (int)((float)x * __builtin_amdgcn_rcpf((float)d));
+        int r = x - q * d;
+        if (r < 0) { q -= 1; r += d; }
+        if (r >= d) q += 1;
+        return q;
+    }
+#endif
+    return x / d;
+}
 NM_HD PlanGroup plan_group(const MatchPlan &p, int x)
 {
     PlanGroup g;
     g.nq = p.q_base + (x < p.q_rem ? 1 : 0);
     g.q0 = x * p.q_base + (x < p.q_rem ? x : p.q_rem);
     const unit_t U = (unit_t)g.nq * p.T;
-    g.base = (int)(U / p.Gx);
-    g.rem = (int)(U % p.Gx);
+    g.base = pdiv(U, p.Gx);
+    g.rem = U - g.base * p.Gx;
     return g;
 }
 NM_HD unit_t group_begin(const PlanGroup &g, int v) { return (unit_t)v * g.base + (v < g.rem ? v : g.rem); }
 NM_HD int group_owner(const PlanGroup &g, unit_t ul)            // local workgroup whose range holds local unit ul
 {
     const unit_t cut = (unit_t)g.rem * (g.base + 1);
-    return (ul < cut) ? (int)(ul / (g.base + 1)) : g.rem + (int)((ul - cut) / g.base);
+    if (ul < cut) return pdiv(ul, g.base + 1);            // (one division, not both: the values are uniform)
+    return g.rem + pdiv(ul - cut, g.base);
 }
 // local unit ul -> chunk c, local query block qbl, tile offset tt inside the piece, piece length Lc
 NM_HD void plan_locate(const MatchPlan &p, const PlanGroup &g, unit_t ul, int &c, int &qbl, int &tt, int &Lc)
 {
     const unit_t per_chunk = (unit_t)g.nq * p.Tc;
-    c = (int)(ul / per_chunk);
+    c = pdiv(ul, per_chunk);
     const int r = (int)(ul - (unit_t)c * per_chunk);
     Lc = p.T - c * p.Tc < p.Tc ? p.T - c * p.Tc : p.Tc;
-    qbl = r / Lc;
+    qbl = pdiv(r, Lc);
     tt = r - qbl * Lc;
 }
 // workgroups (of the group) that work on piece (c, qbl)
