@@ -545,9 +545,15 @@ def main():
         return max(ranks_ms) / 1e3, ranks_ms
 
     def launch_times(evs_all, counts_host):
-        """(ms, flops) of every event-timed MFMA launch: 2*N*M*128 flop with the sizes the step really had."""
+        """(ms, flops) of every event-timed MFMA launch: 2*N*M*128 flop with the sizes the step really had. The two-stage
+        screen's coarse pass is ONE launch per match call (persistent over the call's pairs; the library records the
+        call's first event pair around it and the others empty): its launches are the calls, with the flops of their pairs."""
         ms = [a.elapsed_time(b) for a, b in evs_all[:EV_STEPS * P]]
         fl = [256.0 * float(counts_host[j][2 * i]) * float(counts_host[j][2 * i + 1]) for j in range(EV_STEPS) for i in range(P)]
+        if nm.get_match_screen() == "f16":
+            calls = [(j * P + k, j * P + min(k + MB, P)) for j in range(EV_STEPS) for k in range(0, P, MB)]
+            ms = [sum(ms[a:b]) for a, b in calls]
+            fl = [sum(fl[a:b]) for a, b in calls]
         return ms, fl
 
     screen = nm.get_match_screen()
@@ -733,6 +739,10 @@ def main():
             r.update({"traffic_note": "HBM bytes per launch from the rocprofv3 PMC passes in profiles/ (stored, not live)",
                       "avg_ms": round(sum(ms) / len(ms), 4), "launches_timed": len(ms),
                       "avg_launch_flops": round(sum(fl) / len(fl), 1), "screen": scr})
+            if scr == "f16":                              # one launch = the MB pairs of a match call
+                r.update({"pairs_per_launch": MB, "avg_ms_per_pair": round(sum(ms) / len(ms) / MB, 4)})
+                if r.get("traffic"):
+                    r["traffic"] = r["traffic"] * MB
             return r
         roof = roof_of(screen, match_ms, match_fl)
         roof["launch_shape_last_step_pair0"] = [nA, nB, 128]

@@ -991,12 +991,10 @@ __device__ __forceinline__ void match_top2_body(const float *__restrict__ A, int
 //     fragments of g, after the third of the four half groups) tile g + 2 is requested into the buffer g just left.
 // A segment that follows a one-tile segment (or starts the range) cannot have been requested ahead and takes the slow
 // path: request, wait, barrier. LDS: 2 x 32 KiB tiles | 2 x 2 KiB norm slots | 64 KiB queries = 135 168 B.
-__global__ __launch_bounds__(512, 1) void match_coarse_kernel(const unsigned *__restrict__ Ah, int nA_arg,
-                                                              const unsigned *__restrict__ Bh, int nB_arg,
-                                                              const float *__restrict__ na, const uint4 *__restrict__ nbslot,
-                                                              MatchPlan plan_arg, float4 *__restrict__ partial,
-                                                              float *__restrict__ partial3, const int *__restrict__ d_nA,
-                                                              const int *__restrict__ d_nB, const MatchPlan *__restrict__ d_plan)
+// ONE launch per call: the workgroups are persistent over the PAIRS of the call too (every pair's plan is in device memory,
+// nbmax_kernel), so the launch, the kernel-argument and plan loads and the drain of the slowest workgroup are paid once
+// per call instead of once per pair (~9 us of fixed cost per pair beside ~40 us of tiles when each pair was a launch).
+__global__ __launch_bounds__(512, 1) void match_coarse_kernel(MatchBatch bt)
 {
     constexpr int ROWB = DIM * 2, IMG = TILE_C * ROWB, SLOT0 = 2 * IMG, SLOTB = TILE_C * 16, QREG = SLOT0 + 2 * SLOTB;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1004,22 +1002,6 @@ __global__ __launch_bounds__(512, 1) void match_coarse_kernel(const unsigned *__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wg = blockIdx.x;
-    int nA = nA_arg, nB = nB_arg;
-    MatchPlan plan = plan_arg;
-    if (d_plan) {                                         // uniform: scalar loads
-        if (d_nA) nA = min(max(*d_nA, 0), nA_arg);
-        if (d_nB) nB = min(max(*d_nB, 0), nB_arg);
-        plan = *d_plan;
-        if (nA <= 0 || nB <= 0 || wg >= plan.G) return;
-    }
-    const int S = plan.S;
-    const int xg = wg % plan.X, vg = wg / plan.X;
-    const PlanGroup grp = plan_group(plan, xg);
-    const unit_t u_begin = group_begin(grp, vg), u_end = group_begin(grp, vg + 1);
-    SegIter it;
-    it.init(u_begin, u_end);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(Bh), 0, nB * ROWB, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(Ah), 0, nA * ROWB, 0x00020000);
 
     // LDS-DMA: one wave-instruction lands 1 KiB = four 256-byte rows, lane-linear; the 16-byte chunks of a row are XOR-swizzled
     // with (row & 15) on the SOURCE side here and in the fragment reads' offsets (foff). Wave-instruction t of a wave covers
@@ -1031,6 +1013,26 @@ __global__ __launch_bounds__(512, 1) void match_coarse_kernel(const unsigned *__
     for (int t = 0; t < 4; ++t) dvoff[t] = (unsigned)((lane >> 4) * ROWB + (((lane & 15) ^ ((4 * t + (lane >> 4)) & 15)) << 4));
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     typedef __attribute__((address_space(3))) void lds_void;
+    bool worked = false;
+    for (int pq = 0; pq < bt.n; ++pq) {
+    const MatchPair &c = bt.p[pq];
+    const int nA = pair_nA(c), nB = pair_nB(c);
+    if (nA <= 0 || nB <= 0) continue;                     // an empty set is a no-op for the pair, as in the reference
+    const MatchPlan plan = *c.d_plan;                     // uniform: scalar loads
+    if (wg >= plan.G) continue;
+    const unsigned *__restrict__ Ah = c.Ah, *__restrict__ Bh = c.Bh;
+    const float *__restrict__ na = c.na;
+    const uint4 *__restrict__ nbslot = c.nbslot;
+    float4 *__restrict__ partial = c.partial;
+    float *__restrict__ partial3 = c.partial3;
+    const int S = plan.S;
+    const int xg = wg % plan.X, vg = wg / plan.X;
+    const PlanGroup grp = plan_group(plan, xg);
+    const unit_t u_begin = group_begin(grp, vg), u_end = group_begin(grp, vg + 1);
+    SegIter it;
+    it.init(u_begin, u_end);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(Bh), 0, nB * ROWB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(Ah), 0, nA * ROWB, 0x00020000);
     auto dma_tile = [&](int tile, int b) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -1054,7 +1056,9 @@ __global__ __launch_bounds__(512, 1) void match_coarse_kernel(const unsigned *__
     auto norm_of = [&](int qb) { const int qi = qb * QB + wave * 32 + r; return (qi < nA) ? na[qi] : 0.f; };
 
     unit_t u;
-    if (!it.next(plan, grp, u)) return;
+    if (!it.next(plan, grp, u)) continue;
+    if (worked) __syncthreads();                          // slower waves may still read the previous pair's last tile
+    worked = true;
     Seg cur = locate(u);
     bool ahead = false;                                   // the current segment's queries and first tile(s) were requested ahead
     int g = 0;                                            // stream tile index of the current segment's first tile (its parity picks the buffer)
@@ -1159,6 +1163,7 @@ __global__ __launch_bounds__(512, 1) void match_coarse_kernel(const unsigned *__
         g += ntiles;
         ahead = next_ahead;
         cur = nxt;
+    }
     }
 }
 
@@ -1943,7 +1948,9 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
         c.As = w.As; c.Bs = w.Bs; c.nbslot = w.nbslot;
         if (screen == 2) { c.Ah = w.Ah; c.Bh = w.Bh; c.ra = w.ra; c.rb = w.rb; c.na2 = w.na2; c.f1_list = w.f1_list; }
         c.d_nA = j.d_nA; c.d_nB = j.d_nB;
-        c.d_plan = dev ? reinterpret_cast<MatchPlan *>(w.fb_count + 32) : nullptr;      // inside the 256-byte counter block
+        // inside the 256-byte counter block. The two-stage screen's coarse kernel takes every pair's plan from there (one
+        // launch for all pairs of the call), so nbmax_kernel makes it for the host-sized entries too
+        c.d_plan = (dev || screen == 2) ? reinterpret_cast<MatchPlan *>(w.fb_count + 32) : nullptr;
         if (j.nA >= (1 << 22) || j.nB >= (1 << 22)) return (int)hipErrorInvalidValue;   // 32-bit byte ranges of the SRDs
         max_rows = max(max_rows, j.nA + nm_divup(j.nB, TILE_C) * TILE_C);
         max_a = max(max_a, j.nA);
@@ -1982,11 +1989,12 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
         // device-sized: one workgroup per CU, of which the first plan.G (decided on the device) work
         const int grid = dev_sized ? n_cu * wg_per_cu : plans[q].G;
         const MatchPlan plan_arg = dev_sized ? MatchPlan{} : plans[q];
+        // (profiling hook: one event pair per PAIR of the call. The two-stage screen's coarse pass is one launch for all
+        // pairs: the first pair's events bracket it, the others are recorded back to back.)
         nm_prof_begin(NM_PROF_MATCH_TOP2, st);
-        if (screen == 2)
-            hipLaunchKernelGGL(match_coarse_kernel, dim3(grid), dim3(512), lds_bytes, st, c.Ah, c.nA, c.Bh, c.nB,
-                               c.na, c.nbslot, plan_arg, c.partial, c.partial3, c.d_nA, c.d_nB, c.d_plan);
-        else if (screen)
+        if (screen == 2) {
+            if (q == 0) hipLaunchKernelGGL(match_coarse_kernel, dim3(n_cu), dim3(512), lds_bytes, st, bt);
+        } else if (screen)
             hipLaunchKernelGGL(match_top2_kernel<1>, dim3(grid), dim3(512), lds_bytes, st,
                                reinterpret_cast<const float *>(c.As), c.nA, reinterpret_cast<const float *>(c.Bs), c.nB,
                                c.na, c.nb, c.nbslot, plan_arg, c.partial, c.partial3, c.d_nA, c.d_nB, c.d_plan);
