@@ -1239,15 +1239,10 @@ __device__ __forceinline__ void emit_match(int i, float m1, int idx, float m2, i
 // fallback -- and STAGE 2 after the bf16x3 pass over the listed rows: partial lists, norms and the row count are in list
 // order (r), everything else belongs to row i = f1_list[r].
 template <int STAGE>
-__global__ __launch_bounds__(256) void match_finalize_kernel(MatchBatch bt)
+__device__ __forceinline__ void finalize_block(const MatchBatch &bt, const MatchPair &c, int block, int nA, int S)
 {
-    const MatchPair &c = bt.p[blockIdx.y];
     const float *__restrict__ A = c.A, *__restrict__ B = c.B;
     const int mode = c.mode, index_offset = c.index_offset;
-    if (pair_nA(c) <= 0 || pair_nB(c) <= 0) return;      // device-sized call with an empty set: nothing was screened
-    const int nA = (STAGE == 2) ? min(max(*pair_f1_count(c), 0), pair_nA(c)) : pair_nA(c);
-    const int S = (STAGE == 2) ? pair_plan2(c)->S : pair_S(c);
-    if ((int)blockIdx.x * 64 >= nA) return;              // grids are sized for the batch's largest set (or the capacity)
     const float4 *__restrict__ partial = c.partial;
     const float *__restrict__ partial3 = c.partial3;
     const float *__restrict__ na = c.na;
@@ -1256,7 +1251,7 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(MatchBatch bt)
     float *__restrict__ min1_out = c.min1, *__restrict__ min2_out = c.min2;
     int *__restrict__ idx_out = c.idx1;
     int *__restrict__ fb_count = c.fb_count, *__restrict__ fb_list = c.fb_list;
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int t = block * 256 + threadIdx.x;
     const int sub = t & 3;
     const bool live = (t >> 2) < nA;
     const int iq = live ? (t >> 2) : nA - 1;             // row of the partial lists
@@ -1413,6 +1408,18 @@ __global__ __launch_bounds__(256) void match_finalize_kernel(MatchBatch bt)
     emit_match(i, m1, idx + index_offset, m2, mode, ambiguity, result, min1_out, idx_out, min2_out);
 }
 
+// 64 rows per 256-thread block; the blocks of a pair stride over its rows (STAGE 0 / 1: the grid covers the batch's largest
+// set or the capacity, one block per workgroup; STAGE 2: a few workgroups per pair walk the short list)
+template <int STAGE>
+__global__ __launch_bounds__(256) void match_finalize_kernel(MatchBatch bt)
+{
+    const MatchPair &c = bt.p[blockIdx.y];
+    if (pair_nA(c) <= 0 || pair_nB(c) <= 0) return;      // device-sized call with an empty set: nothing was screened
+    const int nA = (STAGE == 2) ? min(max(*pair_f1_count(c), 0), pair_nA(c)) : pair_nA(c);
+    const int S = (STAGE == 2) ? pair_plan2(c)->S : pair_S(c);
+    for (int block = blockIdx.x; block * 64 < nA; block += gridDim.x) finalize_block<STAGE>(bt, c, block, nA, S);
+}
+
 // Two-stage screen, between its passes: the rows the coarse pass listed get what the bf16x3 kernel reads -- split images
 // (scaled by -2) and norms in LIST order -- and the first wave of every pair makes the work plan for their number (the
 // same make_plan_on as everywhere). Half a wave per listed row, as in prep_kernel.
@@ -1431,9 +1438,10 @@ __global__ __launch_bounds__(256) void fine_rows_kernel(MatchBatch bt)
         if (count == 0) q.G = 0;                          // nothing listed: every workgroup of the second pass leaves at once
         if (lane == 0) *pair_plan2(c) = q;
     }
+    for (int blk = blockIdx.x; blk * PREP_ROWS < count; blk += gridDim.x)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        const int r = blockIdx.x * PREP_ROWS + (threadIdx.x >> 6) * 4 + (lane >> 5) + 2 * q;
+        const int r = blk * PREP_ROWS + (threadIdx.x >> 6) * 4 + (lane >> 5) + 2 * q;
         if (r >= count) continue;
         const int i = c.f1_list[r];
         const float4 x = reinterpret_cast<const float4 *>(c.A + (size_t)i * DIM)[k4];
@@ -1959,8 +1967,13 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
     const int n_cu = nm_cu_count();
     // second pass of the two-stage screen: about a percent of the rows, so a quarter of the CUs per pair is plenty and the
     // launch (one grid row per pair) does not spend its time dispatching workgroups that find nothing to do
-    // (calls of a few pairs -- the 100k x 100k all-pairs case lists thousands of rows -- keep the whole chip)
-    const int n_wg2 = (bt.n >= 4 && n_cu % 4 == 0 && (n_cu / 4) % nm_xcd_count() == 0) ? n_cu / 4 : n_cu;
+    // (calls of a few pairs -- the 100k x 100k all-pairs case lists thousands of rows -- keep the whole chip). A pair of a
+    // 16-pair call lists 10-25 rows of one 256-row block: 16 workgroups of ~6 tiles each instead of 47 of 2, and the 16
+    // pairs' second passes run side by side in one round of workgroups.
+    const int xcd = nm_xcd_count();
+    int n_wg2 = n_cu;
+    if (bt.n >= 4) n_wg2 = max(2 * xcd, (n_cu / bt.n) / xcd * xcd);
+    if (n_wg2 > n_cu || n_wg2 % xcd != 0) n_wg2 = n_cu;
     bt.n_cu = n_cu * wg_per_cu; bt.n_cu2 = n_wg2; bt.n_xcd = nm_xcd_count();
     if (phases & NM_MATCH_PHASE_PREP) {
         const dim3 pg(nm_divup(max_rows, PREP_ROWS), bt.n);
@@ -2011,11 +2024,12 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
         // launch, its plan made on the device for the number listed) and finalized as the single-pass screens are
         hipLaunchKernelGGL(match_finalize_kernel<1>, fg, dim3(256), 0, st, bt);
         NM_LAUNCH_CHECK();
-        hipLaunchKernelGGL(fine_rows_kernel, dim3(nm_divup(max_a, PREP_ROWS), bt.n), dim3(256), 0, st, bt);
+        // (the lists are short: a few workgroups per pair stride over them, see the kernels)
+        hipLaunchKernelGGL(fine_rows_kernel, dim3(min(bt.n >= 4 ? 64 : 1024, nm_divup(max_a, PREP_ROWS)), bt.n), dim3(256), 0, st, bt);
         NM_LAUNCH_CHECK();
         hipLaunchKernelGGL(match_top2_rows_kernel, dim3(n_wg2, bt.n), dim3(512), lds_full, st, bt);
         NM_LAUNCH_CHECK();
-        hipLaunchKernelGGL(match_finalize_kernel<2>, fg, dim3(256), 0, st, bt);
+        hipLaunchKernelGGL(match_finalize_kernel<2>, dim3(min((int)fg.x, bt.n >= 4 ? 32 : 512), bt.n), dim3(256), 0, st, bt);
     } else {
         hipLaunchKernelGGL(match_finalize_kernel<0>, fg, dim3(256), 0, st, bt);
     }
