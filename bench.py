@@ -247,6 +247,26 @@ def roofline_pyramid(B, o0_ms, all_ms, traffic, nodog_ms=None, dogonly_ms=None):
     return out
 
 
+# VALU wave-instructions frame_desc_kernel executes per keypoint (rocprofv3 --pmc SQ_INSTS_VALU over tools/kprofile.py,
+# profiles/r02_b_describe_detect_pmc_counters.txt: ~9.6 executed 64-sample passes x ~250); stored, like the HBM traffic
+DESC_VALU_PER_KEYPOINT = 2410.0
+VALU_ISSUE_GHZ = 2.4 / 4.0           # a SIMD issues one VALU wave-instruction per 4 cycles (fp32, fp64 and packed alike)
+
+
+def roofline_describe(B, ms, keypoints, n_cu):
+    """frame_desc_kernel of one B-frame detect call against the chip's VALU ISSUE rate (4 SIMDs per CU, one wave-instruction
+    per 4 cycles at the nominal 2.4 GHz): the kernel gathers ~1 KB per keypoint and runs ~2 400 vector instructions on
+    it, a third of them binary64 -- neither HBM nor MFMA bounds it. `achieved` = stored instruction count x the keypoints
+    of the call / the kernel's duration (HIP events through the library's profile hook)."""
+    peak = 4.0 * n_cu * VALU_ISSUE_GHZ                    # G wave-instructions per second
+    ach = DESC_VALU_PER_KEYPOINT * keypoints / (ms * 1e-3) / 1e9
+    return {"kernel": "frame_desc_kernel, %d frames per launch" % B, "bound": "valu_issue", "achieved": round(ach, 1),
+            "peak": round(peak, 1), "unit": "G wave-instructions/s", "frac": round(ach / peak, 4), "avg_ms": round(ms, 4),
+            "us_per_frame": round(1e3 * ms / B, 2), "keypoints": int(keypoints),
+            "valu_instructions_per_keypoint": DESC_VALU_PER_KEYPOINT,
+            "note": "instruction count from the rocprofv3 PMC pass in profiles/ (stored, not live); duration live"}
+
+
 def launcher_command(gpus, argv, environ):
     """`python bench.py --gpus N` with N > 1 outside torchrun: the command that re-runs this script as N ranks (one per
     GPU), or None when this process is already a rank (WORLD_SIZE set) or N == 1. Pure function: no GPU, no torch."""
@@ -651,6 +671,26 @@ def main():
     except Exception:
         pyr_all_ms = None
 
+    # descriptor kernel of one B-frame detect call alone (library profile hook; chip otherwise idle), against the VALU issue
+    # rate: it is the largest single kernel of a step and has no memory or MFMA yardstick
+    desc_roof = None
+    try:
+        ed = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(6)]
+        ms_d = []
+        with torch.cuda.stream(mstream):
+            for a, b in ed:                      # torch creates the HIP event at its first record
+                a.record(); b.record()
+            for a, b in ed:
+                nm.profile_events(nm.PROF_DESCRIBE, a, b)
+                nm.detect_describe_batch(arenas[:B], frames[:B])
+                nm.profile_events(nm.PROF_DESCRIBE, None, None)
+        mstream.synchronize()
+        ms_d = sorted(a.elapsed_time(b) for a, b in ed[1:])
+        kp_call = float(sum(int(a.num_items.item()) for a in arenas[:B]))
+        desc_roof = roofline_describe(B, ms_d[len(ms_d) // 2], kp_call, torch.cuda.get_device_properties(dev).multi_processor_count)
+    except Exception as e:
+        desc_roof = {"error": repr(e)}
+
     latency = None
     if rank == 0 and not args.no_latency:
         latency = latency_probe(nm, torch, dev, (frame_sets[0] + frame_sets[-1])[:2] + (frame_sets[0] + frame_sets[-1])[-2:])
@@ -770,6 +810,7 @@ def main():
             "ranks_seen_by_communicator": ranks_seen, "backend": (args.backend if world > 1 else None),
             "roofline": roof,
             "roofline_pyramid": roofline_pyramid(B, p_ms, pyr_all_ms, traffic, pyr_nodog_ms, pyr_dogonly_ms),
+            "roofline_describe": desc_roof,
         }
         if world > 1 and args.backend == "nccl":
             out["rccl_ranks_seen"] = ranks_seen

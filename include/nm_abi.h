@@ -53,7 +53,8 @@ NM_API int nm_fill_u32(void *dst, size_t count, unsigned int pattern, void *stre
  *                        nm_sift_detect_describe[_batch] / nm_sift_octave_pyramid (all frames of a batch)       */
 #define NM_PROF_MATCH_TOP2 0
 #define NM_PROF_PYRAMID_O0 1
-#define NM_PROF_SITES 2
+#define NM_PROF_DESCRIBE 2      /* frame_desc_kernel inside nm_sift_detect_describe[_batch] (all frames of the call) */
+#define NM_PROF_SITES 3
 NM_API int nm_profile_events(int site, void *start_event, void *stop_event);
 /* The same with a caller-owned list of npairs (start, stop) hipEvent_t pairs, events[2k], events[2k+1], consumed by the
  * k-th launch of the site (a batched call launches the MFMA kernel once per pair). npairs = 0 clears. */

@@ -153,6 +153,7 @@ def _dev(t, dtype=None):
 
 PROF_MATCH_TOP2 = 0
 PROF_PYRAMID_O0 = 1
+PROF_DESCRIBE = 2
 
 
 def profile_events(site, start=None, stop=None):

@@ -456,7 +456,9 @@ int nm_launch_frame_describe(const NmDescribeArgs &a, hipStream_t stream)
     const int ob = a.o_begin >= 2 ? 64 : NM_ORIENT_BLOCKS, db = a.o_begin >= 2 ? 512 : NM_DESC_BLOCKS;
     hipLaunchKernelGGL(frame_orient_kernel, dim3(ob, a.n), dim3(256), 0, stream, a);
     NM_LAUNCH_CHECK();
+    nm_prof_begin(NM_PROF_DESCRIBE, stream);
     hipLaunchKernelGGL(frame_desc_kernel, dim3(db, a.n), dim3(64), 0, stream, a);
+    nm_prof_end(NM_PROF_DESCRIBE, stream);
     NM_LAUNCH_CHECK();
     return 0;
 }
