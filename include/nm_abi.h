@@ -48,7 +48,9 @@ NM_API int nm_fill_u32(void *dst, size_t count, unsigned int pattern, void *stre
 /* Profiling hook (no reference counterpart; the reference's CudaTimer brackets whole calls, utils/cudatimer.cu:3-22).
  * While a (start, stop) hipEvent_t pair is registered for `site`, the launcher records start immediately before and
  * stop immediately after that kernel (sequence) on the stream it launches on. Pass NULLs to clear. Per host thread.
- *   NM_PROF_MATCH_TOP2 : the MFMA top-2 kernel inside nm_sift_match_f32 / nm_sift_match_shard_f32
+ *   NM_PROF_MATCH_TOP2 : the MFMA screening kernel inside nm_sift_match_f32 / _shard_f32 / _batch[_dev]_f32: one launch per
+ *                        pair under the fp32 and bf16x3 screens; under the two-stage screen ONE launch (its coarse pass)
+ *                        for all pairs of the call
  *   NM_PROF_PYRAMID_O0 : the octave-0 pyramid sequence (5 fused Gaussian + DoG + gradient launches) inside
  *                        nm_sift_detect_describe[_batch] / nm_sift_octave_pyramid (all frames of a batch)       */
 #define NM_PROF_MATCH_TOP2 0
@@ -57,7 +59,9 @@ NM_API int nm_fill_u32(void *dst, size_t count, unsigned int pattern, void *stre
 #define NM_PROF_SITES 3
 NM_API int nm_profile_events(int site, void *start_event, void *stop_event);
 /* The same with a caller-owned list of npairs (start, stop) hipEvent_t pairs, events[2k], events[2k+1], consumed by the
- * k-th launch of the site (a batched call launches the MFMA kernel once per pair). npairs = 0 clears. */
+ * k-th launch of the site (a batched call launches the MFMA kernel once per pair; under the two-stage screen, whose coarse
+ * pass is one launch per call, the call's FIRST pair brackets that launch and the pairs of its other pairs are recorded
+ * back to back, so that a list of one pair per matched pair stays valid and sums to the launch). npairs = 0 clears. */
 NM_API int nm_profile_event_pairs(int site, void *const *events, int npairs);
 
 /* Self-test (no reference counterpart): the gradient's fast correctly-rounded square root is compared with the IEEE
