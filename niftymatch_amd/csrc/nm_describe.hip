@@ -264,6 +264,7 @@ __device__ __forceinline__ void desc_run(const DescSetup &d, float *__restrict__
             // of a sample never collide and the read-add-write below can be issued as 8 loads, 8 adds, 8 stores
             float wt[8];
             int loc[8];
+            // pad word 16 of histogram row 0 (the same word for every lane; rows 1..7 have one each at + t * DESC_PITCH)
             const int dummy = 16 - 80 * DESC_PITCH - tx;
             // histogram word = (binx * 8 + biny * 32 + bint) * DESC_PITCH with 24-bit multiplies (v_mad_i32_i24 is full
             // rate; the 32-bit v_mul_lo_u32 the plain expression compiles to costs four VALU slots, eight times per sample)
@@ -272,19 +273,24 @@ __device__ __forceinline__ void desc_run(const DescSetup &d, float *__restrict__
             const int tw[2] = {__mul24(t0, DESC_PITCH), __mul24(t1, DESC_PITCH)};
             const bool okx[2] = {(unsigned)(binx + 2) < 4u, (unsigned)(binx + 3) < 4u};
             const bool oky[2] = {(unsigned)(biny + 2) < 4u, (unsigned)(biny + 3) < 4u};
+            // The in-grid test depends on (dbx, dby) only: it is applied to the partial product (wm * ax) * ay and to the
+            // (binx, biny) part of the address -- four selects each instead of eight. A rejected vote is +0 either way
+            // (0 * |..| = +0: the factors are finite and non-negative) and lands in the pad word of row t0 / t1.
 #pragma unroll
             for (int dbx = 0; dbx < 2; ++dbx)
 #pragma unroll
-                for (int dby = 0; dby < 2; ++dby)
+                for (int dby = 0; dby < 2; ++dby) {
+                    const bool ok = inwin && okx[dbx] && oky[dby];
+                    const float w2 = wm * __builtin_fabsf((1.f - dbx) - rbinx) * __builtin_fabsf((1.f - dby) - rbiny);
+                    const float w2s = ok ? w2 : 0.f;
+                    const int b4 = ok ? base + (dbx * 8 + dby * 32) * DESC_PITCH : dummy;
 #pragma unroll
                     for (int dbt = 0; dbt < 2; ++dbt) {
                         const int j = dbx * 4 + dby * 2 + dbt;
-                        const bool ok = inwin && okx[dbx] && oky[dby];
-                        const float w3 = wm * __builtin_fabsf((1.f - dbx) - rbinx) * __builtin_fabsf((1.f - dby) - rbiny) *
-                                         __builtin_fabsf((1.f - dbt) - rbint);
-                        wt[j] = ok ? w3 : 0.f;
-                        loc[j] = ok ? base + (dbx * 8 + dby * 32) * DESC_PITCH + tw[dbt] : dummy;
+                        wt[j] = w2s * __builtin_fabsf((1.f - dbt) - rbint);
+                        loc[j] = b4 + tw[dbt];
                     }
+                }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {          // rows of this pass in increasing cy: 16 lanes per group, LDS in order
                 if (tyg == k) {

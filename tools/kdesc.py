@@ -1,0 +1,21 @@
+"""frame_desc_kernel of a 16-frame 1080p detect call alone (library profile hook NM_PROF_DESCRIBE): median / min us."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+import niftymatch_amd as nm
+dev = torch.device("cuda:0")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+frames = bench.make_frames(nm, torch, dev, list(range(B)))
+arenas = [nm.SiftArena(bench.W, bench.H, bench.CAP, device=dev) for _ in range(B)]
+ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(12)]
+for a, b in ev:
+    a.record(); b.record()
+for a, b in ev:
+    nm.profile_events(nm.PROF_DESCRIBE, a, b)
+    nm.detect_describe_batch(arenas, frames)
+    nm.profile_events(nm.PROF_DESCRIBE, None, None)
+torch.cuda.synchronize()
+ts = sorted(a.elapsed_time(b) * 1e3 for a, b in ev[2:])
+kp = sum(int(a.num_items.item()) for a in arenas)
+print("frame_desc_kernel, %d frames, %d keypoints: median %.1f us, min %.1f us = %.2f us per frame" % (B, kp, ts[len(ts) // 2], ts[0], ts[len(ts) // 2] / B))
