@@ -263,12 +263,13 @@ __device__ __forceinline__ void desc_run(const DescSetup &d, float *__restrict__
             // votes outside the 4x4 grid (or outside the window) become +0 into the row's pad word, so the 8 addresses
             // of a sample never collide and the read-add-write below can be issued as 8 loads, 8 adds, 8 stores
             float wt[8];
-            int loc[8];
+            float *loc[8];
             // pad word 16 of histogram row 0 (the same word for every lane; rows 1..7 have one each at + t * DESC_PITCH)
-            const int dummy = 16 - 80 * DESC_PITCH - tx;
+            float *const dummy = part + 16;
             // histogram word = (binx * 8 + biny * 32 + bint) * DESC_PITCH with 24-bit multiplies (v_mad_i32_i24 is full
-            // rate; the 32-bit v_mul_lo_u32 the plain expression compiles to costs four VALU slots, eight times per sample)
-            const int base = __mul24(binx, 8 * DESC_PITCH) + __mul24(biny, 32 * DESC_PITCH);
+            // rate; the 32-bit v_mul_lo_u32 the plain expression compiles to costs four VALU slots, eight times per sample).
+            // The addresses are formed as pointers: (binx, biny) part once, + the two bint rows -- one add per vote.
+            float *const base = mine + (__mul24(binx, 8 * DESC_PITCH) + __mul24(biny, 32 * DESC_PITCH));
             const int t0 = bint & 7, t1 = (bint + 1) & 7;           // bint in [0, 8]
             const int tw[2] = {__mul24(t0, DESC_PITCH), __mul24(t1, DESC_PITCH)};
             const bool okx[2] = {(unsigned)(binx + 2) < 4u, (unsigned)(binx + 3) < 4u};
@@ -283,7 +284,7 @@ __device__ __forceinline__ void desc_run(const DescSetup &d, float *__restrict__
                     const bool ok = inwin && okx[dbx] && oky[dby];
                     const float w2 = wm * __builtin_fabsf((1.f - dbx) - rbinx) * __builtin_fabsf((1.f - dby) - rbiny);
                     const float w2s = ok ? w2 : 0.f;
-                    const int b4 = ok ? base + (dbx * 8 + dby * 32) * DESC_PITCH : dummy;
+                    float *const b4 = ok ? base + (dbx * 8 + dby * 32) * DESC_PITCH : dummy;
 #pragma unroll
                     for (int dbt = 0; dbt < 2; ++dbt) {
                         const int j = dbx * 4 + dby * 2 + dbt;
@@ -296,9 +297,9 @@ __device__ __forceinline__ void desc_run(const DescSetup &d, float *__restrict__
                 if (tyg == k) {
                     float o[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = mine[loc[j]];
+                    for (int j = 0; j < 8; ++j) o[j] = *loc[j];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) mine[loc[j]] = o[j] + wt[j];
+                    for (int j = 0; j < 8; ++j) *loc[j] = o[j] + wt[j];
                 }
                 // The four groups are mutually exclusive per THREAD, so the compiler may merge or reorder them; their
                 // order only matters across lanes (same word, different rows). A compiler-level memory fence between

@@ -31,9 +31,16 @@ __device__ __forceinline__ float div_to_f32(double a, double b, double r)
 {
     const double y = a * r;
     const unsigned long long u = (unsigned long long)__double_as_longlong(y);
-    const uint32_t lo = (uint32_t)u & 0x1FFFFFFFu;
-    const uint32_t ex = (uint32_t)(u >> 52) & 0x7FFu;
-    if (__builtin_expect(((lo - 0x0FFFFFF0u) <= 0x20u) || (ex < 1023u - 120u && y != 0.0), 0)) return (float)(a / b);
+    const uint32_t ulo = (uint32_t)u, uhi = (uint32_t)(u >> 32);
+    // Two instructions per test (v_lshl_add_u32 + an unsigned compare): the shifts drop the bits that do not take part.
+    //   near: the low 29 mantissa bits lie in [0x0FFFFFF0, 0x10000010] (8 x the difference, modulo 2^32, is <= 0x100 iff
+    //         the difference is in [0, 0x20]);
+    //   tiny: 0 < |y| < 2^-120 (biased exponent below 903), read off the sign-less high word. A double denormal whose
+    //         high mantissa bits are zero is not caught: its float -- and that of the exact quotient -- is a zero of the
+    //         same sign either way.
+    const bool near = ((ulo << 3) - (0x0FFFFFF0u << 3)) <= (0x20u << 3);
+    const bool tiny = ((uhi << 1) - 2u) < (((1023u - 120u) << 21) - 2u);
+    if (__builtin_expect(near | tiny, 0)) return (float)(a / b);
     return (float)y;
 }
 constexpr float TWO_PI_F = (float)(2 * 3.14159265358979323846);
