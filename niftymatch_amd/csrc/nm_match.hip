@@ -468,7 +468,8 @@ __device__ __forceinline__ void top3_merge(Top3 &t, int k, int tag)
     t.k1 = lt1 ? k : t.k1;
     t.t1 = lt1 ? tag : t.t1;
 }
-__device__ __forceinline__ float key_value(int k) { return __int_as_float(k & ~((1 << KEY_SLOT_BITS) - 1)); }
+template <int BITS = KEY_SLOT_BITS>
+__device__ __forceinline__ float key_value(int k) { return __int_as_float(k & ~((1 << BITS) - 1)); }
 
 // used by the lane-half merge at the end of the kernel (values + full indices)
 struct Top2 { float m1, m2, m3; int i1, i2; };
@@ -503,13 +504,14 @@ __device__ __forceinline__ void top2_insert(Top2 &t, float d, int j)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // fold the 2 x 16 accumulator values of one 64-candidate group into the running triple (see Top3 above)
+template <int BITS = KEY_SLOT_BITS>
 __device__ __forceinline__ void select_half(const f32x16 &acc0, const f32x16 &acc1, Top3 &best, int tag)
 {
     int g1 = KEY_INF, g2 = KEY_INF, g3 = KEY_INF;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) key_insert3(g1, g2, g3, (__float_as_int(acc0[e]) & ~((1 << KEY_SLOT_BITS) - 1)) | e);
+    for (int e = 0; e < 16; ++e) key_insert3(g1, g2, g3, (__float_as_int(acc0[e]) & ~((1 << BITS) - 1)) | e);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) key_insert3(g1, g2, g3, (__float_as_int(acc1[e]) & ~((1 << KEY_SLOT_BITS) - 1)) | (16 + e));
+    for (int e = 0; e < 16; ++e) key_insert3(g1, g2, g3, (__float_as_int(acc1[e]) & ~((1 << BITS) - 1)) | (16 + e));
     if (__any(g1 < best.k3)) {
         top3_merge(best, g1, tag);
         top3_merge(best, g2, tag);
@@ -658,6 +660,10 @@ __device__ __forceinline__ void mfma_half_bf16(f32x16 &acc0, f32x16 &acc1, const
 // tb = this lane's candidate row of group 0 in the tile image (256-byte rows, 16-byte chunks XOR-swizzled by row & 15);
 // foff[t] = byte offset of the lane's chunk of k-step t; group 1 = + 32 rows. qf[s] = the query's k-step s (k = 16 s + 8 h ..+7).
 #define NM_MFMA_H "v_mfma_f32_32x32x16_f16 "
+// The coarse pass folds once per TILE ITERATION: the keys of the two groups selected in it (2 n - 1, selected beside the first
+// group of tile n, and 2 n) share one pair of running keys, told apart by a sixth slot bit; 2^-17 instead of 2^-18 of a
+// value is dropped, which the finalize constants cover.
+constexpr int COARSE_SLOT_BITS = 6;
 // Selection in the coarse pass keeps the TWO smallest keys of a 64-candidate group (v_and_or, v_med3, v_min: three
 // instructions per value instead of four -- the selection is this kernel's largest single cost) and hands the second
 // one to the running triple a second time as the group's third: every value of the group it did not keep is >= it, which
@@ -669,7 +675,7 @@ __device__ __forceinline__ void f16_kstep(f32x16 &acc0, f32x16 &acc1, const u32x
 {
     if (SELECT) {
         int k;
-        const int mask = ~((1 << KEY_SLOT_BITS) - 1);
+        const int mask = ~((1 << COARSE_SLOT_BITS) - 1);
         asm volatile(NM_MFMA_H "%0, %5, %7, %0\n\t"
                      "v_and_or_b32 %4, %8, %12, %13\n\t"
                      "v_med3_i32 %3, %2, %3, %4\n\t"
@@ -720,29 +726,33 @@ __device__ __forceinline__ void f16_slots(f32x16 &acc0, f32x16 &acc1, const char
 }
 // k-steps KS0 .. KS0 + 3 of (acc0, acc1); SELECT: the 16 values of pv (one accumulator of the PREVIOUS group; slots
 // 4 KS0 .. 4 KS0 + 15 of that group) are folded into the key triple meanwhile
-template <bool SELECT, int KS0>
+template <bool SELECT, int KS0, int EB = 0>        // EB: slot base of the selected group (0: group 2 n - 1, 32: group 2 n)
 __device__ __forceinline__ void f16_half(f32x16 &acc0, f32x16 &acc1, const f32x16 &pv, const u32x4 (&fr)[8],
                                          const u32x4 (&qf)[16], int &g1, int &g2)
 {
-    f16_kstep<SELECT, 4 * KS0>(acc0, acc1, fr[0], fr[1], qf[KS0], pv[0], pv[1], pv[2], pv[3], g1, g2);
-    f16_kstep<SELECT, 4 * KS0 + 4>(acc0, acc1, fr[2], fr[3], qf[KS0 + 1], pv[4], pv[5], pv[6], pv[7], g1, g2);
-    f16_kstep<SELECT, 4 * KS0 + 8>(acc0, acc1, fr[4], fr[5], qf[KS0 + 2], pv[8], pv[9], pv[10], pv[11], g1, g2);
-    f16_kstep<SELECT, 4 * KS0 + 12>(acc0, acc1, fr[6], fr[7], qf[KS0 + 3], pv[12], pv[13], pv[14], pv[15], g1, g2);
+    f16_kstep<SELECT, EB + 4 * KS0>(acc0, acc1, fr[0], fr[1], qf[KS0], pv[0], pv[1], pv[2], pv[3], g1, g2);
+    f16_kstep<SELECT, EB + 4 * KS0 + 4>(acc0, acc1, fr[2], fr[3], qf[KS0 + 1], pv[4], pv[5], pv[6], pv[7], g1, g2);
+    f16_kstep<SELECT, EB + 4 * KS0 + 8>(acc0, acc1, fr[4], fr[5], qf[KS0 + 2], pv[8], pv[9], pv[10], pv[11], g1, g2);
+    f16_kstep<SELECT, EB + 4 * KS0 + 12>(acc0, acc1, fr[6], fr[7], qf[KS0 + 3], pv[12], pv[13], pv[14], pv[15], g1, g2);
 }
 #undef NM_MFMA_H
 
 // End of a segment: decode (value, candidate index) of the two best, merge the two lane halves (same query, disjoint
 // candidates), publish into this segment's slot of the query block. c0 = first candidate of the segment.
+// BITS 5: tag = 64-candidate group of the segment. BITS 6 (coarse pass): tag = tile iteration n, the sixth slot bit tells
+// group 2 n - 1 (0) from group 2 n (1).
+template <int BITS = KEY_SLOT_BITS>
 __device__ __forceinline__ void segment_publish(const Top3 &best, const MatchPlan &plan, const PlanGroup &grp, int pc, int qbl,
                                                 int vg, bool ends_piece, int c0, int h, int qi, int nA, int S,
                                                 float4 *__restrict__ partial, float *__restrict__ partial3)
 {
     auto index_of = [&](int k, int tag) {
-        const int slot = k & ((1 << KEY_SLOT_BITS) - 1), g = slot >> 4, e = slot & 15;
-        return c0 + tag * 64 + 32 * g + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int slot = k & 31, g = slot >> 4, e = slot & 15;
+        const int group = (BITS == 6) ? 2 * tag - 1 + ((k >> 5) & 1) : tag;
+        return c0 + group * 64 + 32 * g + (e & 3) + 8 * (e >> 2) + 4 * h;
     };
     Top2 m;
-    m.m1 = key_value(best.k1); m.m2 = key_value(best.k2); m.m3 = key_value(best.k3);
+    m.m1 = key_value<BITS>(best.k1); m.m2 = key_value<BITS>(best.k2); m.m3 = key_value<BITS>(best.k3);
     m.i1 = (best.k1 != KEY_INF) ? index_of(best.k1, best.t1) : -1;
     m.i2 = (best.k2 != KEY_INF) ? index_of(best.k2, best.t2) : -1;
     if (best.k1 == KEY_INF) m.m1 = __builtin_inff();
@@ -1114,7 +1124,7 @@ __global__ __launch_bounds__(512, 1) void match_coarse_kernel(MatchBatch bt)
             const int b = (g + n) & 1;
             const char *tb = ldsb + b * IMG + r * ROWB;
             const char *sp = ldsb + SLOT0 + b * SLOTB + r * 16;
-            int g1 = KEY_INF, g2 = KEY_INF;
+            int g1 = KEY_INF, g2 = KEY_INF;               // of groups 2 n - 1 (slots 0..31) and 2 n (slots 32..63) together
             f16_fetch<4>(frB, tb, foff);
             f16_slots(a0, a1, sp, qslot);
             if (n == 0) {
@@ -1125,12 +1135,10 @@ __global__ __launch_bounds__(512, 1) void match_coarse_kernel(MatchBatch bt)
                 f16_half<true, 0>(a0, a1, b0, frA, qw, g1, g2);
                 f16_fetch<0>(frA, tb + 64 * ROWB, foff);
                 f16_half<true, 4>(a0, a1, b1, frB, qw, g1, g2);
-                fold(g1, g2, g2, 2 * n - 1);
             }
-            g1 = g2 = KEY_INF;
             f16_fetch<4>(frB, tb + 64 * ROWB, foff);
             f16_slots(b0, b1, sp + 64 * 16, qslot);
-            f16_half<true, 0>(b0, b1, a0, frA, qw, g1, g2);
+            f16_half<true, 0, 32>(b0, b1, a0, frA, qw, g1, g2);
             // stream tiles g + n + 1 (landed by now; its slots are still in registers) and g + n + 2 (to be requested)
             const bool in1 = n + 1 < ntiles, in2 = n + 2 < ntiles;
             const bool ex1 = in1 || have_next;
@@ -1152,12 +1160,12 @@ __global__ __launch_bounds__(512, 1) void match_coarse_kernel(MatchBatch bt)
                 }
                 if (in1 || next_ahead) f16_fetch<0>(frA, ldsb + (b ^ 1) * IMG + r * ROWB, foff);
             }
-            f16_half<true, 4>(b0, b1, a1, frB, qw, g1, g2);
-            fold(g1, g2, g2, 2 * n);
+            f16_half<true, 4, 32>(b0, b1, a1, frB, qw, g1, g2);
+            fold(g1, g2, g2, n);
         }
         asm volatile("s_nop 15\n\ts_nop 3" : "+v"(b0), "+v"(b1));
-        select_half(b0, b1, best, 2 * ntiles - 1);
-        segment_publish(best, plan, grp, cur.pc, cur.qbl, vg, cur.tt + ntiles == cur.Lc, t0 * TILE_C, h, cur.qb * QB + wave * 32 + r,
+        select_half<COARSE_SLOT_BITS>(b0, b1, best, ntiles);       // group 2 ntiles - 1: slots 0..31 of "iteration" ntiles
+        segment_publish<COARSE_SLOT_BITS>(best, plan, grp, cur.pc, cur.qbl, vg, cur.tt + ntiles == cur.Lc, t0 * TILE_C, h, cur.qb * QB + wave * 32 + r,
                         nA, S, partial, partial3);
         if (!have_next) break;
         g += ntiles;
@@ -1310,7 +1318,8 @@ __device__ __forceinline__ void finalize_block(const MatchBatch &bt, const Match
     const bool in_domain = (STAGE == 1) ? (nai < F16_NORM_LIMIT && nbm < F16_NORM_LIMIT) : (nai < NORM_LIMIT && nbm < NORM_LIMIT);
     if (mode == 0 && in_domain && ci[1] >= 0) {
         const float sna = __builtin_sqrtf(nai), snb = __builtin_sqrtf(nbm);
-        const float coeff = (STAGE == 2 ? bt.err_coeff2 : bt.err_coeff) + 1.2e-5f;
+        // (+ 2^-18 key truncation + gamma_130; the coarse pass's keys drop a sixth bit: 2^-17)
+        const float coeff = (STAGE == 2 ? bt.err_coeff2 : bt.err_coeff) + (STAGE == 1 ? 1.6e-5f : 1.2e-5f);
         const float rai = (STAGE == 1) ? c.ra[i] : 0.f, rbm = (STAGE == 1) ? c.nbmax[1] : 0.f;
         auto E_of = [&](float bn, float rbj) {            // bn: upper bound of |b_j|, rbj: of its fp16 residual norm
             float e = coeff * ((sna + bn) * (sna + bn)) * 1.0001f + 1e-30f;
