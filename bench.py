@@ -247,9 +247,10 @@ def roofline_pyramid(B, o0_ms, all_ms, traffic, nodog_ms=None, dogonly_ms=None):
     return out
 
 
-# VALU wave-instructions frame_desc_kernel executes per keypoint (rocprofv3 --pmc SQ_INSTS_VALU over tools/kprofile.py,
-# profiles/r02_b_describe_detect_pmc_counters.txt: ~9.6 executed 64-sample passes x ~250); stored, like the HBM traffic
-DESC_VALU_PER_KEYPOINT = 2410.0
+# VALU wave-instructions frame_desc_kernel executes per keypoint (rocprofv3 --pmc SQ_INSTS_VALU over tools/kdesc.py,
+# profiles/r03_r_frame_desc_pmc_counters.txt: 455.15 M per 16-frame launch of 194 278 keypoints, ~9.6 executed 64-sample
+# passes x ~243; 2 410 before round 3's instruction-count work); stored, like the HBM traffic
+DESC_VALU_PER_KEYPOINT = 2343.0
 VALU_ISSUE_GHZ = 2.4 / 4.0           # a SIMD issues one VALU wave-instruction per 4 cycles (fp32, fp64 and packed alike)
 
 
