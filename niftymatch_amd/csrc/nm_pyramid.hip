@@ -226,6 +226,14 @@ __device__ __forceinline__ v2f pk_fma_s(v2f a, unsigned long long wq, v2f c)
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(c) : "v"(a), "s"(wq));
     return c;
 }
+// first tap of a sum that starts from +0: fma(a, w, +0) with the inline constant as the addend -- the accumulators need no
+// zeroing moves (24 per thread and tile)
+__device__ __forceinline__ v2f pk_fma_s0(v2f a, unsigned long long wq)
+{
+    v2f c;
+    asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(c) : "v"(a), "s"(wq));
+    return c;
+}
 
 // RN(sqrt(s)) for s = 0 or 2^-96 <= s < 2^96 without the denormal-safe expansion; other inputs take the IEEE path.
 __device__ __forceinline__ float sqrt_rn_fast_core(float s)
@@ -401,9 +409,9 @@ __device__ __forceinline__ void pk_row_task(const float *s_in, float *s_mid, con
     for (int j = 0; j < NC; ++j) win[j] = src[j];
     v2f o[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = (v2f){0.f, 0.f};
+    for (int i = 0; i < 8; ++i) o[i] = pk_fma_s0(win[D + i], w[2 * R]);
 #pragma unroll
-    for (int t = 0; t <= 2 * R; ++t) {
+    for (int t = 1; t <= 2 * R; ++t) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = pk_fma_s(win[D + i + t], w[2 * R - t], o[i]);
     }
@@ -447,9 +455,9 @@ __device__ __forceinline__ void pk_cols_epilogue(const float *s_in, const float 
 #pragma unroll
         for (int j = 0; j < NY + 2 * R; ++j) win[j] = *reinterpret_cast<const v2f *>(src + j * MID_P);
 #pragma unroll
-        for (int i = 0; i < NY; ++i) o[i] = (v2f){0.f, 0.f};
+        for (int i = 0; i < NY; ++i) o[i] = pk_fma_s0(win[i], w[2 * R]);
 #pragma unroll
-        for (int t = 0; t <= 2 * R; ++t) {
+        for (int t = 1; t <= 2 * R; ++t) {
 #pragma unroll
             for (int i = 0; i < NY; ++i) o[i] = pk_fma_s(win[i + t], w[2 * R - t], o[i]);
         }
