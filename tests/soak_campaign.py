@@ -52,6 +52,8 @@ for it in range(n_frames):
             bad += 1
             print("FRAME MISMATCH", it, w, h, cap, n, ref["n"], flush=True)
         a.close()
+    if it % 500 == 499:
+        print("  ... %d frame batches, %d mismatches so far, %.0fs" % (it + 1, bad, time.time() - t0), flush=True)
 print("frames done: %d cases, %d mismatches, %.1fs" % (n_frames, bad, time.time() - t0), flush=True)
 t0 = time.time()
 for it in range(n_match):
@@ -80,6 +82,8 @@ for it in range(n_match):
     if not ok:
         bad += 1
         print("MATCH MISMATCH", it, na, nb, kind, amb, flush=True)
+    if it % 500 == 499:
+        print("  ... %d matcher cases, %d mismatches so far, %.0fs" % (it + 1, bad, time.time() - t0), flush=True)
 print("matches done: %d cases, total mismatches %d, %.1fs" % (n_match, bad, time.time() - t0), flush=True)
 
 # ---- batched matcher: random groups of pairs through nm_sift_match_batch_f32 ----
