@@ -10,6 +10,9 @@
  * private external repo, CONTRIBUTING.md:7,17) and is CUDA-only, so it cannot be compiled or run here. This file
  * is pinned by hand-derived known-answer tests (tests/test_oracle_kat.py) and by the Q-table of SURVEY.md 8(a),
  * which fixes every place where the reference's behaviour is undefined (races, atomics order, stale memory).
+ * The ONE exception: nmo_sift_params (SiftParams, siftparams.h:30-51) is pinned by the reference itself -- that header
+ * compiles with g++, oracle/siftparams_dump.cpp dumps its fields for 12 geometries into tests/golden/siftparams_ref.json
+ * (make -C oracle ref golden) and tests/test_siftparams_pinned.py compares bit for bit.
  *
  * Floating-point contract (shared with the HIP kernels, see DESIGN.md "fp spec"):
  *   - compiled with -ffp-contract=off; every fused multiply-add is an explicit fmaf()/fma() below. The places
