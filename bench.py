@@ -67,11 +67,11 @@ def cpu_baseline(seed0=0, seed1=1):
         tm, m = timed(lambda: O.sift_matches(r0["desc"][:n], r1["desc"], 0.8, want_distance=False))
         return td, tm * (r0["n"] / float(n)), r0, r1, m
 
-    threads = O.set_threads(0)
+    threads = O.set_threads(0)                 # 0 = the default: one thread per processor OpenMP sees
     reps_all = [one(None) for _ in range(3)]
-    O.set_threads(1)
+    assert O.set_threads(1) == 1
     reps_1 = [one(1024) for _ in range(3)]
-    O.set_threads(0)
+    assert O.set_threads(0) == threads, "the oracle's thread count was not restored after the 1-thread leg"
     med = lambda reps: statistics.median(td + tm for td, tm, *_ in reps)
     td, tm, r0, r1, m = sorted(reps_all, key=lambda r: r[0] + r[1])[1]
     out = {"value": round(1.0 / med(reps_all), 4), "unit": "frame-pairs/s", "cores": int(threads), "kind": "port",

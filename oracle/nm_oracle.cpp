@@ -47,7 +47,9 @@ static const float  NMO_2PI_F = (float)(2 * 3.14159265358979323846);
 NMO_API int nmo_set_threads(int n)
 {
 #ifdef _OPENMP
-    if (n > 0) omp_set_num_threads(n);
+    /* n > 0: that many threads; n <= 0: back to the default, one per processor OpenMP sees (omp_get_num_procs honours the
+       affinity mask / cgroup the process runs under), so a caller that lowered the count can restore it */
+    omp_set_num_threads(n > 0 ? n : omp_get_num_procs());
     return omp_get_max_threads();
 #else
     (void)n; return 1;

@@ -51,3 +51,15 @@ def test_exp_exp2_double_within_2_ulp(oracle):
     assert np.max(np.abs(r - np.exp2(d)) / np.exp2(d)) <= 2 * 2.2204e-16
     ints = np.arange(-8, 9).astype(np.float64)
     assert np.array_equal(oracle.vec("exp2", ints, dtype=np.float64), np.exp2(ints))
+
+
+def test_set_threads_zero_restores_the_default(oracle):
+    """bench.py's cpu_baseline lowers the oracle to one thread for its second leg and must get the default back
+    (nmo_set_threads(0) was a no-op once: the all-thread figure of every later call would have been a 1-thread one)."""
+    default = oracle.set_threads(0)
+    assert default >= 1
+    assert oracle.set_threads(1) == 1
+    assert oracle.set_threads(0) == default
+    if default >= 2:
+        assert oracle.set_threads(2) == 2
+        assert oracle.set_threads(-5) == default
