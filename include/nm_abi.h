@@ -233,7 +233,9 @@ NM_API int nm_sift_match_batch_dev_phases_f32(int phases, int n, const float *co
  * query block by query block inside a chunk, so that the workgroups of one XCD stream the same candidate tiles together.
  * nm_sift_match_plan_segments lists what workgroup `wg` does, in order: rows of 5 ints (query block, first tile, number of
  * tiles, partial-list slot, 1 if the segment completes its query block); returns the number of segments. For tests and
- * capacity planning. */
+ * capacity planning. Sets of 2^22 (4 194 304) rows or more are outside the matcher's domain (32-bit byte offsets and unit
+ * indices): nm_sift_match_plan returns an error status, nm_sift_match_plan_segments -1, and every matching entry point
+ * returns an error status before any plan is made. */
 NM_API int nm_sift_match_plan(int nA, int nB, int plan[10]);
 NM_API int nm_sift_match_plan_segments(int nA, int nB, int wg, int *segments, int max_segments);
 NM_API int nm_sift_match_f32(const float *A, int nA, const float *B, int nB, float *distance, int *result,
@@ -367,7 +369,14 @@ NM_API int nm_sift_detect_describe(nm_sift_arena *arena, const float *gray, floa
  * all frames of the call (the frame is a grid dimension): a single 1080p frame is only ~4 workgroups per CU at octave
  * 0 and its higher octaves are pure launch latency, a batch fills the chip and shares the ~60 launches. Results are
  * identical to n separate nm_sift_detect_describe calls. No reference counterpart (the reference processes one frame
- * per call sequence, sift/siftfunctions.cu:42-181).                                                               */
+ * per call sequence, sift/siftfunctions.cu:42-181).
+ * STREAM CAPTURE: the call uses events only (no synchronisation, no allocation) and can be captured into a HIP graph on
+ * `stream`. Internally it forks the first arena's side stream(s) off `stream` and joins EVERY forked stream back into
+ * `stream` directly before it returns (also on an error path). A client that captures around these calls must follow the
+ * same rule for its own streams: on ROCm 7.2 a forked stream that is joined into ANOTHER forked stream (s1 -> s2 -> s3,
+ * then s3 -> s2 -> s1) crashes the capturing process inside hipStreamEndCapture / instantiate; s1 -> s2, s1 -> s3 or
+ * s1 -> s2 -> s3 with s2 -> s1 and s3 -> s1 are safe (tools/capture_shapes.py reproduces both). The same holds for
+ * nm_sift_match_batch[_dev]_f32, which run on `stream` alone.                                                           */
 #define NM_SIFT_MAX_BATCH 16
 NM_API int nm_sift_detect_describe_batch(nm_sift_arena *const *arenas, int n, const float *const *gray,
                                          float *const *desc, float *const *x, float *const *y, float *const *kpts,

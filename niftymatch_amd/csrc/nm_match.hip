@@ -181,6 +181,10 @@ NM_HD int plan_max_slots_part(const MatchPlan &p, int lane, int nlanes)
 }
 
 NM_HD int hd_divup(int a, int b) { return (a + b - 1) / b; }
+// Largest descriptor-set size (exclusive) the matcher accepts: the SRDs address rows with 32-bit byte offsets, and the work
+// plan's unit indices are 32-bit (unit_t): qblocks x T = (2^22 / 256) x (2^22 / 128) = 2^29 units at the limit. Every entry
+// that makes a plan rejects larger sets first (hipErrorInvalidValue).
+constexpr int MATCH_MAX_ROWS = 1 << 22;
 
 // The plan for (nA, nB) on a device of n_cu compute units in n_xcd XCDs. REDUCE(S) turns a caller's partial maximum into
 // the maximum over all callers (identity on the host). Every caller computes the same plan.
@@ -1951,6 +1955,9 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
     for (int k = 0; k < n; ++k) {
         const MatchJob &j = jobs[k];
         if (j.nA <= 0 || j.nB <= 0) continue;                 // empty sets: a no-op for this pair, as in the reference
+        // 32-bit byte ranges of the SRDs, and the plan's 32-bit unit arithmetic (qblocks x T must stay far below 2^31):
+        // checked BEFORE any plan is made
+        if (j.nA >= MATCH_MAX_ROWS || j.nB >= MATCH_MAX_ROWS) return (int)hipErrorInvalidValue;
         const int q = bt.n++;
         const bool dev = j.d_nA != nullptr;
         if (q > 0 && dev != dev_sized) return (int)hipErrorInvalidValue;
@@ -1968,7 +1975,6 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
         // inside the 256-byte counter block. The two-stage screen's coarse kernel takes every pair's plan from there (one
         // launch for all pairs of the call), so nbmax_kernel makes it for the host-sized entries too
         c.d_plan = (dev || screen == 2) ? reinterpret_cast<MatchPlan *>(w.fb_count + 32) : nullptr;
-        if (j.nA >= (1 << 22) || j.nB >= (1 << 22)) return (int)hipErrorInvalidValue;   // 32-bit byte ranges of the SRDs
         max_rows = max(max_rows, j.nA + nm_divup(j.nB, TILE_C) * TILE_C);
         max_a = max(max_a, j.nA);
     }
@@ -2169,7 +2175,7 @@ int nm_sift_match_batch_dev_phases_f32(int phases, int n, const float *const *A,
 
 int nm_sift_match_plan(int nA, int nB, int plan[10])
 {
-    if (!plan || nA < 0 || nB < 0) return (int)hipErrorInvalidValue;
+    if (!plan || nA < 0 || nB < 0 || nA >= MATCH_MAX_ROWS || nB >= MATCH_MAX_ROWS) return (int)hipErrorInvalidValue;
     const MatchPlan p = make_plan(nA, nB);
     plan[0] = p.qblocks; plan[1] = p.T; plan[2] = p.G; plan[3] = p.S; plan[4] = p.X; plan[5] = p.Gx;
     plan[6] = p.Tc; plan[7] = p.C; plan[8] = p.q_base; plan[9] = p.q_rem;
@@ -2180,7 +2186,7 @@ int nm_sift_match_plan(int nA, int nB, int plan[10])
 // ends_block); returns their number (at most max_segments are written).
 int nm_sift_match_plan_segments(int nA, int nB, int wg, int *segments, int max_segments)
 {
-    if (nA < 0 || nB < 0 || wg < 0) return -1;
+    if (nA < 0 || nB < 0 || wg < 0 || nA >= MATCH_MAX_ROWS || nB >= MATCH_MAX_ROWS) return -1;
     const MatchPlan p = make_plan(nA, nB);
     if (wg >= p.G) return 0;
     const int xg = wg % p.X, vg = wg / p.X;

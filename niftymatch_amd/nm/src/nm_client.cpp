@@ -149,7 +149,7 @@ extern "C" double nm_client_pair_loop_ex(const float *gray0, const float *gray1,
             nm_check((int)hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "stream");
             nm_check((int)hipStreamCreateWithFlags(&st1, hipStreamNonBlocking), "stream");
             worker = std::thread([&]() {
-                if (hipSetDevice(device) != hipSuccess) failed = true;
+                if (hipSetDevice(device) != hipSuccess) { std::lock_guard<std::mutex> lk(mu); failed = true; }
                 int seen = 0;
                 for (;;) {
                     {
@@ -158,11 +158,12 @@ extern "C" double nm_client_pair_loop_ex(const float *gray0, const float *gray1,
                         if (quit) return;
                         seen = posted;
                     }
+                    bool bad = false;
                     try {
                         client_frame(params, *py1, gray1, b, st1);
-                        if (hipStreamSynchronize(st1) != hipSuccess) failed = true;
-                    } catch (...) { failed = true; }
-                    { std::lock_guard<std::mutex> lk(mu); done = seen; }
+                        if (hipStreamSynchronize(st1) != hipSuccess) bad = true;
+                    } catch (...) { bad = true; }
+                    { std::lock_guard<std::mutex> lk(mu); done = seen; failed = failed || bad; }
                     cv.notify_all();
                 }
             });
@@ -180,6 +181,21 @@ extern "C" double nm_client_pair_loop_ex(const float *gray0, const float *gray1,
             }
             compute_sift_matches(&a, &b, with_distance ? dist.data() : nullptr, 0.8f, st);
         };
+        // Runs on EVERY way out of this scope, an exception thrown by pair() included: a joinable std::thread that is
+        // destroyed calls std::terminate, and the streams would leak.
+        struct Cleanup {
+            std::thread &worker; std::mutex &mu; std::condition_variable &cv; bool &quit; hipStream_t &st, &st1;
+            ~Cleanup()
+            {
+                if (worker.joinable()) {
+                    { std::lock_guard<std::mutex> lk(mu); quit = true; }
+                    cv.notify_all();
+                    worker.join();
+                }
+                if (st) { (void)hipStreamDestroy(st); st = nullptr; }
+                if (st1) { (void)hipStreamDestroy(st1); st1 = nullptr; }
+            }
+        } cleanup{worker, mu, cv, quit, st, st1};
         double us = -1.0;
         pair();                                                       // warm-up (workspace growth, code loading)
         if (hipDeviceSynchronize() == hipSuccess) {
@@ -188,14 +204,7 @@ extern "C" double nm_client_pair_loop_ex(const float *gray0, const float *gray1,
             if (hipDeviceSynchronize() == hipSuccess)
                 us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
         }
-        if (worker.joinable()) {
-            { std::lock_guard<std::mutex> lk(mu); quit = true; }
-            cv.notify_all();
-            worker.join();
-        }
-        if (st) (void)hipStreamDestroy(st);
-        if (st1) (void)hipStreamDestroy(st1);
-        if (failed) return -1.0;
+        { std::lock_guard<std::mutex> lk(mu); if (failed) return -1.0; }
         if (n_out && us >= 0) {
             n_out[0] = a._num_items; n_out[1] = b._num_items;
             std::vector<int> m = a._match_indexes.to_host();

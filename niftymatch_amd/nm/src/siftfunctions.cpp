@@ -1,6 +1,7 @@
 // siftfunctions.cpp -- host orchestration (reference: src/gpu/sift/siftfunctions.cu:15-181) on the C ABI / L2 launchers.
 #include "../siftfunctions.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 
@@ -20,12 +21,27 @@
 // which synchronises), so a client may read A->_match_indexes from the host or from another stream right after the
 // call. That is kept by default: the call ends with hipStreamSynchronize(stream). NM_ASYNC_MATCHES=1 in the environment
 // (or nm_set_async_matches(1)) makes it asynchronous on `stream` for clients that order their reads themselves.
-static int g_async_matches = -1;
-extern "C" __attribute__((visibility("default"))) void nm_set_async_matches(int on) { g_async_matches = on ? 1 : 0; }
+// Under stream capture a synchronise would invalidate the capture, so a capturing stream is never synchronised: the call
+// is then recorded asynchronously, and the graph's own ordering takes the place of the drain.
+// The flag is an atomic: clients drive compute_sift_matches from several host threads (nm_client_pair_loop_ex does).
+static std::atomic<int> g_async_matches{-1};
+extern "C" __attribute__((visibility("default"))) void nm_set_async_matches(int on) { g_async_matches.store(on ? 1 : 0); }
 static bool async_matches()
 {
-    if (g_async_matches < 0) { const char *e = getenv("NM_ASYNC_MATCHES"); g_async_matches = (e && e[0] == '1') ? 1 : 0; }
-    return g_async_matches == 1;
+    int v = g_async_matches.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("NM_ASYNC_MATCHES");
+        int expected = -1;
+        g_async_matches.compare_exchange_strong(expected, (e && e[0] == '1') ? 1 : 0);   // a concurrent nm_set_async_matches wins
+        v = g_async_matches.load(std::memory_order_relaxed);
+    }
+    return v == 1;
+}
+static bool stream_is_capturing(hipStream_t stream)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st != hipStreamCaptureStatusNone;
 }
 
 void compute_sift_matches(SiftData *A, SiftData *B, float *distance, float ambiguity, hipStream_t stream)
@@ -37,7 +53,10 @@ void compute_sift_matches(SiftData *A, SiftData *B, float *distance, float ambig
     if (A->_match_workspace.size() < need) {
         // sized for the container's capacity so that later calls with more keypoints do not grow it again
         const int cap_a = A->_capacity > A_size ? A->_capacity : A_size, cap_b = B->_capacity > B_size ? B->_capacity : B_size;
-        nm_check((int)hipStreamSynchronize(stream), "SIFT matching failed");      // an earlier match may still use the old one
+        // an earlier match may still use the old one. (Under capture nothing has run yet and growing is not possible
+        // without a synchronise: size A's workspace with one eager call before capturing, as INTEGRATION.md says.)
+        if (stream_is_capturing(stream)) RUNTIME_EXCEPTION("compute_sift_matches: the match workspace cannot grow under stream capture");
+        nm_check((int)hipStreamSynchronize(stream), "SIFT matching failed");
         A->_match_workspace = nm::device_vector<int>();
         // exact size (resize_uninitialized would add its 50 % growth headroom to what is already the capacity's bound)
         A->_match_workspace = nm::device_vector<int>(nm_sift_match_workspace_bytes(cap_a, cap_b) / sizeof(int) + 1);
@@ -45,7 +64,7 @@ void compute_sift_matches(SiftData *A, SiftData *B, float *distance, float ambig
     nm_check(nm_sift_match_f32(A->_desc.data(), A_size, B->_desc.data(), B_size, distance, A->_match_indexes.data(),
                                ambiguity, A->_match_workspace.data(), stream),
              "SIFT matching failed");
-    if (!async_matches()) nm_check((int)hipStreamSynchronize(stream), "SIFT matching failed");
+    if (!async_matches() && !stream_is_capturing(stream)) nm_check((int)hipStreamSynchronize(stream), "SIFT matching failed");
 }
 
 void compute_dog(PyramidData &pydata, const int octave_width, const int octave_height, hipStream_t stream)

@@ -100,6 +100,20 @@ def test_cmake_find_package_dropin(tmp_path, nm):
     assert out == ["6", "5", "4"]
 
 
+def test_match_plan_rejects_sets_beyond_the_32_bit_domain(nm):
+    """2^22 rows or more would overflow the plan's 32-bit unit arithmetic (qblocks x T wraps at 2^24 x 2^24 and the host's
+    group_owner then divides by zero): rejected with a status before any plan is made."""
+    import ctypes as C
+    lib = nm.lib()
+    out = (C.c_int * 10)()
+    buf = (C.c_int * 5)()
+    for nA, nB in [(1 << 22, 10), (10, 1 << 22), (1 << 24, 1 << 24), (2 ** 31 - 1, 2 ** 31 - 1)]:
+        assert lib.nm_sift_match_plan(nA, nB, out) != 0
+        assert lib.nm_sift_match_plan_segments(nA, nB, 0, buf, 1) == -1
+    assert lib.nm_sift_match_plan((1 << 22) - 1, (1 << 22) - 1, out) == 0 and out[0] == 1 << 14 and out[1] == 1 << 15
+    assert lib.nm_sift_match_plan_segments((1 << 22) - 1, (1 << 22) - 1, 255, buf, 1) >= 1
+
+
 def test_match_plan_invariants(nm):
     """Host logic of the matcher's work distribution (nm_sift_match_plan / _plan_segments, no GPU needed): every unit
     (query block, candidate tile) is processed by exactly one workgroup, workgroups of a group differ by at most one unit,
