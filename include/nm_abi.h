@@ -68,6 +68,28 @@ NM_API int nm_profile_event_pairs(int site, void *const *events, int npairs);
  * expansion for EVERY float of its domain [2^-96, 2^96) and 0; *d_mismatches (device) receives the number of differing
  * inputs. Must be 0. */
 NM_API int nm_selftest_sqrt(unsigned long long *d_mismatches, void *stream);
+/* Self-test of the matrix-pipe rounding premise under the matcher's proofs (no reference counterpart; what it protects is
+ * the exact scan of kernels/match.cu:83-117, which match_finalize_kernel must reproduce from MFMA-screened candidates).
+ * instruction: 0 = v_mfma_f32_32x32x16_bf16 (bf16x3 screen, every norm k-slot), 1 = v_mfma_f32_32x32x16_f16 (coarse pass of
+ * the default two-stage screen). Runs, on the current device: the operand / accumulator layout probe, the directed rounding
+ * cases, about n_random random single instructions, and about n_chains x 1024 accumulator chains issued exactly as the
+ * screens issue them (one bf16 norm k-slot instruction, then 8 f16 or 24 bf16 instructions) on adversarial row families
+ * incl. fp16-subnormal operands, each against binary64. d_out: NM_SELFTEST_MFMA_OUTPUTS floats on the device:
+ *   [0] layout mismatches (must be 0)
+ *   [1] C = 1 + 16 x 2^-25: (D - 1) in ulp (4 = dot product formed first)      [2] C = 1 + 2^-24 (1 + 2^-6): 1 = round to nearest
+ *   [3] 1 + 15 x 2^-25, C = 0: ulp above 1                                      [4] C = 2^24 + 16 x 1: D - 2^24 (16 = summed first)
+ *   [5] random instructions: max |D - exact| / (2^-24 (|C| + sum |a_k b_k|))
+ *   [6] the same against the model: max |D - exact| / (2^-24 |exact| + 7 x 2^-24 (pmax_lo + pmax_hi)); <= 1 = inside the
+ *       model whose DOUBLE the kernels' constants assume              [7] random instructions run
+ *   [8] chains: max |value - exact of the same operand images| / (sqrt na + sqrt nb)^2 -- to be held against
+ *       nm_sift_match_accum_budget(screen)                             [9] the same over the fp16-subnormal families only
+ *   [10] chain launches of 1024 chains each                            [11] same-half truncation probe, ulp above 1 */
+#define NM_SELFTEST_MFMA_OUTPUTS 16
+NM_API int nm_selftest_mfma_model(int instruction, int n_random, int n_chains, float *d_out, void *stream);
+/* What the finalize pass budgets for the accumulation error of a screen's MFMA chain, as a multiple of
+ * (sqrt na + sqrt nb)^2 (HOST function; screen: 0 = fp32, 1 = bf16x3, 2 = two-stage coarse pass): the share of
+ * screen_err_coeff that is a hardware premise rather than arithmetic. The self-test's [8] must stay below half of it. */
+NM_API float nm_sift_match_accum_budget(int screen);
 
 /* ---- host-side scale-space constants ---- */
 /* PyramidData::create_kernel_for_sigma (sift/pyramidata.cu:105-123). HOST function: writes 2*radius+1 normalised

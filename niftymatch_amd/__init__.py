@@ -73,6 +73,8 @@ _SIGNATURES = {
     "nm_downsample2_u8x4": (_I, [_P, _I, _I, _P, _I, _I, _P]),
     "nm_align_points": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "nm_selftest_sqrt": (_I, [_P, _P]),
+    "nm_selftest_mfma_model": (_I, [_I, _I, _I, _P, _P]),
+    "nm_sift_match_accum_budget": (_F, [_I]),
     "nm_undistort_map_f32": (_I, [_P, _P, _SZ, _SZ, _P, _P, _P, _P, _P]),
     "nm_resample_undistort_f32": (_I, [_P, _I, _I, _I, _P, _P, _SZ, _SZ, _P, _P]),
     "nm_resample_mask_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P]),
@@ -515,6 +517,28 @@ def selftest_sqrt():
     out = torch.zeros(1, dtype=torch.int64, device="cuda")
     _check(lib().nm_selftest_sqrt(_dev(out), _stream()), "nm_selftest_sqrt")
     return int(out.item())
+
+
+MFMA_BF16, MFMA_F16 = 0, 1
+
+
+def selftest_mfma_model(instruction, n_random=1 << 20, n_chains=4096):
+    """nm_selftest_mfma_model: the rounding model of the matrix instruction the matcher's screens issue, measured on this
+    device (layout probe, directed cases, random instructions, the screens' own accumulator chains on adversarial rows
+    incl. fp16 subnormals, all against binary64). Returns a dict of the NM_SELFTEST_MFMA_OUTPUTS figures."""
+    torch = _torch()
+    out = torch.zeros(16, dtype=torch.float32, device="cuda")
+    _check(lib().nm_selftest_mfma_model(int(instruction), int(n_random), int(n_chains), _dev(out), _stream()),
+           "nm_selftest_mfma_model")
+    v = [float(x) for x in out.cpu()]
+    return {"layout_mismatches": v[0], "c1_plus_16_small_ulp": v[1], "c1_plus_one_small_ulp": v[2],
+            "one_plus_15_small_ulp": v[3], "c2p24_plus_16": v[4], "rel_u": v[5], "model_ratio": v[6],
+            "instructions": v[7], "chain_coeff": v[8], "chain_coeff_subnormal": v[9], "chain_launches": v[10],
+            "same_half_truncation_ulp": v[11]}
+
+
+def match_accum_budget(screen):
+    return float(lib().nm_sift_match_accum_budget(int(screen)))
 
 
 TEX_U8N, TEX_U8X4N, TEX_F32 = 0, 1, 2

@@ -1889,6 +1889,14 @@ static int match_screen()
 // |screen value - exact squared distance| <= coeff (sqrt na + sqrt nb)^2  
 // (two-stage screen: the coarse pass's fp32 accumulation only -- 134 terms, with a factor 2 of slack -- see match_finalize_kernel<1>)
 static float screen_err_coeff(int screen) { return screen == 2 ? 3.2e-5f : screen ? 2.75e-5f : 1.56e-5f; }
+// The share of those coefficients that covers the accumulation inside the matrix instructions (a hardware premise, measured
+// by nm_selftest_mfma_model and asserted by tests/test_gpu_match.py): the whole of the coarse pass's coefficient (its
+// representation error is bounded separately from measured residual norms), 65 x 2^-24 of the bf16x3 coefficient (the rest is
+// the split's representation error, 2.31e-5, and the norms), and the fp32 screen's 2 gamma_129 fma-chain bound.
+extern "C" __attribute__((visibility("default"))) float nm_sift_match_accum_budget(int screen)
+{
+    return screen == 2 ? screen_err_coeff(2) : screen == 1 ? 65.0f * 5.9604645e-8f : screen_err_coeff(0);
+}
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 

@@ -142,3 +142,53 @@ def test_match_batch_dev_16_pairs_on_real_descriptors(nm, oracle, cuda, bench16)
                 assert np.array_equal(dev[k][:cnt[a]].cpu().numpy(), ref), "pair %d (%s) vs oracle" % (k, screen)
     finally:
         nm.set_match_screen(before)
+
+
+def test_detect_256_loop_of_the_bench(nm, oracle, cuda):
+    """BASELINE configs[3] exactly as bench.detect_256 runs it (sift/siftfunctions.cu:100-181 per frame): 256 distinct 1080p
+    frames in sixteen 16-frame calls over 4 streams, each stream re-using its 16 arenas four times per pass, several passes.
+    The first, a middle and the last frame against the oracle (every output, bit for bit); all 256 keypoint counts and
+    descriptor checksums against single-frame calls."""
+    import torch
+
+    import bench
+    streams = [torch.cuda.Stream(device=cuda) for _ in range(4)]
+    arenas = [nm.SiftArena(W, H_, CAP, device=cuda) for _ in range(64)]
+    frames = bench.make_frames(nm, torch, cuda, list(range(256)))
+    counts = torch.zeros(256, dtype=torch.int32, device=cuda)
+    sums = torch.zeros(256, dtype=torch.float64, device=cuda)
+    keep = {0: None, 137: None, 255: None}
+    rows = torch.arange(CAP, device=cuda)
+
+    def after_call(c, b, e, ar):                 # runs on the call's stream, right behind it
+        for k, a in enumerate(ar):
+            counts[b + k] = a.num_items[0]
+            live = (rows < a.num_items[0]).double()     # rows past the count hold earlier frames' descriptors
+            sums[b + k] = (a.desc.double().sum(dim=1) * live).sum()
+            if b + k in keep:
+                keep[b + k] = (a.kpts.clone(), a.orients.clone(), a.x.clone(), a.y.clone(), a.desc.clone())
+
+    out = bench.detect_256(nm, torch, None, cuda, cuda, 0, 1, arenas, streams, 16, passes=2, frames=frames, after_call=after_call)
+    torch.cuda.synchronize()
+    assert out["frames_per_s"] > 0 and out["frames_per_s_sustained"] > 0 and len(out["ms_per_pass"]) == 2
+    counts = counts.cpu().numpy()
+    assert out["keypoints_total"] == int(counts.sum()) and counts.min() > 10000
+    for f, (kpts, orients, x, y, desc) in keep.items():
+        ref = oracle.sift_detect_describe(H.blurred_frame(f, W, H_), CAP)
+        n = int(counts[f])
+        assert n == ref["n"]
+        _eq(kpts[:n], ref["kpts"], "keypoints frame %d" % f)
+        _eq(orients[:n], ref["orient"], "orientations frame %d" % f)
+        _eq(x[:n], ref["x"], "x frame %d" % f)
+        _eq(y[:n], ref["y"], "y frame %d" % f)
+        _eq(desc[:n], ref["desc"], "descriptors frame %d" % f)
+    single = nm.SiftArena(W, H_, CAP, device=cuda)
+    sums = sums.cpu().numpy()
+    for f in range(256):
+        single.detect_describe(frames[f])
+        n = int(single.num_items.item())
+        assert n == counts[f], "frame %d: %d keypoints in the 256-frame loop, %d alone" % (f, counts[f], n)
+        assert float(single.desc[:n].double().sum(dim=1).sum().item()) == sums[f], "frame %d: descriptor checksum" % f
+    single.close()
+    for a in arenas:
+        a.close()

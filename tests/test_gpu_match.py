@@ -561,3 +561,29 @@ def test_match_phases_equal_the_whole_call(nm, oracle, cuda):
         assert np.array_equal(whole[k][:na].cpu().numpy(), ref)
     with pytest.raises(nm.NmError):
         nm.sift_match_batch_dev(*args, parts, 0.8, workspace=ws2, phases=8)
+
+
+@pytest.mark.parametrize("instruction,screen", [(1, 2), (0, 1)], ids=["f16_coarse", "bf16x3"])
+def test_mfma_rounding_model_is_inside_what_the_screens_budget(nm, cuda, instruction, screen):
+    """The premise under the matcher's exactness (protects kernels/match.cu:83-117): the error of the
+    fp32 accumulation INSIDE v_mfma_f32_32x32x16_{bf16,f16} is a hardware model, not IEEE arithmetic. nm_selftest_mfma_model
+    measures it on THIS device -- layout, directed cases, 2^20 random instructions, and the screens' own chains (bf16 norm
+    k-slot instruction with C = 0, then 8 f16 or 24 bf16 instructions into the same accumulator) on adversarial rows incl.
+    fp16-subnormal operands alone and mixed with normal ones (a pipe that flushed them would read ~0.25 here) -- against
+    binary64. Asserted: at most HALF of what screen_err_coeff budgets for the accumulation (nm_sift_match_accum_budget)."""
+    r = nm.selftest_mfma_model(instruction, n_random=1 << 20, n_chains=8192)
+    budget = nm.match_accum_budget(screen)
+    u = 2.0 ** -24
+    assert r["layout_mismatches"] == 0
+    assert r["instructions"] >= (1 << 20) and r["chain_launches"] >= 8192
+    # the dot product is formed before C is added, and the final rounding is to nearest (model H)
+    assert r["c1_plus_16_small_ulp"] == 4 and r["c1_plus_one_small_ulp"] == 1 and r["c2p24_plus_16"] == 16
+    # one instruction, random operands: inside the model whose double the constants assume
+    assert 0 < r["model_ratio"] <= 1.0, r
+    # the chains as issued: measured coefficient <= half of the budgeted one, subnormal operands included
+    assert 0 < r["chain_coeff"] <= 0.5 * budget, (r, budget)
+    assert r["chain_coeff_subnormal"] <= 0.5 * budget, (r, budget)
+    # and the crude per-instruction reading: n + 1 instructions, each off by rel_u u (|C| + sum |p|) <= rel_u u 1.01 (sqrt na + sqrt nb)^2
+    n_instr = 9 if instruction == 1 else 25
+    if instruction == 1:
+        assert r["rel_u"] * u * (n_instr + 1) * 1.01 <= 0.5 * budget, (r, budget)
