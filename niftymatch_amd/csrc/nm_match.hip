@@ -1888,14 +1888,21 @@ static int match_screen()
 }
 // |screen value - exact squared distance| <= coeff (sqrt na + sqrt nb)^2  
 // (two-stage screen: the coarse pass's fp32 accumulation only -- 134 terms, with a factor 2 of slack -- see match_finalize_kernel<1>)
-static float screen_err_coeff(int screen) { return screen == 2 ? 3.2e-5f : screen ? 2.75e-5f : 1.56e-5f; }
+// Round 4: the bf16x3 coefficient rose from 2.75e-5 to 3.15e-5. Its accumulation share was 65 u (u = 2^-24): twice the
+// 25 u + 7 u of the model H-bf16 as probed by hand in round 2. nm_selftest_mfma_model (4.2e9 random results per instruction
+// on MI355X, profiles/r04_b_mfma_model.txt) measures single instructions up to 1.91 x (bf16) / 1.73 x (f16) that model --
+// the combination of the two halves and C loses up to one ulp, not half of one -- so 65 u was the bound itself, without
+// slack. The share is now 140 u = 8.3e-6: 2.2 x the 64 u that the measured law |D - exact| <= 2 (u |D| + 7 u (pmax_lo +
+// pmax_hi)) gives for a chain of 25 instructions (2 (25 u + 7 u)), and 3.2 x the largest chain error the self-test's
+// adversarial families reach (2.6e-6). The coarse pass's 3.2e-5 = 537 u stands: its 9 instructions need 2 (9 u + 7 u) = 32 u.
+static float screen_err_coeff(int screen) { return screen == 2 ? 3.2e-5f : screen ? 3.15e-5f : 1.56e-5f; }
 // The share of those coefficients that covers the accumulation inside the matrix instructions (a hardware premise, measured
 // by nm_selftest_mfma_model and asserted by tests/test_gpu_match.py): the whole of the coarse pass's coefficient (its
-// representation error is bounded separately from measured residual norms), 65 x 2^-24 of the bf16x3 coefficient (the rest is
-// the split's representation error, 2.31e-5, and the norms), and the fp32 screen's 2 gamma_129 fma-chain bound.
+// representation error is bounded separately from measured residual norms), 140 x 2^-24 of the bf16x3 coefficient (the rest
+// is the split's representation error, 2.31e-5, and the norms), and the fp32 screen's 2 gamma_129 fma-chain bound.
 extern "C" __attribute__((visibility("default"))) float nm_sift_match_accum_budget(int screen)
 {
-    return screen == 2 ? screen_err_coeff(2) : screen == 1 ? 65.0f * 5.9604645e-8f : screen_err_coeff(0);
+    return screen == 2 ? screen_err_coeff(2) : screen == 1 ? 140.0f * 5.9604645e-8f : screen_err_coeff(0);
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }

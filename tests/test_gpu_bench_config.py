@@ -156,15 +156,15 @@ def test_detect_256_loop_of_the_bench(nm, oracle, cuda):
     arenas = [nm.SiftArena(W, H_, CAP, device=cuda) for _ in range(64)]
     frames = bench.make_frames(nm, torch, cuda, list(range(256)))
     counts = torch.zeros(256, dtype=torch.int32, device=cuda)
-    sums = torch.zeros(256, dtype=torch.float64, device=cuda)
+    sums = torch.zeros(256, dtype=torch.int64, device=cuda)
     keep = {0: None, 137: None, 255: None}
     rows = torch.arange(CAP, device=cuda)
 
     def after_call(c, b, e, ar):                 # runs on the call's stream, right behind it
         for k, a in enumerate(ar):
             counts[b + k] = a.num_items[0]
-            live = (rows < a.num_items[0]).double()     # rows past the count hold earlier frames' descriptors
-            sums[b + k] = (a.desc.double().sum(dim=1) * live).sum()
+            live = (rows < a.num_items[0]).long()       # rows past the count hold earlier frames' descriptors
+            sums[b + k] = (a.desc.view(torch.int32).long().sum(dim=1) * live).sum()     # bit patterns: exact, order-free
             if b + k in keep:
                 keep[b + k] = (a.kpts.clone(), a.orients.clone(), a.x.clone(), a.y.clone(), a.desc.clone())
 
@@ -188,7 +188,7 @@ def test_detect_256_loop_of_the_bench(nm, oracle, cuda):
         single.detect_describe(frames[f])
         n = int(single.num_items.item())
         assert n == counts[f], "frame %d: %d keypoints in the 256-frame loop, %d alone" % (f, counts[f], n)
-        assert float(single.desc[:n].double().sum(dim=1).sum().item()) == sums[f], "frame %d: descriptor checksum" % f
+        assert int(single.desc[:n].view(torch.int32).long().sum().item()) == int(sums[f]), "frame %d: descriptor checksum" % f
     single.close()
     for a in arenas:
         a.close()
