@@ -381,6 +381,15 @@ NM_API int nm_sift_arena_get_params(const nm_sift_arena *arena, float *peak_thre
  * mask: caller-owned DEVICE plane of exactly the arena's width x height floats, read by every later call until it is
  * replaced; NULL removes it. Per arena: the frames of a batched call may have different masks or none.               */
 NM_API int nm_sift_arena_set_mask(nm_sift_arena *arena, const float *mask, int mask_width, int mask_height);
+/* Diagnostics of the octave-tail launch (csrc/nm_tail.hip; the octaves >= 2 of a call run as ONE persistent launch whose
+ * work items draw tickets): the plan's segments (5 ints each: kind 0 = levels 1..3 / whole plane, 1 = levels 4..5, 2 = detect,
+ * 3 = scan + gather, 4 = gradient planes of a whole octave; slot; items per frame; first item per frame; octave) and, when the
+ * arena was created under NM_TAIL_TRACE=1 and was the first arena of the last call, 4 words per item of that launch (meta,
+ * clock at ticket, at inputs ready, at done; 100 MHz). Returns the items per frame (0: this geometry takes the per-octave
+ * launches; < 0: error). Synchronises the device when `out` is given. */
+NM_API int nm_sift_arena_tail_trace(const nm_sift_arena *arena, unsigned long long *out, int max_items, int *segments,
+                                    int max_segments);
+NM_API int nm_sift_arena_tail_segments(const nm_sift_arena *arena);
 /* gray: width*height fp32 on the device. Outputs on the device: desc capacity x 128, x,y capacity (full-resolution
  * coordinates, descriptor.cu:75-77), d_num_items = number of descriptors written (<= capacity,
  * siftfunctions.cu:165-169). kpts (capacity float4) and orients (capacity float2) are optional (NULL).        */

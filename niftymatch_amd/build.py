@@ -24,7 +24,7 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=h
          "-Wall", "-Wno-unused-function"]
 
 KERNEL_SOURCES = ["nm_pyramid.hip", "nm_keypoint.hip", "nm_describe.hip", "nm_match.hip", "nm_image.hip", "nm_warp.hip", "nm_ransac.hip", "nm_selftest.hip"]
-SIFT_SOURCES = ["nm_frame.hip"]
+SIFT_SOURCES = ["nm_frame.hip", "nm_tail.hip"]
 KERNEL_CPP = ["kernels_api.cpp", "ransac.cpp"]
 SIFT_CPP = ["pyramidata.cpp", "siftdata.cpp", "siftfunctions.cpp", "nm_client.cpp"]
 UTIL_CPP = ["gpuutils.cpp"]

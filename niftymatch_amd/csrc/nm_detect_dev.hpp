@@ -141,16 +141,22 @@ struct DetectView {
 // One unit group (DET_ROWS rows of one 256-pixel segment) of one frame's octave: `blk` = seg + nseg * row group. 256 threads.
 // SC1: the survivors and the per-unit counts are consumed by ANOTHER workgroup of the SAME launch (the octave-tail kernel's
 // scan + gather item): they are stored write-through (agent-scope atomic stores = global_store ... sc1), see nm_tail.hip.
-template <bool DENSE, bool LEV, bool MASKED, bool SC1 = false>
-__device__ __forceinline__ void detect_stage_body(const DetectView &a, int blk, DetectSmem &sm)
+// NQ > 1 (the tail kernel's 1024-thread workgroups): NQ unit groups run side by side, 256 threads each (quarter q =
+// threadIdx.x / 256 works on sm_all[q]); the workgroup barriers inside are shared, so the refinement loop runs for the
+// LONGEST candidate list of the NQ groups. !active: the quarter has no unit group (the last item of a segment): it computes on
+// a clamped one and stores nothing.
+template <bool DENSE, bool LEV, bool MASKED, bool SC1 = false, int NQ = 1>
+__device__ __forceinline__ void detect_stage_body(const DetectView &a, int blk, DetectSmem *sm_all, bool active = true)
 {
+    const int tid = (NQ > 1) ? (int)(threadIdx.x & 255) : (int)threadIdx.x;
+    DetectSmem &sm = sm_all[(NQ > 1) ? (threadIdx.x >> 8) : 0];
     auto &s_x = sm.s_x; auto &s_cnt = sm.s_cnt; auto &s_acc = sm.s_acc; auto &s_last = sm.s_last; auto &s_wtot = sm.s_wtot;
     auto &s_pref = sm.s_pref;
     const float *const *dog = a.planes;                    // LEV: the six Gaussian levels, else the five DoG planes
     const int seg = blk % a.nseg, yg = blk / a.nseg;
     const int y0 = yg * DET_ROWS;
-    const int x = seg * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = seg * 256 + tid;
+    const int lane = tid & 63, wave = tid >> 6;
     const int ow = a.ow, oh = a.oh;
     const bool xin = x < ow;
     const int xc = xin ? x : ow - 1;                       // clamped column for safe addressing
@@ -255,8 +261,13 @@ __device__ __forceinline__ void detect_stage_body(const DetectView &a, int blk, 
     }
     __syncthreads();
     const int total = s_cnt[DET_ROWS * 12];
-    for (int b0 = 0; b0 < total; b0 += 256) {           // 256 candidates per pass (a 4 x 256 pixel unit usually holds < 100)
-        const int c = b0 + (int)threadIdx.x;
+    int total_all = total;                                  // barriers inside the loop: every quarter runs the longest list
+    if (NQ > 1) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) total_all = max(total_all, sm_all[q].s_cnt[DET_ROWS * 12]);
+    }
+    for (int b0 = 0; b0 < total_all; b0 += 256) {           // 256 candidates per pass (a 4 x 256 pixel unit usually holds < 100)
+        const int c = b0 + tid;
         bool acc = false;
         float4 kp = make_float4(-1.f, -1.f, -1.f, -1.f);
         int g = 0, px = 0, py = 0, lvl = 0;
@@ -290,8 +301,8 @@ __device__ __forceinline__ void detect_stage_body(const DetectView &a, int blk, 
 #pragma unroll
         for (int w = 0; w < 4; ++w)
             if (w < wave) before += s_wtot[w];
-        s_pref[threadIdx.x] = before;                     // accepted candidates of this pass before candidate c
-        if (threadIdx.x == 255) s_pref[256] = before + (acc ? 1 : 0);
+        s_pref[tid] = before;                     // accepted candidates of this pass before candidate c
+        if (tid == 255) s_pref[256] = before + (acc ? 1 : 0);
         __syncthreads();
         if (c < total) {
             const int gs = s_cnt[g * 4], ge = s_cnt[g * 4 + 4];       // the group's flattened range (s_cnt[48] = total)
@@ -300,23 +311,25 @@ __device__ __forceinline__ void detect_stage_body(const DetectView &a, int blk, 
             if (acc) {
                 const int unit = py * a.nseg + seg;
                 float4 *st = reinterpret_cast<float4 *>(a.staging) + (size_t)lvl * a.stage_stride + (size_t)unit * 256;
-                if (SC1) nmdev::store_f4_agent(st + pos, kp); else st[pos] = kp;
+                if (!active) {}
+                else if (SC1) nmdev::store_f4_agent(st + pos, kp);
+                else st[pos] = kp;
             }
             if (c == min(ge, b0 + 256) - 1) s_last[g] = pos + (acc ? 1 : 0);     // accepted so far, this pass included
         }
         __syncthreads();
-        if (threadIdx.x < DET_ROWS * 3) {
-            const int gs = s_cnt[threadIdx.x * 4], ge = s_cnt[threadIdx.x * 4 + 4];
-            if (ge > b0 && gs < b0 + 256 && ge > gs) s_acc[threadIdx.x] = s_last[threadIdx.x];
+        if (tid < DET_ROWS * 3) {
+            const int gs = s_cnt[tid * 4], ge = s_cnt[tid * 4 + 4];
+            if (ge > b0 && gs < b0 + 256 && ge > gs) s_acc[tid] = s_last[tid];
         }
         __syncthreads();
     }
-    if (!DENSE && threadIdx.x < DET_ROWS * 3) {           // per-unit counts of the three levels
-        const int jr = threadIdx.x / 3, lv = threadIdx.x - 3 * jr;
+    if (!DENSE && tid < DET_ROWS * 3) {           // per-unit counts of the three levels
+        const int jr = tid / 3, lv = tid - 3 * jr;
         const int y = y0 + jr;
-        if (y < oh) {
+        if (y < oh && active) {
             int *dst = a.counts + lv * a.n_blocks + y * a.nseg + seg;
-            if (SC1) nmdev::store_i32_agent(dst, s_acc[threadIdx.x]); else *dst = s_acc[threadIdx.x];
+            if (SC1) nmdev::store_i32_agent(dst, s_acc[tid]); else *dst = s_acc[tid];
         }
     }
 }

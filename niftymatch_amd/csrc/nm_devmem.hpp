@@ -34,10 +34,14 @@ __device__ __forceinline__ void store_f2_agent(float2 *p, float a, float b)     
     const unsigned long long v = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
     __hip_atomic_store(g64(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void store_f4_agent(float4 *p, float4 v)              // two 8-byte write-through stores
+// 16-byte write-through store (p 16-byte aligned): ONE global_store_dwordx4 sc1. Narrow sc1 stores are one fabric write per
+// lane (a dword costs ~6x the time per byte of a dwordx4), so bulk payload goes out 16 bytes per lane. The compiler does not
+// count an asm store in vmcnt; publish_add's explicit s_waitcnt vmcnt(0) does (the hardware counter sees it).
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_f4_agent(float4 *p, float4 v)
 {
-    store_f2_agent(reinterpret_cast<float2 *>(p), v.x, v.y);
-    store_f2_agent(reinterpret_cast<float2 *>(p) + 1, v.z, v.w);
+    const v4f_t d = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"((unsigned long long)p), "v"(d) : "memory");
 }
 __device__ __forceinline__ int load_i32_agent(const int *p)
 {

@@ -1,6 +1,7 @@
 // nm_frame.hip -- library-level entry points: device helpers, host-side tap generation, and the per-frame driver
 // that runs the reference's implied client loop (orchestration order of sift/siftfunctions.cu:42-181)
 // as one allocation-free, sync-free launch sequence on a stream.
+#include <algorithm>
 #include <cmath>
 #include <new>
 #include <vector>
@@ -10,6 +11,7 @@
 #include "nm_common.hpp"
 #include "nm_describe.hpp"
 #include "nm_keypoint.hpp"
+#include "nm_tail.hpp"
 
 namespace {
 
@@ -47,6 +49,14 @@ struct nm_sift_arena {
     NmFrameBook *book;
     float *kpts, *orients;     // internal lists used when the caller passes NULL
     const float *mask;         // nm_sift_arena_set_mask: caller-owned full-resolution plane (width x height) or NULL
+    // octave tail (nm_tail.hip): the octaves >= tail.T of a call run as ONE persistent launch. Their detection stages into
+    // per-octave lists (an octave's gather may run after the next octave's detection), the launch finds a frame's planes in a
+    // device-resident table, and the FIRST arena of a call lends its state words (zero between launches).
+    float *stg[20]; size_t stg_stride[20]; int *cnt[20];
+    NmTailFrame *tail_frame;
+    int *tail_state;
+    NmTailArgs tail;           // the plan for this geometry (per-call fields are filled by the driver)
+    bool tail_ok;
 
     template <typename T>
     int alloc(T **p, size_t n)
@@ -61,6 +71,16 @@ struct nm_sift_arena {
         return 0;
     }
 };
+
+// write_dog = false (frame driver): the DoG planes are not materialised -- detection forms them from the levels -- which
+// takes 20 of the chain's 64 written bytes per pixel away (level 5 has to be stored instead: + 4). per_octave: the
+// levels live in the octave's own planes (lev[o]); otherwise in level[] (single-octave API call).
+// NM_FRAME_DOG=1: the frame driver materialises the DoG planes as in round 1 (detection then reads them).
+static bool frame_driver_writes_dog()
+{
+    static const bool v = [] { const char *e = getenv("NM_FRAME_DOG"); return e && e[0] == '1'; }();
+    return v;
+}
 
 extern "C" {
 
@@ -168,6 +188,44 @@ int nm_sift_arena_create(int width, int height, int capacity, nm_sift_arena **ou
     if (!rc) rc = a->alloc(&a->kpts, (size_t)4 * capacity);
     if (!rc) rc = a->alloc(&a->orients, (size_t)2 * capacity);
     if (!rc) rc = (int)hipMemset(a->book, 0, sizeof(NmFrameBook));
+    // octave tail: first octave T = 2 (NM_FRAME_TAIL=0 switches it off, 1..3 choose T): octaves 0 and 1 are real streaming
+    // work for the whole chip and keep their per-octave launches
+    a->tail_ok = false; a->tail_frame = nullptr; a->tail_state = nullptr;
+    for (int o = 0; o < 20; ++o) { a->stg[o] = nullptr; a->stg_stride[o] = 0; a->cnt[o] = nullptr; }
+    {
+        const char *e = getenv("NM_FRAME_TAIL");
+        const int T = e ? atoi(e) : 2;
+        int radii[5] = {0, 0, 0, 0, 0};
+        for (size_t i = 0; i < P._sigmas.size() && i < 5; ++i) radii[i] = a->radii[i];
+        if (!rc && T >= 1 && T <= 3 && P._sigmas.size() == 5 && P._num_dog_levels == 3 && !frame_driver_writes_dog() &&
+            nm_tail_plan(a->tail, width, height, P._num_octaves, T, radii)) {
+            NmTailFrame h{};
+            for (int o = 0; o < P._num_octaves; ++o) {
+                for (int i = 0; i < 6; ++i) h.lev[o][i] = a->lev[o][i];
+                h.grad[o] = a->grad[o];
+            }
+            for (int o = T; !rc && o < P._num_octaves; ++o) {
+                const size_t units = (size_t)(height >> o) * nm_divup(width >> o, 256);
+                a->stg_stride[o] = units * 256;
+                rc = a->alloc(&a->stg[o], 3 * a->stg_stride[o] * 4);
+                if (!rc) rc = a->alloc(&a->cnt[o], 3 * units);
+                h.staging[o] = a->stg[o]; h.stage_stride[o] = a->stg_stride[o]; h.counts[o] = a->cnt[o];
+            }
+            h.book = a->book;
+            if (!rc) rc = a->alloc(&a->tail_frame, 1);
+            if (!rc) rc = (int)hipMemcpy(a->tail_frame, &h, sizeof(h), hipMemcpyHostToDevice);
+            if (!rc) rc = a->alloc(&a->tail_state, NM_TAIL_STATE_INTS);
+            if (!rc) rc = (int)hipMemset(a->tail_state, 0, NM_TAIL_STATE_INTS * sizeof(int));
+            for (int i = 0; i < 5; ++i) a->tail.taps[i] = a->taps[i];
+            a->tail.trace = nullptr;
+            const char *tr = getenv("NM_TAIL_TRACE");          // diagnostic: per-item timestamps of the tail launch
+            if (!rc && tr && tr[0] == '1') {
+                rc = a->alloc(&a->tail.trace, (size_t)16 * NM_MAX_BATCH * a->tail.items_per_frame);
+                if (!rc) rc = (int)hipMemset(a->tail.trace, 0, (size_t)128 * NM_MAX_BATCH * a->tail.items_per_frame);
+            }
+            a->tail_ok = !rc;
+        }
+    }
     if (!rc) rc = (int)hipDeviceSynchronize();
     if (rc) { nm_sift_arena_destroy(a); return rc; }
     *out = a;
@@ -189,6 +247,29 @@ void nm_sift_arena_destroy(nm_sift_arena *a)
 }
 
 size_t nm_sift_arena_bytes(const nm_sift_arena *a) { return a ? a->bytes : 0; }
+
+// Diagnostic: the per-item record of the arena's last octave-tail launch (NM_TAIL_TRACE=1 when the arena was created; the
+// arena must have been the FIRST of its call). Synchronises the device. out: 4 words per item -- kind | slot << 8 | frame
+// << 16 | index << 24 | workgroup << 48, then the 100 MHz clock when the ticket was drawn, when its inputs were ready, when it
+// was done. Returns the number of items per frame (0: no trace), *n_segments / segments (5 ints each: kind, slot, items per
+// frame, first item, octave) describe the plan.
+int nm_sift_arena_tail_trace(const nm_sift_arena *a, unsigned long long *out, int max_items, int *segments, int max_segments)
+{
+    if (!a || !a->tail_ok) return 0;
+    for (int i = 0; segments && i < a->tail.n_seg && i < max_segments; ++i) {
+        const NmTailSeg &g = a->tail.seg[i];
+        int *r = segments + 5 * i;
+        r[0] = g.kind; r[1] = g.slot; r[2] = g.per_frame; r[3] = g.first_per_frame; r[4] = a->tail.oct[g.slot].o;
+    }
+    if (out && a->tail.trace && max_items > 0) {
+        // layout of the launch's record: 4 words per item for all n_frames * items_per_frame items, then 12 phase stamps per item
+        // (conv items only); max_items must be that product, out holds 16 words per item
+        if (hipDeviceSynchronize() != hipSuccess) return -1;
+        if (hipMemcpy(out, a->tail.trace, (size_t)max_items * 128, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    }
+    return a->tail.items_per_frame;
+}
+int nm_sift_arena_tail_segments(const nm_sift_arena *a) { return (a && a->tail_ok) ? a->tail.n_seg : 0; }
 
 // The reference's run-time knobs on the frame driver: SiftParams::_peak_threshold / _edge_threshold are public fields read
 // per compute_keypoints call (sift/siftparams.h:97-98, siftfunctions.cu:123-125); compute_keypoints_with_mask
@@ -218,16 +299,6 @@ int nm_sift_arena_set_mask(nm_sift_arena *a, const float *mask, int mask_width, 
 float *nm_sift_arena_level(nm_sift_arena *a, int l) { return (a && l >= 0 && l < 6) ? a->level[l] : nullptr; }
 float *nm_sift_arena_dog(nm_sift_arena *a, int d) { return (a && d >= 0 && d < 5) ? a->dog[0][d] : nullptr; }
 float *nm_sift_arena_grad(nm_sift_arena *a) { return a ? a->grad[0] : nullptr; }
-
-// write_dog = false (frame driver): the DoG planes are not materialised -- detection forms them from the levels -- which
-// takes 20 of the chain's 64 written bytes per pixel away (level 5 has to be stored instead: + 4). per_octave: the
-// levels live in the octave's own planes (lev[o]); otherwise in level[] (single-octave API call).
-// NM_FRAME_DOG=1: the frame driver materialises the DoG planes as in round 1 (detection then reads them).
-static bool frame_driver_writes_dog()
-{
-    static const bool v = [] { const char *e = getenv("NM_FRAME_DOG"); return e && e[0] == '1'; }();
-    return v;
-}
 
 static int octave_pyramid(nm_sift_arena *const *as, int n, int o, int ow, int oh, bool store_top, bool decimate,
                           hipStream_t st, bool write_dog = true, bool per_octave = false, bool write_grad = true)
@@ -321,14 +392,53 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
     // by the HOST's ~55 launches on the slower boxes, got 40 us slower (545 vs 507 us): two more launches and four more
     // event operations. Not the default.
     static const int split_cfg = [] { const char *e = getenv("NM_FRAME_SPLIT_DESCRIBE"); return e ? atoi(e) : 0; }();
-    const int split = (split_cfg > 0 && split_cfg < P._num_octaves) ? split_cfg : 0;
+    int split = (split_cfg > 0 && split_cfg < P._num_octaves) ? split_cfg : 0;
+    // Octave tail (nm_tail.hip): every arena of the call planned it for this geometry (same width / height => same plan).
+    // It is the LATENCY path: a call of one or two frames is a chain of dependent launches that no other frame's work fills
+    // (a 1080p frame: 22 launches instead of 55); in calls of many frames every per-octave launch is shared by all of them
+    // and runs at a better efficiency than the tail's LDS-fused tiles (halo recomputed per tile), so those keep them
+    // (16 frames per call, MI355X: 160 vs 171 us per frame). NM_FRAME_TAIL_MAX_BATCH moves the threshold.
+    static const int tail_max_batch = [] { const char *e = getenv("NM_FRAME_TAIL_MAX_BATCH"); return e ? atoi(e) : 2; }();
+    bool use_tail = !dogs && !split && n <= tail_max_batch;
+    for (int f = 0; f < n; ++f) use_tail = use_tail && as[f]->tail_ok;
+    const int first_tail = use_tail ? as[0]->tail.T : P._num_octaves;
+    // With the tail, the octaves < T (98 % of a frame's keypoints) are described on the description stream as soon as octave
+    // T - 1 has been detected, BESIDE the tail launch; the few keypoints of the tail octaves follow behind its scans.
+    if (use_tail) split = first_tail;
+    NmTailArgs tail_args{};
+    if (use_tail) {
+        tail_args = as[0]->tail;
+        tail_args.n = n;
+        for (int f = 0; f < n; ++f) {
+            tail_args.fr[f] = as[f]->tail_frame; tail_args.kpts[f] = kp[f];
+            tail_args.d_num_items[f] = d_num_items ? d_num_items[f] : nullptr;
+            tail_args.masks[f] = as[f]->mask; tail_args.any_mask |= as[f]->mask ? 1 : 0;
+        }
+        tail_args.mask_w = W; tail_args.mask_h = H;
+        tail_args.peak = P._peak_threshold; tail_args.edge = P._edge_threshold; tail_args.sigma0 = P._sigma_0;
+        tail_args.num_dogs = P._num_dog_levels; tail_args.capacity = as[0]->capacity;
+        tail_args.state = as[0]->tail_state;
+    }
     auto body = [&]() -> int {
         for (int o = 0; o < P._num_octaves; ++o) {
             const int ow = W >> o, oh = H >> o;
             const float xper = (float)std::pow(2.0, o);
+            if (o >= first_tail) {                 // the tail launch below covers this octave; the describe pass needs its geometry
+                for (int f = 0; f < n; ++f) da.grad[f][o] = as[f]->grad[o];
+                da.geom[o].ow = ow; da.geom[o].oh = oh; da.geom[o].xper = xper;
+                continue;
+            }
             int e = octave_pyramid(as, n, o, ow, oh, !dogs, o + 1 < P._num_octaves, st, dogs, true);
             if (e) return e;
             NM_RETURN_IF(hipEventRecord(as[0]->ev_pyr[o], st));
+            if (use_tail && o + 1 == first_tail) {
+                // The tail launch (levels, gradients, detection of the octaves >= T) goes to the CALLER's stream, straight behind
+                // the pyramid of octave T - 1 whose decimated level 3 seeds it -- issued BEFORE this octave's detection launches
+                // so that the host does not hold it back -- and runs beside the detection of the octaves < T on the side stream.
+                e = nm_launch_tail(tail_args, st);
+                if (e) return e;
+                NM_RETURN_IF(hipEventRecord(as[0]->ev_pyr[first_tail], st));
+            }
             NM_RETURN_IF(hipStreamWaitEvent(side, as[0]->ev_pyr[o], 0));
             forked = true;
 
@@ -369,6 +479,13 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
                 e = nm_launch_frame_describe(da, dstr);
                 if (e) return e;
             }
+        }
+        if (use_tail) {
+            // the tail's book-keeping scans + gathers continue octave T - 1's book: on the side stream, behind its detection and
+            // behind the tail launch
+            NM_RETURN_IF(hipStreamWaitEvent(side, as[0]->ev_pyr[first_tail], 0));
+            const int e = nm_launch_tail_scan(tail_args, side);
+            if (e) return e;
         }
         da.o_begin = split; da.o_end = P._num_octaves;
         return nm_launch_frame_describe(da, side);

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
     v.mask = MASKED ? (DENSE ? a.mask : a.masks[frame]) : nullptr; v.mask_w = a.mask_w; v.mask_h = a.mask_h;
     v.ow = a.ow; v.oh = a.oh; v.peak = a.peak; v.edge = a.edge; v.xper = a.xper; v.sigma0 = a.sigma0;
     v.num_dogs = a.num_dogs; v.n_blocks = a.n_blocks; v.nseg = a.nseg;
-    detect_stage_body<DENSE, LEV, MASKED>(v, blockIdx.x, sm);
+    detect_stage_body<DENSE, LEV, MASKED>(v, blockIdx.x, &sm);
 }
 
 __global__ __launch_bounds__(1024) void scan_book_kernel(NmScanArgs a)
