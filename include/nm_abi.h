@@ -390,6 +390,13 @@ NM_API int nm_sift_arena_set_mask(nm_sift_arena *arena, const float *mask, int m
 NM_API int nm_sift_arena_tail_trace(const nm_sift_arena *arena, unsigned long long *out, int max_items, int *segments,
                                     int max_segments);
 NM_API int nm_sift_arena_tail_segments(const nm_sift_arena *arena);
+/* HOST function (no device access): the octave-tail plan for a width x height frame whose tail starts at octave T (the frame
+ * driver uses T = 2; NM_FRAME_TAIL=1..3 in the environment when an arena is created). segments: 8 ints each (kind, slot, items
+ * per frame, first item per frame, octave, 1 if the whole plane is one item, octave width, octave height), in the order in
+ * which the launch's tickets run through them -- an item only ever waits for items of EARLIER segments; info: items per
+ * frame, LDS bytes of the tail launch, of the scan launch, number of tail octaves. Returns the number of segments; 0 when the
+ * geometry is not covered (too few octaves, radii other than the SIFT defaults, LDS) and takes the per-octave launches. */
+NM_API int nm_sift_tail_plan(int width, int height, int T, int *segments, int max_segments, int info[4]);
 /* gray: width*height fp32 on the device. Outputs on the device: desc capacity x 128, x,y capacity (full-resolution
  * coordinates, descriptor.cu:75-77), d_num_items = number of descriptors written (<= capacity,
  * siftfunctions.cu:165-169). kpts (capacity float4) and orients (capacity float2) are optional (NULL).        */

@@ -271,6 +271,29 @@ int nm_sift_arena_tail_trace(const nm_sift_arena *a, unsigned long long *out, in
 }
 int nm_sift_arena_tail_segments(const nm_sift_arena *a) { return (a && a->tail_ok) ? a->tail.n_seg : 0; }
 
+// HOST function (no device access): the octave-tail plan of a width x height frame with first tail octave T -- what
+// nm_sift_arena_create makes for the arena. segments: 8 ints each (kind, slot, items per frame, first item, octave, whole
+// plane?, octave width, octave height); info: items per frame, LDS bytes of the tail launch, LDS bytes of the scan launch,
+// tail octaves. Returns the number of segments, 0 when the geometry takes the per-octave launches.
+int nm_sift_tail_plan(int width, int height, int T, int *segments, int max_segments, int info[4])
+{
+    if (width <= 0 || height <= 0) return 0;
+    const SiftParams P(width, height);
+    NmTailArgs a{};
+    int radii[5] = {0, 0, 0, 0, 0};
+    if (P._sigmas.size() != 5) return 0;
+    for (int i = 0; i < 5; ++i) radii[i] = nm_create_kernel_for_sigma(P._sigmas[i], nullptr);
+    if (!nm_tail_plan(a, width, height, P._num_octaves, T, radii)) return 0;
+    for (int i = 0; segments && i < a.n_seg && i < max_segments; ++i) {
+        const NmTailSeg &g = a.seg[i];
+        const NmTailOct &oc = a.oct[g.slot];
+        int *r = segments + 8 * i;
+        r[0] = g.kind; r[1] = g.slot; r[2] = g.per_frame; r[3] = g.first_per_frame; r[4] = oc.o; r[5] = oc.whole; r[6] = oc.ow; r[7] = oc.oh;
+    }
+    if (info) { info[0] = a.items_per_frame; info[1] = a.lds_bytes; info[2] = a.scan_lds_bytes; info[3] = a.n_oct; }
+    return a.n_seg;
+}
+
 // The reference's run-time knobs on the frame driver: SiftParams::_peak_threshold / _edge_threshold are public fields read
 // per compute_keypoints call (sift/siftparams.h:97-98, siftfunctions.cu:123-125); compute_keypoints_with_mask
 // (siftfunctions.cu:65-98) restricts detection to where the full-resolution mask's bilinear fetch is >= 1 (keypoint.cu:214).
@@ -437,7 +460,6 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
                 // so that the host does not hold it back -- and runs beside the detection of the octaves < T on the side stream.
                 e = nm_launch_tail(tail_args, st);
                 if (e) return e;
-                NM_RETURN_IF(hipEventRecord(as[0]->ev_pyr[first_tail], st));
             }
             NM_RETURN_IF(hipStreamWaitEvent(side, as[0]->ev_pyr[o], 0));
             forked = true;
@@ -480,14 +502,17 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
                 if (e) return e;
             }
         }
-        if (use_tail) {
-            // the tail's book-keeping scans + gathers continue octave T - 1's book: on the side stream, behind its detection and
-            // behind the tail launch
-            NM_RETURN_IF(hipStreamWaitEvent(side, as[0]->ev_pyr[first_tail], 0));
-            const int e = nm_launch_tail_scan(tail_args, side);
-            if (e) return e;
-        }
         da.o_begin = split; da.o_end = P._num_octaves;
+        if (use_tail) {
+            // The tail's book-keeping scans + gathers continue octave T - 1's book (ev_det: recorded on the side stream behind
+            // that octave's detection, long reached by now) and stay on the CALLER's stream, straight behind the tail launch
+            // -- an event hand-over to another stream costs ~10 us at the end of the chain -- as does the description of the
+            // tail octaves' few keypoints.
+            NM_RETURN_IF(hipStreamWaitEvent(st, as[0]->ev_det, 0));
+            const int e = nm_launch_tail_scan(tail_args, st);
+            if (e) return e;
+            return nm_launch_frame_describe(da, st);
+        }
         return nm_launch_frame_describe(da, side);
     };
     rc = body();

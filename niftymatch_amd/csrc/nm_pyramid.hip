@@ -7,10 +7,12 @@
 #include "nm_common.hpp"
 #include "nm_fpspec.hpp"
 #include "nm_grad_dev.hpp"
+#include "nm_pk_dev.hpp"
 #include "../../include/nm_abi.h"
 
 using nmfp::fma32;
 using namespace nmgrad;
+using namespace nmpk;
 
 int nm_cu_count()
 {
@@ -210,7 +212,6 @@ __global__ __launch_bounds__(TH * 8) void conv_sep_kernel(float *__restrict__ re
 //   * the gradient uses a correctly rounded sqrt built from v_rsq_f32 + two exact-residual corrections (validated
 //     against the IEEE expansion for every float of its domain by nm_selftest_sqrt), the single-subtraction form of
 //     mod_2pi, and 0.5f*x for (float)(0.5*(double)x) (exact scaling).
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -218,23 +219,6 @@ __device__ __forceinline__ v2f pk_fma(v2f a, float w, v2f c)
 {
     const v2f ww = {w, w};
     return __builtin_elementwise_fma(a, ww, c);
-}
-
-// The same with the tap in a SCALAR register: op_sel_hi:[1,0,1] makes both halves of the packed FMA read the low dword of
-// the scalar pair, so a uniform weight needs no VGPR pair and no v_mov to build one (the kernel spent 24 % of its VALU
-// instructions on register moves, most of them broadcasting the 2R+1 taps into pairs for both passes).
-__device__ __forceinline__ v2f pk_fma_s(v2f a, unsigned long long wq, v2f c)
-{
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(c) : "v"(a), "s"(wq));
-    return c;
-}
-// first tap of a sum that starts from +0: fma(a, w, +0) with the inline constant as the addend -- the accumulators need no
-// zeroing moves (24 per thread and tile)
-__device__ __forceinline__ v2f pk_fma_s0(v2f a, unsigned long long wq)
-{
-    v2f c;
-    asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(c) : "v"(a), "s"(wq));
-    return c;
 }
 
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }

@@ -293,6 +293,7 @@ __device__ void grad_item(const NmTailOct &oc, const NmTailFrame *fr, int idx)
 // thread chains the book through the octaves (empty-level rule of sift/siftfunctions.cu:145,160, capacity rule of
 // :165-169), and all output slots of all (octave, level) lists are gathered together (sift/pyramidata.cu:84-91: raster
 // order). li: ints of LDS: the offsets, then 16 words per (octave, level).
+template <int NTH>
 __device__ void scan_gather_all(const NmTailArgs &a, const NmTailFrame *fr, int f, int *li)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_lists = 3 * a.n_oct;
@@ -304,10 +305,10 @@ __device__ void scan_gather_all(const NmTailArgs &a, const NmTailFrame *fr, int 
     for (int j = 0; j < a.n_oct; ++j) {                   // all loads in flight together
         const int *counts = fr->counts[a.oct[j].o];
         const int n = 3 * a.oct[j].n_blocks;
-        for (int i = tid; i < n; i += NT) s_off[base_of[j] + i] = counts[i];
+        for (int i = tid; i < n; i += NTH) s_off[base_of[j] + i] = counts[i];
     }
     __syncthreads();
-    for (int q = wave; q < n_lists; q += NT / 64) {       // exclusive scan of list q = (slot j, level l) by this wave
+    for (int q = wave; q < n_lists; q += NTH / 64) {       // exclusive scan of list q = (slot j, level l) by this wave
         const int j = q / 3, l = q - 3 * j, nb = a.oct[j].n_blocks;
         int *v = s_off + base_of[j] + l * nb;
         int run = 0;
@@ -352,7 +353,7 @@ __device__ void scan_gather_all(const NmTailArgs &a, const NmTailFrame *fr, int 
     __syncthreads();
     float4 *out = reinterpret_cast<float4 *>(a.kpts[f]);
     const int first = s_tot[64], total = s_tot[96];
-    for (int p = tid; p < total; p += NT) {
+    for (int p = tid; p < total; p += NTH) {
         const int slot_out = first + p;
         int q = 0;                                        // the list that holds output slot `slot_out`
         while (q + 1 < n_lists && slot_out >= s_tot[64 + q + 1]) ++q;
@@ -386,6 +387,19 @@ __device__ __forceinline__ void detect_item(const NmTailArgs &a, const NmTailOct
     v.mask = MASKED ? a.masks[f] : nullptr; v.mask_w = a.mask_w; v.mask_h = a.mask_h;
     v.ow = oc.ow; v.oh = oc.oh; v.peak = a.peak; v.edge = a.edge; v.xper = oc.xper; v.sigma0 = a.sigma0;
     v.num_dogs = a.num_dogs; v.n_blocks = oc.n_blocks; v.nseg = oc.nseg;
+    {   // Touch the 7 rows x 6 levels of this quarter's unit group with all loads in flight: the levels were written through to
+        // memory by other CUs a moment ago, so the body's row-by-row fetches (one dependent round trip per row) would each
+        // pay the full memory latency; behind this pass they hit the XCD's L2.
+        const int seg = blk % oc.nseg, yg = blk / oc.nseg, x = min(seg * 256 + (int)(threadIdx.x & 255), oc.ow - 1);
+        float junk = 0.f;
+#pragma unroll
+        for (int r = -1; r <= nmdet::DET_ROWS; ++r) {
+            const int yy = min(max(yg * nmdet::DET_ROWS + r, 0), oc.oh - 1);
+#pragma unroll
+            for (int p = 0; p < 6; ++p) junk += v.planes[p][(size_t)yy * oc.ow + x];
+        }
+        asm volatile("" : : "v"(junk));
+    }
     nmdet::detect_stage_body<false, true, MASKED, false, NQ>(v, blk, sm, active);
 }
 
@@ -464,10 +478,11 @@ __global__ __launch_bounds__(NT) void tail_kernel(NmTailArgs a)
 // The book-keeping scan + ordered gather of the tail octaves, one workgroup per frame walking the octaves in order (the
 // book's running count chains them); a launch of its own on the detection stream, behind the detection of octave T - 1 and
 // behind the tail launch.
-__global__ __launch_bounds__(NT) void tail_scan_kernel(NmTailArgs a)
+constexpr int SCAN_NT = 256;             // a few hundred counts and keypoints per frame: four waves find a CU at once
+__global__ __launch_bounds__(SCAN_NT) void tail_scan_kernel(NmTailArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    scan_gather_all(a, a.fr[blockIdx.x], blockIdx.x, reinterpret_cast<int *>(lds));
+    scan_gather_all<SCAN_NT>(a, a.fr[blockIdx.x], blockIdx.x, reinterpret_cast<int *>(lds));
 }
 
 }  // namespace
@@ -568,7 +583,7 @@ int nm_launch_tail(const NmTailArgs &a, hipStream_t stream)
 int nm_launch_tail_scan(const NmTailArgs &a, hipStream_t stream)
 {
     if (a.n <= 0 || a.n_oct <= 0) return 0;
-    hipLaunchKernelGGL(tail_scan_kernel, dim3(a.n), dim3(NT), a.scan_lds_bytes, stream, a);
+    hipLaunchKernelGGL(tail_scan_kernel, dim3(a.n), dim3(SCAN_NT), a.scan_lds_bytes, stream, a);
     NM_LAUNCH_CHECK();
     return 0;
 }
