@@ -387,19 +387,8 @@ __device__ __forceinline__ void detect_item(const NmTailArgs &a, const NmTailOct
     v.mask = MASKED ? a.masks[f] : nullptr; v.mask_w = a.mask_w; v.mask_h = a.mask_h;
     v.ow = oc.ow; v.oh = oc.oh; v.peak = a.peak; v.edge = a.edge; v.xper = oc.xper; v.sigma0 = a.sigma0;
     v.num_dogs = a.num_dogs; v.n_blocks = oc.n_blocks; v.nseg = oc.nseg;
-    {   // Touch the 7 rows x 6 levels of this quarter's unit group with all loads in flight: the levels were written through to
-        // memory by other CUs a moment ago, so the body's row-by-row fetches (one dependent round trip per row) would each
-        // pay the full memory latency; behind this pass they hit the XCD's L2.
-        const int seg = blk % oc.nseg, yg = blk / oc.nseg, x = min(seg * 256 + (int)(threadIdx.x & 255), oc.ow - 1);
-        float junk = 0.f;
-#pragma unroll
-        for (int r = -1; r <= nmdet::DET_ROWS; ++r) {
-            const int yy = min(max(yg * nmdet::DET_ROWS + r, 0), oc.oh - 1);
-#pragma unroll
-            for (int p = 0; p < 6; ++p) junk += v.planes[p][(size_t)yy * oc.ow + x];
-        }
-        asm volatile("" : : "v"(junk));
-    }
+    // (Touching the group's 7 rows x 6 levels with all loads in flight first -- the body fetches row by row, one dependent
+    // round trip each, from planes other CUs wrote through to memory a moment ago -- was measured: 31 instead of 20 us per item.)
     nmdet::detect_stage_body<false, true, MASKED, false, NQ>(v, blk, sm, active);
 }
 
