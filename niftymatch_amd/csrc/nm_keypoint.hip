@@ -137,45 +137,82 @@ __global__ __launch_bounds__(256) void scatter_valid3_kernel(NmCompact3 c)
     if (f) c.out[l][c.offsets[l * c.nb + blockIdx.x] + r] = v;
 }
 
-// Exclusive scan of n ints by ONE workgroup of 1024 threads; returns the total to every thread.
-__device__ int block_exclusive_scan_1024(const int *__restrict__ in, int *__restrict__ out, int n, int *s /* [1024+1] */)
+// Exclusive scans of NL arrays of n ints each (in + l * stride -> out + l * stride) by ONE workgroup of 1024 threads; total[l]
+// receives array l's sum (every thread). A thread owns `per` consecutive elements of every array: all its loads are issued
+// before the first is used (the kernel is one workgroup's chain of memory round trips), the running sums go through lane
+// shuffles inside a wave and one LDS word per wave and array across waves: one barrier instead of twenty per array.
+// s: 16 * NL + 1 ints of LDS.
+template <int NL>
+__device__ __forceinline__ void block_exclusive_scan_1024(const int *__restrict__ in, int *__restrict__ out, int n, int stride,
+                                                          int *s, int (&total)[NL])
 {
-    const int t = threadIdx.x;
+    constexpr int MAXPER = 12;                             // elements per thread kept in registers (n <= 12 288)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int per = (n + 1023) / 1024;
-    const int beg = t * per, end = min(beg + per, n);
-    int sum = 0;
-    for (int i = beg; i < end; ++i) sum += in[i];
-    s[t] = sum;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {          // Hillis-Steele inclusive scan
-        int v = 0;
-        if (t >= d) v = s[t - d];
-        __syncthreads();
-        s[t] += v;
-        __syncthreads();
+    const int beg = min(t * per, n), end = min(beg + per, n);
+    int v[NL][MAXPER], sum[NL];
+    const bool regs = per <= MAXPER;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        sum[l] = 0;
+        if (regs) {
+#pragma unroll
+            for (int k = 0; k < MAXPER; ++k) v[l][k] = (beg + k < end) ? in[l * stride + beg + k] : 0;
+#pragma unroll
+            for (int k = 0; k < MAXPER; ++k) sum[l] += v[l][k];
+        } else {
+            for (int i = beg; i < end; ++i) sum[l] += in[l * stride + i];
+        }
     }
-    const int total = s[1023];
-    int run = s[t] - sum;
-    for (int i = beg; i < end; ++i) { const int c = in[i]; out[i] = run; run += c; }
+    int incl[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        incl[l] = sum[l];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl[l], d);
+            if (lane >= d) incl[l] += up;
+        }
+        if (lane == 63) s[l * 16 + wave] = incl[l];
+    }
     __syncthreads();
-    return total;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        int before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int c = s[l * 16 + w];
+            if (w < wave) before += c;
+            all += c;
+        }
+        total[l] = all;
+        int run = before + incl[l] - sum[l];
+        if (regs) {
+#pragma unroll
+            for (int k = 0; k < MAXPER; ++k)
+                if (beg + k < end) { out[l * stride + beg + k] = run; run += v[l][k]; }
+        } else {
+            for (int i = beg; i < end; ++i) { const int c = in[l * stride + i]; out[l * stride + i] = run; run += c; }
+        }
+    }
+    __syncthreads();                                       // s may be reused
 }
 
 __global__ __launch_bounds__(1024) void scan_counts_kernel(const int *__restrict__ counts, int *__restrict__ offsets,
                                                           int n, int *__restrict__ total_out)
 {
-    __shared__ int s[1024];
-    const int total = block_exclusive_scan_1024(counts, offsets, n, s);
-    if (threadIdx.x == 0 && total_out) *total_out = total;
+    __shared__ int s[16];
+    int total[1];
+    block_exclusive_scan_1024<1>(counts, offsets, n, 0, s, total);
+    if (threadIdx.x == 0 && total_out) *total_out = total[0];
 }
 
 __global__ __launch_bounds__(1024) void scan_counts3_kernel(NmCompact3 c)
 {
-    __shared__ int s[1024];
-    for (int l = 0; l < 3; ++l) {
-        const int total = block_exclusive_scan_1024(c.counts + l * c.nb, c.offsets + l * c.nb, c.nb, s);
-        if (threadIdx.x == 0) c.totals[l] = total;
-    }
+    __shared__ int s[48];
+    int total[3];
+    block_exclusive_scan_1024<3>(c.counts, c.offsets, c.nb, c.nb, s, total);
+    if (threadIdx.x < 3) c.totals[threadIdx.x] = total[threadIdx.x];
 }
 
 // ---- frame-driver kernels: detect 3 levels of one octave straight into per-unit staging, then scan + book-keeping,
@@ -204,14 +241,10 @@ __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
 
 __global__ __launch_bounds__(1024) void scan_book_kernel(NmScanArgs a)
 {
-    __shared__ int s[1024];
-    __shared__ int totals[3];
+    __shared__ int s[48];
     const int frame = blockIdx.x;
-    for (int l = 0; l < 3; ++l) {
-        const int tot = block_exclusive_scan_1024(a.counts[frame] + l * a.n_blocks, a.offsets[frame] + l * a.n_blocks, a.n_blocks, s);
-        if (threadIdx.x == 0) totals[l] = tot;
-    }
-    __syncthreads();
+    int totals[3];
+    block_exclusive_scan_1024<3>(a.counts[frame], a.offsets[frame], a.n_blocks, a.n_blocks, s, totals);
     if (threadIdx.x == 0) {
         NmFrameBook *b = a.book[frame];
         int num_items = (a.octave == 0) ? 0 : b->num_items;

@@ -59,6 +59,11 @@ __device__ __forceinline__ int *counter_of(const NmTailArgs &a, int f, int slot,
     return a.state + NM_TAIL_STATE_HEAD + ((f * NM_TAIL_MAX_OCT + slot) << 2) + k;
 }
 
+// (Packed v_pk_fma_f32 forms of both passes -- two rows / two columns half a region apart per register pair, taps in scalar
+// registers, 8 or 4 outputs per task -- were built and measured on MI355X: bit-identical, but no faster (level step 4.3 -> 4.3-7
+// us). In this one big kernel the windows of register pairs push the allocation over the 128 VGPRs a 1024-thread workgroup may
+// have, and the spills cost more than the halved FMA count returns; the detection items, which share the allocation, went
+// from 20 to 46 us.)
 // rows [ry0, ry1) x columns [cx0, cx1) of the row pass: M[row][x] = sum_k A[row][x + k] w[R - k]
 template <int R>
 __device__ __forceinline__ void row_pass(const float *A, float *M, const Frame &F, const float *__restrict__ taps, int ry0,
