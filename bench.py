@@ -405,6 +405,8 @@ def latency_probe(nm, torch, dev, frames4):
     out = {"what": "batch 1, one stream, back-to-back calls, us per call (1080p); pair = one 2-frame detect call + "
                    "device-sized match"}
     try:
+        out["launches_per_frame_call"] = nm.lib().nm_sift_arena_launches_per_call(a[0]._h, 1)
+        out["launches_per_16_frame_call"] = nm.lib().nm_sift_arena_launches_per_call(a[0]._h, 16)
         out["frame_us_eager"] = round(timeit(frame, 50), 1)
         out["pair_us_eager"] = round(timeit(pair, 30), 1)
         gf, gp = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()

@@ -390,6 +390,9 @@ NM_API int nm_sift_arena_set_mask(nm_sift_arena *arena, const float *mask, int m
 NM_API int nm_sift_arena_tail_trace(const nm_sift_arena *arena, unsigned long long *out, int max_items, int *segments,
                                     int max_segments);
 NM_API int nm_sift_arena_tail_segments(const nm_sift_arena *arena);
+/* HOST function: the number of kernel launches one nm_sift_detect_describe[_batch] call of n frames on this arena issues
+ * (1080p: 23 for n <= 2, where the octave tail is used; 51 above). */
+NM_API int nm_sift_arena_launches_per_call(const nm_sift_arena *arena, int n);
 /* HOST function (no device access): the octave-tail plan for a width x height frame whose tail starts at octave T (the frame
  * driver uses T = 2; NM_FRAME_TAIL=1..3 in the environment when an arena is created). segments: 8 ints each (kind, slot, items
  * per frame, first item per frame, octave, 1 if the whole plane is one item, octave width, octave height), in the order in

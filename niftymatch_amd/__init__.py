@@ -87,6 +87,7 @@ _SIGNATURES = {
     "nm_sift_arena_bytes": (_SZ, [_P]),
     "nm_sift_arena_tail_trace": (_I, [_P, _P, _I, _P, _I]),
     "nm_sift_arena_tail_segments": (_I, [_P]),
+    "nm_sift_arena_launches_per_call": (_I, [_P, _I]),
     "nm_sift_tail_plan": (_I, [_I, _I, _I, _P, _I, _P]),
     "nm_sift_arena_set_params": (_I, [_P, _F, _F]),
     "nm_sift_arena_get_params": (_I, [_P, _P, _P]),

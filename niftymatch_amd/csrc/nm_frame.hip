@@ -271,6 +271,23 @@ int nm_sift_arena_tail_trace(const nm_sift_arena *a, unsigned long long *out, in
 }
 int nm_sift_arena_tail_segments(const nm_sift_arena *a) { return (a && a->tail_ok) ? a->tail.n_seg : 0; }
 
+// Kernel launches one nm_sift_detect_describe[_batch] call of n frames on this arena issues (HOST function): base blur, five
+// Gaussian launches + detect / scan / gather per octave, orientation + descriptors; with the octave tail (calls of up to
+// NM_FRAME_TAIL_MAX_BATCH = 2 frames) the octaves >= T are two launches and the description runs in two parts.
+static int tail_max_batch()
+{
+    static const int v = [] { const char *e = getenv("NM_FRAME_TAIL_MAX_BATCH"); return e ? atoi(e) : 2; }();
+    return v;
+}
+int nm_sift_arena_launches_per_call(const nm_sift_arena *a, int n)
+{
+    if (!a || n <= 0) return 0;
+    const int oct = a->params._num_octaves;
+    const bool tail = a->tail_ok && n <= tail_max_batch() && !frame_driver_writes_dog();
+    if (!tail) return 1 + oct * 8 + 2;
+    return 1 + a->tail.T * 8 + 2 + 4;
+}
+
 // HOST function (no device access): the octave-tail plan of a width x height frame with first tail octave T -- what
 // nm_sift_arena_create makes for the arena. segments: 8 ints each (kind, slot, items per frame, first item, octave, whole
 // plane?, octave width, octave height); info: items per frame, LDS bytes of the tail launch, LDS bytes of the scan launch,
@@ -421,8 +438,7 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
     // (a 1080p frame: 22 launches instead of 55); in calls of many frames every per-octave launch is shared by all of them
     // and runs at a better efficiency than the tail's LDS-fused tiles (halo recomputed per tile), so those keep them
     // (16 frames per call, MI355X: 160 vs 171 us per frame). NM_FRAME_TAIL_MAX_BATCH moves the threshold.
-    static const int tail_max_batch = [] { const char *e = getenv("NM_FRAME_TAIL_MAX_BATCH"); return e ? atoi(e) : 2; }();
-    bool use_tail = !dogs && !split && n <= tail_max_batch;
+    bool use_tail = !dogs && !split && n <= tail_max_batch();
     for (int f = 0; f < n; ++f) use_tail = use_tail && as[f]->tail_ok;
     const int first_tail = use_tail ? as[0]->tail.T : P._num_octaves;
     // With the tail, the octaves < T (98 % of a frame's keypoints) are described on the description stream as soon as octave
@@ -495,10 +511,16 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
             da.geom[o].ow = ow; da.geom[o].oh = oh; da.geom[o].xper = xper;
             if (split && o + 1 == split) {
                 NM_RETURN_IF(hipEventRecord(as[0]->ev_det, side));
-                NM_RETURN_IF(hipStreamWaitEvent(dstr, as[0]->ev_det, 0));
-                forked_desc = true;
                 da.o_begin = 0; da.o_end = split;
-                e = nm_launch_frame_describe(da, dstr);
+                if (use_tail) {
+                    // with the tail the side stream has nothing left to detect: the octaves < T are described right there
+                    // (one stream hand-over less on the path base blur -> ... -> descriptors), beside the tail on the caller's
+                    e = nm_launch_frame_describe(da, side);
+                } else {
+                    NM_RETURN_IF(hipStreamWaitEvent(dstr, as[0]->ev_det, 0));
+                    forked_desc = true;
+                    e = nm_launch_frame_describe(da, dstr);
+                }
                 if (e) return e;
             }
         }

@@ -161,5 +161,9 @@ def test_launch_count_of_a_single_frame_call(nm, cuda):
     info = (C.c_int * 4)()
     n = nm.lib().nm_sift_tail_plan(1920, 1080, 2, seg, 40, info)
     assert n > 0 and info[3] == 4                     # octaves 2..5 in one launch
-    launches = 1 + 2 * 5 + 2 * 3 + 2 + 2 + 2          # base blur, 2 octaves x 5 levels, 2 x (detect, scan, gather), tail + scan, 2 x describe
-    assert launches <= 25
+    launches = 1 + 2 * 5 + 2 * 3 + 2 + 2 * 2          # base blur, 2 octaves x 5 levels, 2 x (detect, scan, gather), tail + scan, 2 x describe
+    a = nm.SiftArena(1920, 1080, CAP, device=cuda)
+    assert nm.lib().nm_sift_arena_launches_per_call(a._h, 1) == launches == 23
+    assert nm.lib().nm_sift_arena_launches_per_call(a._h, 2) == 23
+    assert nm.lib().nm_sift_arena_launches_per_call(a._h, 16) == 1 + 6 * 8 + 2
+    a.close()
