@@ -53,7 +53,7 @@ struct nm_sift_arena {
     // per-octave lists (an octave's gather may run after the next octave's detection), the launch finds a frame's planes in a
     // device-resident table, and the FIRST arena of a call lends its state words (zero between launches).
     float *stg[20]; size_t stg_stride[20]; int *cnt[20];
-    NmTailFrame *tail_frame;
+    NmTailFrame tail_frame;      // this arena's planes of the tail octaves (copied into the launch's arguments)
     int *tail_state;
     NmTailArgs tail;           // the plan for this geometry (per-call fields are filled by the driver)
     bool tail_ok;
@@ -190,7 +190,7 @@ int nm_sift_arena_create(int width, int height, int capacity, nm_sift_arena **ou
     if (!rc) rc = (int)hipMemset(a->book, 0, sizeof(NmFrameBook));
     // octave tail: first octave T = 2 (NM_FRAME_TAIL=0 switches it off, 1..3 choose T): octaves 0 and 1 are real streaming
     // work for the whole chip and keep their per-octave launches
-    a->tail_ok = false; a->tail_frame = nullptr; a->tail_state = nullptr;
+    a->tail_ok = false; a->tail_frame = NmTailFrame{}; a->tail_state = nullptr;
     for (int o = 0; o < 20; ++o) { a->stg[o] = nullptr; a->stg_stride[o] = 0; a->cnt[o] = nullptr; }
     {
         const char *e = getenv("NM_FRAME_TAIL");
@@ -199,29 +199,26 @@ int nm_sift_arena_create(int width, int height, int capacity, nm_sift_arena **ou
         for (size_t i = 0; i < P._sigmas.size() && i < 5; ++i) radii[i] = a->radii[i];
         if (!rc && T >= 1 && T <= 3 && P._sigmas.size() == 5 && P._num_dog_levels == 3 && !frame_driver_writes_dog() &&
             nm_tail_plan(a->tail, width, height, P._num_octaves, T, radii)) {
-            NmTailFrame h{};
-            for (int o = 0; o < P._num_octaves; ++o) {
-                for (int i = 0; i < 6; ++i) h.lev[o][i] = a->lev[o][i];
-                h.grad[o] = a->grad[o];
-            }
+            NmTailFrame &h = a->tail_frame;
             for (int o = T; !rc && o < P._num_octaves; ++o) {
+                const int j = o - T;
+                for (int i = 0; i < 6; ++i) h.lev[j][i] = a->lev[o][i];
+                h.grad[j] = a->grad[o];
                 const size_t units = (size_t)(height >> o) * nm_divup(width >> o, 256);
                 a->stg_stride[o] = units * 256;
                 rc = a->alloc(&a->stg[o], 3 * a->stg_stride[o] * 4);
                 if (!rc) rc = a->alloc(&a->cnt[o], 3 * units);
-                h.staging[o] = a->stg[o]; h.stage_stride[o] = a->stg_stride[o]; h.counts[o] = a->cnt[o];
+                h.staging[j] = a->stg[o]; h.stage_stride[j] = a->stg_stride[o]; h.counts[j] = a->cnt[o];
             }
             h.book = a->book;
-            if (!rc) rc = a->alloc(&a->tail_frame, 1);
-            if (!rc) rc = (int)hipMemcpy(a->tail_frame, &h, sizeof(h), hipMemcpyHostToDevice);
             if (!rc) rc = a->alloc(&a->tail_state, NM_TAIL_STATE_INTS);
             if (!rc) rc = (int)hipMemset(a->tail_state, 0, NM_TAIL_STATE_INTS * sizeof(int));
             for (int i = 0; i < 5; ++i) a->tail.taps[i] = a->taps[i];
             a->tail.trace = nullptr;
             const char *tr = getenv("NM_TAIL_TRACE");          // diagnostic: per-item timestamps of the tail launch
             if (!rc && tr && tr[0] == '1') {
-                rc = a->alloc(&a->tail.trace, (size_t)16 * NM_MAX_BATCH * a->tail.items_per_frame);
-                if (!rc) rc = (int)hipMemset(a->tail.trace, 0, (size_t)128 * NM_MAX_BATCH * a->tail.items_per_frame);
+                rc = a->alloc(&a->tail.trace, (size_t)16 * NM_TAIL_MAX_FRAMES * a->tail.items_per_frame);
+                if (!rc) rc = (int)hipMemset(a->tail.trace, 0, (size_t)128 * NM_TAIL_MAX_FRAMES * a->tail.items_per_frame);
             }
             a->tail_ok = !rc;
         }
@@ -283,7 +280,7 @@ int nm_sift_arena_launches_per_call(const nm_sift_arena *a, int n)
 {
     if (!a || n <= 0) return 0;
     const int oct = a->params._num_octaves;
-    const bool tail = a->tail_ok && n <= tail_max_batch() && !frame_driver_writes_dog();
+    const bool tail = a->tail_ok && n <= tail_max_batch() && n <= NM_TAIL_MAX_FRAMES && !frame_driver_writes_dog();
     if (!tail) return 1 + oct * 8 + 2;
     return 1 + a->tail.T * 8 + 2 + 4;
 }
@@ -438,7 +435,7 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
     // (a 1080p frame: 22 launches instead of 55); in calls of many frames every per-octave launch is shared by all of them
     // and runs at a better efficiency than the tail's LDS-fused tiles (halo recomputed per tile), so those keep them
     // (16 frames per call, MI355X: 160 vs 171 us per frame). NM_FRAME_TAIL_MAX_BATCH moves the threshold.
-    bool use_tail = !dogs && !split && n <= tail_max_batch();
+    bool use_tail = !dogs && !split && n <= tail_max_batch() && n <= NM_TAIL_MAX_FRAMES;
     for (int f = 0; f < n; ++f) use_tail = use_tail && as[f]->tail_ok;
     const int first_tail = use_tail ? as[0]->tail.T : P._num_octaves;
     // With the tail, the octaves < T (98 % of a frame's keypoints) are described on the description stream as soon as octave

@@ -200,10 +200,10 @@ __device__ __forceinline__ void grad_from_lds(const float *A, const Frame &F, in
 // One conv item: levels la..lb of the rectangle [x0, x1) x [y0, y1) of octave oc of frame fr.
 // ph: NULL, or 12 words of the diagnostic trace that receive the clock after each phase of the item
 #define NM_TAIL_STAMP(k) do { if (ph && threadIdx.x == 0) ph[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
-__device__ void conv_item(const NmTailArgs &a, const NmTailOct &oc, const NmTailFrame *fr, int f, int slot, int x0, int x1,
+__device__ void conv_item(const NmTailArgs &a, const NmTailOct &oc, const NmTailFrame &fr, int f, int slot, int x0, int x1,
                           int y0, int y1, int la, int lb, float *lds, unsigned long long *ph)
 {
-    const int ow = oc.ow, oh = oc.oh, o = oc.o;
+    const int ow = oc.ow, oh = oc.oh;
     int H = 0;                                             // cumulative halo of the fused levels
     for (int l = la; l <= lb; ++l) H += a.radii[l - 1];
     Frame F;
@@ -223,7 +223,7 @@ __device__ void conv_item(const NmTailArgs &a, const NmTailOct &oc, const NmTail
     {   // input level la - 1 on the image part of the halo region
         const int rx0 = max(x0 - H, 0), rx1 = min(x1 + H, ow), ry0 = max(y0 - H, 0), ry1 = min(y1 + H, oh);
         const int rw = rx1 - rx0, n = rw * (ry1 - ry0);
-        const float *src = fr->lev[o][la - 1];
+        const float *src = fr.lev[slot][la - 1];
         for (int base = 0; base < n; base += 4 * NT) {     // four loads in flight per thread before the first LDS store
             float v[4];
             int dst[4];
@@ -250,12 +250,12 @@ __device__ void conv_item(const NmTailArgs &a, const NmTailOct &oc, const NmTail
         const int R = a.radii[l - 1];
         const float *taps = a.taps[l - 1];
         if (!oc.whole && l - 1 >= 1 && l - 1 <= 3)          // gradient of the INPUT level (plane l - 2 of the octave's three)
-            grad_from_lds(A, F, x0, x1, y0, y1, ow, oh, reinterpret_cast<float2 *>(fr->grad[o]) + (size_t)(l - 2) * ow * oh);
+            grad_from_lds(A, F, x0, x1, y0, y1, ow, oh, reinterpret_cast<float2 *>(fr.grad[slot]) + (size_t)(l - 2) * ow * oh);
         const int hn = h - R;                               // halo of level l
         const int rx0 = max(x0 - hn, 0), rx1 = min(x1 + hn, ow), ry0 = max(y0 - hn, 0), ry1 = min(y1 + hn, oh);
         const int py0 = max(y0 - h, 0), py1 = min(y1 + h, oh);              // rows of the row pass
-        float *plane = fr->lev[o][l];
-        float *down = (l == 3 && oc.decimate) ? fr->lev[o + 1][0] : nullptr;
+        float *plane = fr.lev[slot][l];
+        float *down = (l == 3 && oc.decimate) ? fr.lev[slot + 1][0] : nullptr;
         switch (R) {
             case 5: level_step<5>(A, M, F, taps, rx0, rx1, ry0, ry1, py0, py1, x0, x1, y0, y1, plane, ow, oh, down); break;
             case 7: level_step<7>(A, M, F, taps, rx0, rx1, ry0, ry1, py0, py1, x0, x1, y0, y1, plane, ow, oh, down); break;
@@ -273,13 +273,13 @@ __device__ void conv_item(const NmTailArgs &a, const NmTailOct &oc, const NmTail
 }
 
 // gradient item of a whole plane: level m (1..3), rows [band * GRAD_BAND, ...), straight from the global level plane
-__device__ void grad_item(const NmTailOct &oc, const NmTailFrame *fr, int idx)
+__device__ void grad_item(const NmTailOct &oc, const NmTailFrame &fr, int slot, int idx)
 {
     const int bands = (oc.oh + GRAD_BAND - 1) / GRAD_BAND;
     const int m = 1 + idx / bands, band = idx - (m - 1) * bands;
     const int ow = oc.ow, oh = oc.oh, y0 = band * GRAD_BAND, y1 = min(y0 + GRAD_BAND, oh);
-    const float *src = fr->lev[oc.o][m];
-    float2 *gplane = reinterpret_cast<float2 *>(fr->grad[oc.o]) + (size_t)(m - 1) * ow * oh;
+    const float *src = fr.lev[slot][m];
+    float2 *gplane = reinterpret_cast<float2 *>(fr.grad[slot]) + (size_t)(m - 1) * ow * oh;
     const int n = ow * (y1 - y0);
     for (int i = threadIdx.x; i < n; i += NT) {
         const int ry = i / ow, x = i - ry * ow, y = y0 + ry;
@@ -299,7 +299,7 @@ __device__ void grad_item(const NmTailOct &oc, const NmTailFrame *fr, int idx)
 // :165-169), and all output slots of all (octave, level) lists are gathered together (sift/pyramidata.cu:84-91: raster
 // order). li: ints of LDS: the offsets, then 16 words per (octave, level).
 template <int NTH>
-__device__ void scan_gather_all(const NmTailArgs &a, const NmTailFrame *fr, int f, int *li)
+__device__ void scan_gather_all(const NmTailArgs &a, const NmTailFrame &fr, int f, int *li)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_lists = 3 * a.n_oct;
     int base_of[NM_TAIL_MAX_OCT + 1];                     // first LDS word of octave slot j's 3 x n_blocks offsets
@@ -307,8 +307,10 @@ __device__ void scan_gather_all(const NmTailArgs &a, const NmTailFrame *fr, int 
 #pragma unroll
     for (int j = 0; j < NM_TAIL_MAX_OCT; ++j) base_of[j + 1] = base_of[j] + (j < a.n_oct ? 3 * a.oct[j].n_blocks : 0);
     int *s_off = li, *s_tot = li + base_of[NM_TAIL_MAX_OCT];     // s_tot[3 j + l]: total; [32 + ..]: lvl_n; [64 + ..]: lvl_base
+    // the book's running count after octave T - 1 (an earlier launch of this stream): requested now, used after the scans
+    const int items_before = (tid == 0 && a.oct[0].o != 0) ? fr.book->num_items : 0;
     for (int j = 0; j < a.n_oct; ++j) {                   // all loads in flight together
-        const int *counts = fr->counts[a.oct[j].o];
+        const int *counts = fr.counts[j];
         const int n = 3 * a.oct[j].n_blocks;
         for (int i = tid; i < n; i += NTH) s_off[base_of[j] + i] = counts[i];
     }
@@ -333,8 +335,8 @@ __device__ void scan_gather_all(const NmTailArgs &a, const NmTailFrame *fr, int 
     }
     __syncthreads();
     if (tid == 0) {
-        NmFrameBook *b = fr->book;
-        int num_items = (a.oct[0].o == 0) ? 0 : b->num_items;      // octave T - 1's scan ran in an earlier launch of this stream
+        NmFrameBook *b = fr.book;
+        int num_items = items_before;
         for (int j = 0; j < a.n_oct; ++j) {
             const int o = a.oct[j].o;
             b->oct_base[o] = num_items;
@@ -363,22 +365,22 @@ __device__ void scan_gather_all(const NmTailArgs &a, const NmTailFrame *fr, int 
         int q = 0;                                        // the list that holds output slot `slot_out`
         while (q + 1 < n_lists && slot_out >= s_tot[64 + q + 1]) ++q;
         while (s_tot[32 + q] == 0 && q + 1 < n_lists) ++q;         // (lists of zero length share their successor's base)
-        const int j = q / 3, l = q - 3 * j, nb = a.oct[j].n_blocks, o = a.oct[j].o, pos = slot_out - s_tot[64 + q];
+        const int j = q / 3, l = q - 3 * j, nb = a.oct[j].n_blocks, pos = slot_out - s_tot[64 + q];
         const int *off = s_off + base_of[j] + l * nb;
         int lo = 0, hi = nb;                              // last unit whose exclusive offset is <= pos
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
             if (off[mid] <= pos) lo = mid; else hi = mid;
         }
-        const float4 *st = reinterpret_cast<const float4 *>(fr->staging[o]) + (size_t)l * fr->stage_stride[o];
+        const float4 *st = reinterpret_cast<const float4 *>(fr.staging[j]) + (size_t)l * fr.stage_stride[j];
         out[slot_out] = st[(size_t)lo * 256 + (pos - off[lo])];
     }
 }
 
 // NQ unit groups per item, one per 256-thread quarter of the workgroup (idx-th item: groups NQ idx .. NQ idx + NQ - 1)
 template <bool MASKED>
-__device__ __forceinline__ void detect_item(const NmTailArgs &a, const NmTailOct &oc, const NmTailFrame *fr, int f, int idx,
-                                            nmdet::DetectSmem *sm)
+__device__ __forceinline__ void detect_item(const NmTailArgs &a, const NmTailOct &oc, const NmTailFrame &fr, int slot, int f,
+                                            int idx, nmdet::DetectSmem *sm)
 {
     const int groups = oc.nseg * ((oc.oh + nmdet::DET_ROWS - 1) / nmdet::DET_ROWS);
     const int want = NQ * idx + (int)(threadIdx.x >> 8);
@@ -386,8 +388,8 @@ __device__ __forceinline__ void detect_item(const NmTailArgs &a, const NmTailOct
     const int blk = active ? want : groups - 1;
     nmdet::DetectView v;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) v.planes[i] = fr->lev[oc.o][i];
-    v.staging = fr->staging[oc.o]; v.stage_stride = fr->stage_stride[oc.o]; v.counts = fr->counts[oc.o];
+    for (int i = 0; i < 6; ++i) v.planes[i] = fr.lev[slot][i];
+    v.staging = fr.staging[slot]; v.stage_stride = fr.stage_stride[slot]; v.counts = fr.counts[slot];
     v.dense[0] = v.dense[1] = v.dense[2] = nullptr;
     v.mask = MASKED ? a.masks[f] : nullptr; v.mask_w = a.mask_w; v.mask_h = a.mask_h;
     v.ow = oc.ow; v.oh = oc.oh; v.peak = a.peak; v.edge = a.edge; v.xper = oc.xper; v.sigma0 = a.sigma0;
@@ -406,6 +408,7 @@ __global__ __launch_bounds__(NT) void tail_kernel(NmTailArgs a)
     int &s_flag = reinterpret_cast<int *>(lds + (a.lds_bytes >> 2))[1];
     int *const state = a.state;
     const int total = a.n * a.items_per_frame;
+    __builtin_amdgcn_s_setprio(2);                          // a latency chain beside the other stream's throughput kernels
     for (;;) {
         if (threadIdx.x == 0) s_ticket = add_i32_agent(state + 0, 1);
         __syncthreads();
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(NT) void tail_kernel(NmTailArgs a)
         const int local = t - a.n * a.seg[si].first_per_frame;
         const int f = local / per_frame, idx = local - f * per_frame;
         const NmTailOct &oc = a.oct[slot];
-        const NmTailFrame *fr = a.fr[f];
+        const NmTailFrame &fr = a.fr[f];
         // what the item waits for (always items with smaller tickets)
         const int *c0 = nullptr, *c1 = nullptr;
         int t0 = 0, t1 = 0;
@@ -446,11 +449,11 @@ __global__ __launch_bounds__(NT) void tail_kernel(NmTailArgs a)
             conv_item(a, oc, fr, f, slot, x0, x1, y0, y1, la, lb, lds,
                       a.trace ? a.trace + 4 * (size_t)total + 12 * (size_t)t : nullptr);
         } else if (kind == NM_TAIL_GRAD) {
-            grad_item(oc, fr, idx);
+            grad_item(oc, fr, slot, idx);
         } else {
             // staging lists and counts go to the scan launch behind this one: plain stores, nothing to publish
             nmdet::DetectSmem *sm = reinterpret_cast<nmdet::DetectSmem *>(lds);
-            if (a.any_mask) detect_item<true>(a, oc, fr, f, idx, sm); else detect_item<false>(a, oc, fr, f, idx, sm);
+            if (a.any_mask) detect_item<true>(a, oc, fr, slot, f, idx, sm); else detect_item<false>(a, oc, fr, slot, f, idx, sm);
         }
         __syncthreads();                                   // the LDS is reused by the next item
         if (a.trace && threadIdx.x == 0) {                 // 100 MHz clock: ticket drawn, inputs ready, item done
@@ -476,6 +479,9 @@ constexpr int SCAN_NT = 256;             // a few hundred counts and keypoints p
 __global__ __launch_bounds__(SCAN_NT) void tail_scan_kernel(NmTailArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // four waves on the critical path of a single-frame call, sharing their CU with the description kernel of the other
+    // stream (16 waves of dense VALU work): without the raised issue priority they take 39 us for what they do alone in 8
+    __builtin_amdgcn_s_setprio(3);
     scan_gather_all<SCAN_NT>(a, a.fr[blockIdx.x], blockIdx.x, reinterpret_cast<int *>(lds));
 }
 

@@ -23,14 +23,16 @@ struct NmTailOct {
     int decimate;                    // level 3 seeds octave o + 1
 };
 
-// Device-resident table of one arena's per-octave planes (filled once at arena creation): the tail kernel's items find
-// their frame's buffers here instead of in a 4 KB kernel-argument block.
+// One frame's buffers for the tail octaves, indexed by SLOT (octave - T). Kept by value inside the kernel arguments (the
+// tail serves calls of at most NM_TAIL_MAX_FRAMES frames): an item reads its plane pointers from the kernel-argument segment
+// instead of paying a dependent memory round trip for a device-resident table first.
+#define NM_TAIL_MAX_FRAMES 2
 struct NmTailFrame {
-    float *lev[20][6];
-    float *grad[20];
-    float *staging[20];
-    size_t stage_stride[20];
-    int *counts[20];
+    float *lev[NM_TAIL_MAX_OCT][6];
+    float *grad[NM_TAIL_MAX_OCT];
+    float *staging[NM_TAIL_MAX_OCT];
+    size_t stage_stride[NM_TAIL_MAX_OCT];
+    int *counts[NM_TAIL_MAX_OCT];
     NmFrameBook *book;
 };
 
@@ -44,10 +46,10 @@ struct NmTailSeg {
 struct NmTailArgs {
     int n, n_oct, T;
     NmTailOct oct[NM_TAIL_MAX_OCT];
-    const NmTailFrame *fr[NM_MAX_BATCH];
-    float *kpts[NM_MAX_BATCH];
-    int *d_num_items[NM_MAX_BATCH];
-    const float *masks[NM_MAX_BATCH];
+    NmTailFrame fr[NM_TAIL_MAX_FRAMES];
+    float *kpts[NM_TAIL_MAX_FRAMES];
+    int *d_num_items[NM_TAIL_MAX_FRAMES];
+    const float *masks[NM_TAIL_MAX_FRAMES];
     int any_mask, mask_w, mask_h;
     float peak, edge, sigma0;
     int num_dogs, capacity;
@@ -64,7 +66,7 @@ static_assert(sizeof(NmTailArgs) <= 4096, "kernel arguments are limited to 4 KB"
 
 // state words: [0] ticket, [1] workgroups that have left, [2] sticky error, then per (frame, slot) four counters
 #define NM_TAIL_STATE_HEAD 4
-#define NM_TAIL_STATE_INTS (NM_TAIL_STATE_HEAD + NM_MAX_BATCH * NM_TAIL_MAX_OCT * 4)
+#define NM_TAIL_STATE_INTS (NM_TAIL_STATE_HEAD + NM_TAIL_MAX_FRAMES * NM_TAIL_MAX_OCT * 4)
 
 // Host side: plans the launch for one geometry (false: this geometry / these radii are not covered, use the per-octave launches).
 bool nm_tail_plan(NmTailArgs &a, int width, int height, int num_octaves, int T, const int radii[5]);
