@@ -416,6 +416,22 @@ def latency_probe(nm, torch, dev, frames4):
             pair()
         out["frame_us_graph"] = round(timeit(gf.replay, 50), 1)
         out["pair_us_graph"] = round(timeit(gp.replay, 30), 1)
+        # what a latency-bound client does with two frames: one single-frame call per frame on a stream of its own (each is
+        # the 23-launch tail path and leaves most of the chip idle), the match behind both on the first stream
+        s2, ev = torch.cuda.Stream(device=dev), torch.cuda.Event()
+
+        def pair_two_streams():
+            ev0 = torch.cuda.Event()
+            ev0.record(s)
+            with torch.cuda.stream(s2):
+                s2.wait_event(ev0)                       # ordered behind the previous match (it read a[1])
+                a[1].detect_describe(buf[1])
+                ev.record(s2)
+            a[0].detect_describe(buf[0])
+            s.wait_event(ev)
+            nm.sift_match_batch_dev([a[0].desc], [a[0].num_items], [a[1].desc], [a[1].num_items], [res], 0.8, workspace=ws)
+
+        out["pair_us_eager_two_streams"] = round(timeit(pair_two_streams, 30), 1)
         # the pair graph on OTHER frames (their keypoint counts differ): must equal the eager calls on those frames
         buf[0].copy_(frames4[2]); buf[1].copy_(frames4[3])
         res.fill_(-1)
@@ -901,7 +917,7 @@ def main():
         # the figures a reader needs first go to the head of the line: the driver keeps only a tail of a long stdout
         head.update({"roofline_frac": roof.get("frac"), "roofline_kernel": roof.get("kernel"),
                      "verified_pair0_vs_oracle": out.get("verified_pair0_vs_oracle"),
-                     "latency_us": ({k: latency.get(k) for k in ("frame_us_eager", "frame_us_graph", "pair_us_eager", "pair_us_graph")}
+                     "latency_us": ({k: latency.get(k) for k in ("launches_per_frame_call", "frame_us_eager", "frame_us_graph", "pair_us_eager", "pair_us_graph", "pair_us_eager_two_streams")}
                                     if isinstance(latency, dict) else None),
                      "detect_256_frames_per_s": (detect256 or {}).get("frames_per_s")})
         ordered = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step")}

@@ -24,6 +24,8 @@ bad = 0
 t0 = time.time()
 for it in range(n_frames):
     w = int(rng.integers(24, 400)); h = int(rng.integers(24, 300))
+    if rng.random() < 0.25:                                            # round 4: geometries whose octaves >= 2 take the tail launch
+        w = int(rng.integers(256, 900)); h = int(rng.integers(200, 700))   # (tiled and whole-plane items, odd sizes)
     if rng.random() < 0.5:
         w = (w // 4) * 4 + (0 if rng.random() < 0.8 else 1)        # mostly the packed path, sometimes the generic one
     nb = int(rng.integers(1, 4))
