@@ -126,11 +126,13 @@ struct DetectSmem {
 // What one unit group needs of one frame's octave (filled from NmDetectArgs by the launch wrapper, or from the tail
 // kernel's per-frame tables).
 struct DetectView {
-    const float *planes[6];         // LEV: Gaussian levels 0..5; else DoG planes 0..4
+    const float *const *planes;     // LEV: Gaussian levels 0..5, else DoG planes 0..4: a pointer INTO THE KERNEL ARGUMENTS (the
+                                    // refinement indexes it with a run-time level: a copy in the view would live in scratch memory,
+                                    // which cost detect_stage_kernel 12 % when the body was first factored out)
     float *staging;                 // 3 x stage_stride float4
     size_t stage_stride;
     int *counts;                    // 3 x n_blocks
-    float *dense[3];                // DENSE (API path)
+    float *const *dense;            // DENSE (API path): the three dense maps, likewise a pointer into the kernel arguments
     const float *mask;              // full-resolution mask or NULL
     int mask_w, mask_h;
     int ow, oh;

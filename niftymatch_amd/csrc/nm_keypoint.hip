@@ -229,10 +229,9 @@ __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
     __shared__ DetectSmem sm;
     const int frame = blockIdx.y;
     DetectView v;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) v.planes[i] = LEV ? a.lev[frame][i] : (i < 5 ? a.dog[frame][i] : nullptr);
+    v.planes = LEV ? a.lev[frame] : a.dog[frame];
     v.staging = a.staging[frame]; v.stage_stride = a.stage_stride; v.counts = a.counts[frame];
-    v.dense[0] = a.dense[0]; v.dense[1] = a.dense[1]; v.dense[2] = a.dense[2];
+    v.dense = a.dense;
     v.mask = MASKED ? (DENSE ? a.mask : a.masks[frame]) : nullptr; v.mask_w = a.mask_w; v.mask_h = a.mask_h;
     v.ow = a.ow; v.oh = a.oh; v.peak = a.peak; v.edge = a.edge; v.xper = a.xper; v.sigma0 = a.sigma0;
     v.num_dogs = a.num_dogs; v.n_blocks = a.n_blocks; v.nseg = a.nseg;

@@ -387,10 +387,9 @@ __device__ __forceinline__ void detect_item(const NmTailArgs &a, const NmTailOct
     const bool active = want < groups;
     const int blk = active ? want : groups - 1;
     nmdet::DetectView v;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) v.planes[i] = fr.lev[slot][i];
+    v.planes = fr.lev[slot];
     v.staging = fr.staging[slot]; v.stage_stride = fr.stage_stride[slot]; v.counts = fr.counts[slot];
-    v.dense[0] = v.dense[1] = v.dense[2] = nullptr;
+    v.dense = nullptr;
     v.mask = MASKED ? a.masks[f] : nullptr; v.mask_w = a.mask_w; v.mask_h = a.mask_h;
     v.ow = oc.ow; v.oh = oc.oh; v.peak = a.peak; v.edge = a.edge; v.xper = oc.xper; v.sigma0 = a.sigma0;
     v.num_dogs = a.num_dogs; v.n_blocks = oc.n_blocks; v.nseg = oc.nseg;
