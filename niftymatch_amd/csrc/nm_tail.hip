@@ -309,10 +309,35 @@ __device__ void scan_gather_all(const NmTailArgs &a, const NmTailFrame &fr, int 
     int *s_off = li, *s_tot = li + base_of[NM_TAIL_MAX_OCT];     // s_tot[3 j + l]: total; [32 + ..]: lvl_n; [64 + ..]: lvl_base
     // the book's running count after octave T - 1 (an earlier launch of this stream): requested now, used after the scans
     const int items_before = (tid == 0 && a.oct[0].o != 0) ? fr.book->num_items : 0;
-    for (int j = 0; j < a.n_oct; ++j) {                   // all loads in flight together
-        const int *counts = fr.counts[j];
-        const int n = 3 * a.oct[j].n_blocks;
-        for (int i = tid; i < n; i += NTH) s_off[base_of[j] + i] = counts[i];
+    {   // every octave's counts with ALL of a thread's loads in flight before the first LDS store: this launch is a chain of
+        // memory round trips on the critical path of a single-frame call (a loop of load -> store pairs made it eleven of them)
+        constexpr int MAXK = 12;
+        const int n_all = base_of[NM_TAIL_MAX_OCT];
+        if (n_all <= MAXK * NTH) {
+            int v[MAXK];
+#pragma unroll
+            for (int k = 0; k < MAXK; ++k) {
+                const int idx = tid + k * NTH;
+                v[k] = 0;
+                if (idx < n_all) {
+                    const int *cp = fr.counts[0];           // select chain over compile-time slots: the pointers stay scalar loads
+                    int b0 = 0;
+#pragma unroll
+                    for (int jj = 1; jj < NM_TAIL_MAX_OCT; ++jj)
+                        if (jj < a.n_oct && idx >= base_of[jj]) { cp = fr.counts[jj]; b0 = base_of[jj]; }
+                    v[k] = cp[idx - b0];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < MAXK; ++k)
+                if (tid + k * NTH < n_all) s_off[tid + k * NTH] = v[k];
+        } else {
+            for (int j = 0; j < a.n_oct; ++j) {
+                const int *counts = fr.counts[j];
+                const int n = 3 * a.oct[j].n_blocks;
+                for (int i = tid; i < n; i += NTH) s_off[base_of[j] + i] = counts[i];
+            }
+        }
     }
     __syncthreads();
     for (int q = wave; q < n_lists; q += NTH / 64) {       // exclusive scan of list q = (slot j, level l) by this wave

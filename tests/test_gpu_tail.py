@@ -155,7 +155,7 @@ def test_many_tail_launches_side_by_side(nm, cuda):
 
 
 def test_launch_count_of_a_single_frame_call(nm, cuda):
-    """A 1080p frame: 22 launches with the tail (55 without): the plan says what the tail launch covers."""
+    """A 1080p frame: 23 launches with the tail (51 without): the plan says what the tail launch covers."""
     import ctypes as C
     seg = (C.c_int * (8 * 40))()
     info = (C.c_int * 4)()
