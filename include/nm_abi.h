@@ -68,6 +68,12 @@ NM_API int nm_profile_event_pairs(int site, void *const *events, int npairs);
  * expansion for EVERY float of its domain [2^-96, 2^96) and 0; *d_mismatches (device) receives the number of differing
  * inputs. Must be 0. */
 NM_API int nm_selftest_sqrt(unsigned long long *d_mismatches, void *stream);
+/* Self-test (no reference counterpart): the descriptor's window weight (float)exp((nx^2 + ny^2) / 8) (kernels/descriptor.cu:108)
+ * is evaluated on voting samples by a table form whose result is proven equal to the spec's binary64 sequence unless it
+ * reports a nearby binary32 rounding boundary (then the spec sequence runs). Every float of the form's domain [0, 12.875] is
+ * compared. d_out (device, 3 x unsigned long long): [0] unreported differences (must be 0), [1] inputs that report a nearby
+ * boundary, [2] inputs tested. */
+NM_API int nm_selftest_expw(unsigned long long *d_out, void *stream);
 /* Self-test of the matrix-pipe rounding premise under the matcher's proofs (no reference counterpart; what it protects is
  * the exact scan of kernels/match.cu:83-117, which match_finalize_kernel must reproduce from MFMA-screened candidates).
  * instruction: 0 = v_mfma_f32_32x32x16_bf16 (bf16x3 screen, every norm k-slot), 1 = v_mfma_f32_32x32x16_f16 (coarse pass of

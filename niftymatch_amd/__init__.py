@@ -73,6 +73,7 @@ _SIGNATURES = {
     "nm_downsample2_u8x4": (_I, [_P, _I, _I, _P, _I, _I, _P]),
     "nm_align_points": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "nm_selftest_sqrt": (_I, [_P, _P]),
+    "nm_selftest_expw": (_I, [_P, _P]),
     "nm_selftest_mfma_model": (_I, [_I, _I, _I, _P, _P]),
     "nm_sift_match_accum_budget": (_F, [_I]),
     "nm_undistort_map_f32": (_I, [_P, _P, _SZ, _SZ, _P, _P, _P, _P, _P]),
@@ -521,6 +522,15 @@ def selftest_sqrt():
     out = torch.zeros(1, dtype=torch.int64, device="cuda")
     _check(lib().nm_selftest_sqrt(_dev(out), _stream()), "nm_selftest_sqrt")
     return int(out.item())
+
+
+def selftest_expw():
+    """nm_selftest_expw: (unreported differences, inputs reporting a nearby rounding boundary, inputs tested) of the descriptor
+    weight's table form against the spec sequence over its whole domain. The first must be 0."""
+    torch = _torch()
+    out = torch.zeros(3, dtype=torch.int64, device="cuda")
+    _check(lib().nm_selftest_expw(_dev(out), _stream()), "nm_selftest_expw")
+    return tuple(int(v) for v in out.cpu())
 
 
 MFMA_BF16, MFMA_F16 = 0, 1

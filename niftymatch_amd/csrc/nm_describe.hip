@@ -10,6 +10,7 @@
 //                (4 rows per wave pass, issued as 4 exec-masked read-add-write groups in row order: LDS executes a
 //                wave's instructions in order), 8 votes per sample in (dbinx, dbiny, dbint) order; the 16 partials
 //                are combined by a balanced pairwise tree (strides 1,2,4,8) by the lane that owns the bin.
+#include <cstdlib>
 #include "nm_common.hpp"
 #include "nm_fpspec.hpp"
 #include "nm_describe.hpp"
@@ -153,9 +154,19 @@ __device__ __forceinline__ int orient_wave(const float4 kp, const float2 *__rest
     return orient_finish(o, th0, th1, part);
 }
 
-constexpr int DESC_PITCH = 20;                  // floats per bin row: 16 partials + 4 pad (conflict-free b128 reads)
-constexpr int DESC_LDS = 128 * DESC_PITCH;      // floats of LDS per wave (10 KB)
-
+// LDS of one descriptor wave (floats): [16 cells][9 temporal slots][16 partials] | [9 rows][16] landing words of rejected votes.
+// The kernel is bound by the NUMBER of LDS instructions its votes issue (round 4: halving the waves per SIMD -> 1.7 x the time;
+// 10 % fewer VALU instructions, conflict-free banks, the votes' latency hidden behind the next pass's math -> no gain or a
+// loss; no votes at all -> -27 %; LDS float atomics -> 6 x slower), so the layout serves the votes: a sample's two temporal
+// votes go to slots (bint & 7) and (bint & 7) + 1 of the same cell and partial -- 16 floats apart, ONE ds_read2_b32 and ONE
+// ds_write2_b32 -- with slot 8 collecting what wraps round to orientation bin 0 (added to it when the partials are combined:
+// the fp spec's summation order). With a pitch of 16 floats the 16 lanes of a vote instruction (partials
+// tx = 0..15 of arbitrary rows) hit 16 different banks.
+constexpr int DESC_PITCH = 16;
+constexpr int DESC_ROWS = 16 * 9;               // 144
+constexpr int DESC_DUMMY = DESC_ROWS * DESC_PITCH;             // + slot * DESC_PITCH + tx
+constexpr int DESC_LDS = DESC_DUMMY + 9 * DESC_PITCH;          // 2448 floats = 9 792 B: 16 waves per CU
+static_assert(DESC_LDS * 4 <= 10240, "descriptor LDS layout");
 // One wave computes one descriptor. part: DESC_LDS floats of LDS private to the wave, laid out [bin][partial].
 // A descriptor is computed in two steps so that a wave can set up its NEXT keypoint (window, and the gradient samples of
 // the first 16 x 16 chunk) before it processes the current one: the gather latency at the start of a keypoint was exposed.
@@ -215,40 +226,57 @@ __device__ __forceinline__ void desc_run(const DescSetup &d, float *__restrict__
 
     {   // zero the wave's partial histograms with 16-byte stores
         float4 *z = reinterpret_cast<float4 *>(part);
+        static_assert(DESC_LDS / 4 == 9 * 64 + 36, "zeroing pattern");
 #pragma unroll
-        for (int i = 0; i < DESC_LDS / 4 / 64; ++i) z[i * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < 9; ++i) z[i * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < 36) z[9 * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    float *mine = part + 80 * DESC_PITCH + tx;    // origin at the centre bin (descriptor.cu:81), partial tx
+    float *mine = part + 90 * DESC_PITCH + tx;    // origin at the centre cell (descriptor.cu:81: cell (2, 2) = row 9 * 10), partial tx
+    // Per-lane constants of the sample grid. A lane's samples are (column tx of chunk c, row 4 q + tyg of chunk c):
+    //   cx = xmin + tx + 16 c,  cy = ymin + tyg + 16 c + 4 q;  in the window <=> 16 c <= lx and 16 c + 4 q <= ly.
+    // fx0 + 16 c and fy0 + (16 c + 4 q) are exact (integers below 2^24): the sample's pixel coordinate (float)(xi + cx).
+    const float fx0 = (float)(xi + xmin + tx), fy0 = (float)(yi + ymin + tyg);
+    const int lx = xmax - xmin - tx, ly = ymax - ymin - tyg;
+    // binary32 ESTIMATE of the normalised coordinates (nx, ny), linear in (c, q): only used to skip passes, with a margin
+    // (0.01) a thousand times its error
+    const float ex0 = (fct * (fx0 - x) + fst * (fy0 - y)) * frs, ey0 = (fct * (fy0 - y) - fst * (fx0 - x)) * frs;
+    const float sxc = 16.f * (fct + fst) * frs, syc = 16.f * (fct - fst) * frs, sxq = 4.f * fst * frs, syq = 4.f * fct * frs;
 
     // Gradient samples of a chunk are fetched together (4 independent loads per lane) and the next chunk's loads are
     // issued before the current chunk is processed, so the gather latency is paid once, not per sample.
     float2 cur[4], nxt[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) cur[q] = d.first[q];
+
     for (int c = 0; c < chunks; ++c) {
         if (c + 1 < chunks) desc_fetch_chunk(d, c + 1, nxt);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int cx = tx + xmin + 16 * c, cy = 4 * q + tyg + ymin + 16 * c;
-            const bool inwin = (cx <= xmax && cy <= ymax);
+            const bool inwin = (16 * c <= lx) && (16 * c + 4 * q <= ly);
             {   // a sample votes only if |nx| < 2.5 and |ny| < 2.5 (bins -2..1 in x and y). Skip the whole 4 x 16 pass
                 // when no lane can: the skipped votes would all have been exact +0 no-ops. fp32 estimate, 0.01 margin.
-                const float fdx = (float)(xi + cx) - x, fdy = (float)(yi + cy) - y;
-                const float enx = (fct * fdx + fst * fdy) * frs, eny = (fct * fdy - fst * fdx) * frs;
+                const float exc = fma32((float)c, sxc, ex0), eyc = fma32((float)c, syc, ey0);
+                const float enx = q ? fma32((float)q, sxq, exc) : exc, eny = q ? fma32((float)q, syq, eyc) : eyc;
                 const bool maybe = inwin && __builtin_fabsf(enx) < 2.51f && __builtin_fabsf(eny) < 2.51f;
                 if (!__any(maybe)) continue;
             }
             const float2 gq = cur[q];
             const float mod = inwin ? gq.x : 0.f, ang = gq.y;
             const float theta = nmfp::mod_2pi_f(ang - angle0);
-            const float dx = (float)(xi + cx) - x, dy = (float)(yi + cy) - y;
-            const float nx = nmfp::div_to_f32(fma64(ct0, (double)dx, st0 * (double)dy), dSBP, rSBP);
-            const float ny = nmfp::div_to_f32(fma64(-st0, (double)dx, ct0 * (double)dy), dSBP, rSBP);
-            const float nt = nmfp::div_to_f32((double)(8.0f * theta), nmfp::TWO_PI_D, nmfp::INV_TWO_PI_D);
+            const float dx = (fx0 + (float)(16 * c)) - x, dy = (fy0 + (float)(16 * c + 4 * q)) - y;
+            const float nx = nmfp::div_to_f32_wave(fma64(ct0, (double)dx, st0 * (double)dy), dSBP, rSBP);
+            const float ny = nmfp::div_to_f32_wave(fma64(-st0, (double)dx, ct0 * (double)dy), dSBP, rSBP);
+            const float nt = nmfp::div_to_f32_wave((double)(8.0f * theta), nmfp::TWO_PI_D, nmfp::INV_TWO_PI_D);
             // exp_spec clamps its argument to [-700, 700]: t / 8 > 700 <=> t > 5600 exactly (t = nx^2 + ny^2 >= 0 is a float,
             // the division by 8 is exact), so the clamp is taken on the float (one v_min_f32) and the binary64 compares /
             // selects are dropped
-            const float win = (float)nmfp::exp_spec_in_range((double)__builtin_fminf(fma32(nx, nx, ny * ny), 5600.0f) / 8.0);
+            // (On a sample that can vote, |nx|, |ny| <= 2.5 and t <= 12.5: the fast form of nm_fpspec.hpp, bit-identical to the
+            // spec sequence unless it reports `near`. Beyond EXPW_TMAX the clamped value is meaningless and never used: every
+            // vote of such a sample is rejected by the in-grid test below.)
+            const float t = fma32(nx, nx, ny * ny);
+            bool near;
+            float win = nmfp::expw_fast(__builtin_fminf(t, nmfp::EXPW_TMAX), near);
+            if (__builtin_expect(__any(near), 0)) win = (float)nmfp::exp_spec_in_range((double)__builtin_fminf(t, 5600.0f) / 8.0);
             // floor((double)n - 0.5) and (float)((double)n - (bin + 0.5)) in binary32, bit for bit: (double)n - 0.5 is exact, so
             // the floor is floor(n) - [n - floor(n) < 0.5] (both exact in binary32); bin + 0.5 is exact in binary32, and the
             // one rounding of n - (bin + 0.5) is the same rounding of the same real number (|n| < 2^22 inside a window)
@@ -260,50 +288,44 @@ __device__ __forceinline__ void desc_run(const DescSetup &d, float *__restrict__
             const float rbiny = ny - ((float)biny + 0.5f);
             const float rbint = nt - (float)bint;
             const float wm = win * mod;
-            // votes outside the 4x4 grid (or outside the window) become +0 into the row's pad word, so the 8 addresses
-            // of a sample never collide and the read-add-write below can be issued as 8 loads, 8 adds, 8 stores
-            float wt[8];
-            float *loc[8];
-            // pad word 16 of histogram row 0 (the same word for every lane; rows 1..7 have one each at + t * DESC_PITCH)
-            float *const dummy = part + 16;
-            // histogram word = (binx * 8 + biny * 32 + bint) * DESC_PITCH with 24-bit multiplies (v_mad_i32_i24 is full
-            // rate; the 32-bit v_mul_lo_u32 the plain expression compiles to costs four VALU slots, eight times per sample).
-            // The addresses are formed as pointers: (binx, biny) part once, + the two bint rows -- one add per vote.
-            float *const base = mine + (__mul24(binx, 8 * DESC_PITCH) + __mul24(biny, 32 * DESC_PITCH));
-            const int t0 = bint & 7, t1 = (bint + 1) & 7;           // bint in [0, 8]
-            const int tw[2] = {__mul24(t0, DESC_PITCH), __mul24(t1, DESC_PITCH)};
+            // votes outside the 4x4 grid (or outside the window) become +0 into a landing word behind the histogram, so the 8
+            // addresses of a sample never collide and a round can be issued as 4 two-word loads, 8 adds, 4 two-word stores
+            float *const dummy = part + DESC_DUMMY + tx;
+            // word = (9 * cell + slot) * DESC_PITCH + tx, cell = (binx + 2) + 4 (biny + 2), with 24-bit multiplies
+            float *const base = mine + (__mul24(binx, 9 * DESC_PITCH) + __mul24(biny, 36 * DESC_PITCH));
+            const int tw = (bint & 7) * DESC_PITCH;                  // bint in [0, 8]; the second vote lies DESC_PITCH further
             const bool okx[2] = {(unsigned)(binx + 2) < 4u, (unsigned)(binx + 3) < 4u};
             const bool oky[2] = {(unsigned)(biny + 2) < 4u, (unsigned)(biny + 3) < 4u};
             // The in-grid test depends on (dbx, dby) only: it is applied to the partial product (wm * ax) * ay and to the
             // (binx, biny) part of the address -- four selects each instead of eight. A rejected vote is +0 either way
-            // (0 * |..| = +0: the factors are finite and non-negative) and lands in the pad word of row t0 / t1.
+            // (0 * |..| = +0: the factors are finite and non-negative).
+            float wt[8];
+            float *loc[4];
+            const float at0 = __builtin_fabsf(1.f - rbint), at1 = __builtin_fabsf(0.f - rbint);
 #pragma unroll
             for (int dbx = 0; dbx < 2; ++dbx)
 #pragma unroll
                 for (int dby = 0; dby < 2; ++dby) {
+                    const int c4 = dbx * 2 + dby;
                     const bool ok = inwin && okx[dbx] && oky[dby];
                     const float w2 = wm * __builtin_fabsf((1.f - dbx) - rbinx) * __builtin_fabsf((1.f - dby) - rbiny);
                     const float w2s = ok ? w2 : 0.f;
-                    float *const b4 = ok ? base + (dbx * 8 + dby * 32) * DESC_PITCH : dummy;
-#pragma unroll
-                    for (int dbt = 0; dbt < 2; ++dbt) {
-                        const int j = dbx * 4 + dby * 2 + dbt;
-                        wt[j] = w2s * __builtin_fabsf((1.f - dbt) - rbint);
-                        loc[j] = b4 + tw[dbt];
-                    }
+                    loc[c4] = (ok ? base + (dbx * 9 + dby * 36) * DESC_PITCH : dummy) + tw;
+                    wt[2 * c4] = w2s * at0;
+                    wt[2 * c4 + 1] = w2s * at1;
                 }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {          // rows of this pass in increasing cy: 16 lanes per group, LDS in order
+            for (int k = 0; k < 4; ++k) {          // rows of this pass in increasing cy: 16 lanes per round, LDS in order
                 if (tyg == k) {
                     float o[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = *loc[j];
+                    for (int c4 = 0; c4 < 4; ++c4) { o[2 * c4] = loc[c4][0]; o[2 * c4 + 1] = loc[c4][DESC_PITCH]; }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) *loc[j] = o[j] + wt[j];
+                    for (int c4 = 0; c4 < 4; ++c4) { loc[c4][0] = o[2 * c4] + wt[2 * c4]; loc[c4][DESC_PITCH] = o[2 * c4 + 1] + wt[2 * c4 + 1]; }
                 }
-                // The four groups are mutually exclusive per THREAD, so the compiler may merge or reorder them; their
+                // The four rounds are mutually exclusive per THREAD, so the compiler may merge or reorder them; their
                 // order only matters across lanes (same word, different rows). A compiler-level memory fence between
-                // the groups pins the program order that the in-order LDS then executes.
+                // the rounds pins the program order that the in-order LDS then executes.
                 asm volatile("" ::: "memory");
             }
         }
@@ -312,15 +334,22 @@ __device__ __forceinline__ void desc_run(const DescSetup &d, float *__restrict__
     }
     __builtin_amdgcn_wave_barrier();
 
-    // lane b owns bins b and b+64: pairwise tree over the 16 partials (strides 1,2,4,8), all in registers
-#pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-        const float4 *row = reinterpret_cast<const float4 *>(part + (lane + 64 * hb) * DESC_PITCH);
-        const float4 a = row[0], b = row[1], c = row[2], d = row[3];
+    // lane b owns descriptor elements b and b + 64 (element = 8 cell + t): pairwise tree over the 16 partials (strides 1, 2,
+    // 4, 8) of its slot row, all in registers; orientation bin 0 also takes the tree of slot 8 (the wrapped votes)
+    auto tree = [&](int row) {
+        const float4 *r4 = reinterpret_cast<const float4 *>(part + row * DESC_PITCH);
+        const float4 a = r4[0], b = r4[1], c = r4[2], d = r4[3];
         const float s01 = a.x + a.y, s23 = a.z + a.w, s45 = b.x + b.y, s67 = b.z + b.w;
         const float s89 = c.x + c.y, sab = c.z + c.w, scd = d.x + d.y, sef = d.z + d.w;
         const float t0 = s01 + s23, t1 = s45 + s67, t2 = s89 + sab, t3 = scd + sef;
-        desc[lane + 64 * hb] = (t0 + t1) + (t2 + t3);
+        return (t0 + t1) + (t2 + t3);
+    };
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+        const int e = lane + 64 * hb, cell = e >> 3, t = e & 7;
+        float v = tree(9 * cell + t);
+        if (t == 0) v = v + tree(9 * cell + 8);
+        desc[e] = v;
     }
 }
 
@@ -450,6 +479,26 @@ __global__ __launch_bounds__(64) void frame_desc_kernel(NmDescribeArgs a)
     }
 }
 
+// Exhaustive self-test of nmfp::expw_fast: every float t in [0, EXPW_TMAX] against the spec sequence.
+// out[0] = inputs whose fast value differs from the spec's although `near` was not reported (must be 0), out[1] = inputs that
+// report `near` (they take the spec sequence in the kernel; ~2^-15 of all), out[2] = inputs tested.
+__global__ __launch_bounds__(256) void selftest_expw_kernel(unsigned long long *out)
+{
+    const uint32_t last = __float_as_uint(nmfp::EXPW_TMAX);
+    unsigned long long bad = 0, nears = 0, n = 0;
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b <= last; b += (uint64_t)gridDim.x * blockDim.x) {
+        const float t = __uint_as_float((uint32_t)b);
+        bool near;
+        const float f = nmfp::expw_fast(t, near);
+        const float e = (float)nmfp::exp_spec_in_range((double)t / 8.0);
+        ++n;
+        if (near) ++nears;
+        else if (__float_as_uint(f) != __float_as_uint(e)) ++bad;
+    }
+    for (int d = 32; d >= 1; d >>= 1) { bad += __shfl_xor(bad, d); nears += __shfl_xor(nears, d); n += __shfl_xor(n, d); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], bad); atomicAdd(&out[1], nears); atomicAdd(&out[2], n); }
+}
+
 }  // namespace
 
 // workgroups (of 4 keypoint-waves) per frame: few enough that a wave walks several keypoints and the prefetch pays
@@ -460,7 +509,13 @@ int nm_launch_frame_describe(const NmDescribeArgs &a, hipStream_t stream)
 {
     if (a.n <= 0 || a.o_end <= a.o_begin) return 0;
     // the small octaves hold a few hundred keypoints at most: a grid sized for octave 0 would be thousands of empty workgroups
-    const int ob = a.o_begin >= 2 ? 64 : NM_ORIENT_BLOCKS, db = a.o_begin >= 2 ? 512 : NM_DESC_BLOCKS;
+    int ob = a.o_begin >= 2 ? 64 : NM_ORIENT_BLOCKS, db = a.o_begin >= 2 ? 512 : NM_DESC_BLOCKS;
+    // (tuning hooks: workgroups per frame of the two launches; a smaller grid leaves wave slots and LDS of every CU to the
+    // other streams' scale-space and detection launches)
+    static const int env_ob = [] { const char *e = getenv("NM_ORIENT_BLOCKS"); return e ? atoi(e) : 0; }();
+    static const int env_db = [] { const char *e = getenv("NM_DESC_BLOCKS"); return e ? atoi(e) : 0; }();
+    if (env_ob > 0 && a.o_begin < 2) ob = max(1, env_ob / a.n);
+    if (env_db > 0 && a.o_begin < 2) db = max(1, env_db / a.n);
     hipLaunchKernelGGL(frame_orient_kernel, dim3(ob, a.n), dim3(256), 0, stream, a);
     NM_LAUNCH_CHECK();
     nm_prof_begin(NM_PROF_DESCRIBE, stream);
@@ -471,6 +526,15 @@ int nm_launch_frame_describe(const NmDescribeArgs &a, hipStream_t stream)
 }
 
 extern "C" {
+
+int nm_selftest_expw(unsigned long long *d_out, void *stream)
+{
+    if (!d_out) return (int)hipErrorInvalidValue;
+    NM_RETURN_IF(hipMemsetAsync(d_out, 0, 3 * sizeof(unsigned long long), nm_stream(stream)));
+    hipLaunchKernelGGL(selftest_expw_kernel, dim3(8192), dim3(256), 0, nm_stream(stream), d_out);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
 
 int nm_detect_orientations(const float *key_pts, const float *grad, int num_pts, int octave_width, int octave_height,
                            float gauss_factor, float xper, float *result, void *stream)

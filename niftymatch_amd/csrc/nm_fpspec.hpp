@@ -43,6 +43,18 @@ __device__ __forceinline__ float div_to_f32(double a, double b, double r)
     if (__builtin_expect(near | tiny, 0)) return (float)(a / b);
     return (float)y;
 }
+// The same for a caller whose lanes all take the division together (a WAVE-UNIFORM branch: no exec-masked block in the
+// caller's instruction stream). Lanes that are not near a boundary get the same float from either expression.
+__device__ __forceinline__ float div_to_f32_wave(double a, double b, double r)
+{
+    const double y = a * r;
+    const unsigned long long u = (unsigned long long)__double_as_longlong(y);
+    const uint32_t ulo = (uint32_t)u, uhi = (uint32_t)(u >> 32);
+    const bool near = ((ulo << 3) - (0x0FFFFFF0u << 3)) <= (0x20u << 3);
+    const bool tiny = ((uhi << 1) - 2u) < (((1023u - 120u) << 21) - 2u);
+    if (__builtin_expect(__any(near | tiny), 0)) return (float)(a / b);
+    return (float)y;
+}
 constexpr float TWO_PI_F = (float)(2 * 3.14159265358979323846);
 
 // atan(ay/ax), ax > 0, ay >= 0: one IEEE division (range chosen by products, see oracle/nmo_math.h)
@@ -166,6 +178,38 @@ __device__ __forceinline__ double exp_spec_in_range(double x)
     double r = p / (q - p);
     r = fma64(2.0, r, 1.0);
     return r * pow2i_d(n);
+}
+
+// ---- (float)exp_spec(t / 8) for a float 0 <= t <= 12.875: the descriptor's window weight on every sample that can vote ----
+// exp_spec_in_range is ~34 binary64 instructions with a division; its result is only used narrowed to binary32. The fast form
+//   t / 8 = n ln 2 + r,  n = rint(t / 8 log2 e) in {0, 1, 2},  |r| <= 0.3466,   y = 2^n (1 + r + r^2/2! + ... + r^10/10!)
+// (the reduction with exp_spec's own two-piece ln 2) is within 2^-41.5 (relative) of exp(t / 8): the Taylor remainder
+// r^11 / 11! e^|r| < 2^-41.6 of the value, the roundings of the reduction, the coefficients and the 11 operations < 2^-49
+// together. exp_spec is within a few 2^-53 of it. Two binary64 values that close narrow to the SAME binary32 unless a binary32
+// rounding boundary (low 29 mantissa bits = 0x10000000) lies between them, which needs the low 29 bits of y within 2^11.5 of
+// that pattern: `near` reports a window of +-2^13 (probability 2^-15 per sample), and the caller then evaluates exp_spec
+// itself. No table, no memory access. Checked against exp_spec for EVERY float of the range by nm_selftest_expw.
+constexpr float EXPW_TMAX = 12.875f;
+__device__ __forceinline__ float expw_fast(float t, bool &near)
+{
+    const double x = (double)t * 0.125;
+    const double nd = __builtin_rint(x * 1.4426950408889634073599);
+    double r = fma64(nd, -6.93145751953125e-1, x);
+    r = fma64(nd, -1.42860682030941723212e-6, r);
+    double p = fma64(r, 1.0 / 3628800.0, 1.0 / 362880.0);
+    p = fma64(p, r, 1.0 / 40320.0);
+    p = fma64(p, r, 1.0 / 5040.0);
+    p = fma64(p, r, 1.0 / 720.0);
+    p = fma64(p, r, 1.0 / 120.0);
+    p = fma64(p, r, 1.0 / 24.0);
+    p = fma64(p, r, 1.0 / 6.0);
+    p = fma64(p, r, 0.5);
+    p = fma64(p, r, 1.0);
+    p = fma64(p, r, 1.0);
+    const double y = __builtin_ldexp(p, (int)nd);
+    const uint32_t ulo = (uint32_t)(unsigned long long)__double_as_longlong(y);
+    near = ((ulo << 3) - ((0x10000000u - 8192u) << 3)) <= (16384u << 3);
+    return (float)y;
 }
 
 __device__ __forceinline__ double exp_spec(double x)

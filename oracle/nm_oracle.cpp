@@ -402,7 +402,11 @@ NMO_API void nmo_compute_sift_descriptors(const float *key_pts, const float *ori
         const float *gptr = grad + 2 * (((long)si * oh + yi) * ow + xi);
         const float angle0 = orients[2 * (size_t)pt];
         const double st0 = (double)nmo_sinf(angle0), ct0 = (double)nmo_cosf(angle0);
-        std::vector<float> part(16 * 128, 0.f);           /* part[tx*128 + (80 + loc)] */
+        /* 16 partial histograms (one per window column modulo 16), each 16 cells x NINE temporal slots: a sample's two
+         * temporal votes go to slots (bint & 7) and (bint & 7) + 1, so slot 8 collects what wraps round to orientation bin 0
+         * (descriptor.cu:136: (bint + dbint) % NBO); it is added to bin 0 after the partials have been combined. The reference
+         * adds with atomicAdd in an undefined order (descriptor.cu:137): this order is the spec (DESIGN.md "fp spec"). */
+        std::vector<float> part(16 * 144, 0.f);           /* part[tx*144 + 9 * cell + slot], cell = (binx+2) + 4 (biny+2) */
         for (int c = 0; c < chunks; ++c)
             for (int q = 0; q < 4; ++q)
                 for (int L = 0; L < 64; ++L) {
@@ -430,16 +434,20 @@ NMO_API void nmo_compute_sift_descriptors(const float *key_pts, const float *ori
                                     biny + dby >= -(NBP / 2) && biny + dby < (NBP / 2)) {
                                     const float wt = win * mod * std::fabs((1.f - dbx) - rbinx) *
                                                      std::fabs((1.f - dby) - rbiny) * std::fabs((1.f - dbt) - rbint);
-                                    const int loc = (binx + dbx) * binxo + (biny + dby) * binyo +
-                                                    ((bint + dbt) * binto) % NBO;
-                                    part[(p & 15) * 128 + 80 + loc] += wt;
+                                    const int cell = (binx + dbx + NBP / 2) + NBP * (biny + dby + NBP / 2);
+                                    part[(p & 15) * 144 + 9 * cell + (bint & (NBO - 1)) + dbt] += wt;
                                 }
                             }
                 }
         for (int stride = 1; stride < 16; stride *= 2)
             for (int i = 0; i < 16; i += 2 * stride)
-                for (int b = 0; b < 128; ++b) part[i * 128 + b] += part[(i + stride) * 128 + b];
-        std::memcpy(desc + 128 * (size_t)pt, part.data(), 128 * sizeof(float));
+                for (int b = 0; b < 144; ++b) part[i * 144 + b] += part[(i + stride) * 144 + b];
+        /* descriptor element (binx + 2) * binxo + (biny + 2) * binyo + t (descriptor.cu:81,136); bin 0 = slot 0 + slot 8 */
+        for (int cell = 0; cell < 16; ++cell)
+            for (int t = 0; t < NBO; ++t) {
+                const int e = (cell & 3) * binxo + (cell >> 2) * binyo + t * binto;
+                desc[128 * (size_t)pt + e] = (t == 0) ? part[9 * cell] + part[9 * cell + 8] : part[9 * cell + t];
+            }
     }
 }
 

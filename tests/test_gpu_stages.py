@@ -57,6 +57,15 @@ def test_fast_sqrt_is_correctly_rounded_everywhere(nm):
     assert nm.selftest_sqrt() == 0
 
 
+def test_descriptor_weight_table_form_equals_the_spec_sequence_everywhere(nm):
+    """The descriptor kernel evaluates (float)exp(t / 8) on voting samples from a 104-entry table and a degree-4 polynomial
+    and falls back to the spec's binary64 sequence when a binary32 rounding boundary is near: every float t in [0, 12.875]."""
+    bad, near, n = nm.selftest_expw()
+    assert bad == 0
+    assert n == int(np.float32(12.875).view(np.uint32)) + 1
+    assert near < n / 2 ** 13            # the fallback stays rare (2^-15 expected)
+
+
 def _octave(oracle, w, h, seed):
     lv0 = H.blurred_frame(seed, w, h, sigma=2.0)
     return oracle.octave_pyramid(lv0, 1920, 1080)
