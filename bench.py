@@ -298,7 +298,7 @@ def roofline_pyramid(B, o0_ms, all_ms, traffic, nodog_ms=None, dogonly_ms=None):
     return out
 
 
-# VALU wave-instructions frame_desc_kernel executes per keypoint (rocprofv3 --pmc SQ_INSTS_VALU over tools/kdesc.py,
+# VALU wave-instructions frame_desc_kernel executes per keypoint (rocprofv3 --pmc SQ_INSTS_VALU over tools/ksite.py,
 # profiles/r03_r_frame_desc_pmc_counters.txt: 455.15 M per 16-frame launch of 194 278 keypoints, ~9.6 executed 64-sample
 # passes x ~243; 2 410 before round 3's instruction-count work); stored, like the HBM traffic
 DESC_VALU_PER_KEYPOINT = 2343.0

@@ -56,7 +56,9 @@ NM_API int nm_fill_u32(void *dst, size_t count, unsigned int pattern, void *stre
 #define NM_PROF_MATCH_TOP2 0
 #define NM_PROF_PYRAMID_O0 1
 #define NM_PROF_DESCRIBE 2      /* frame_desc_kernel inside nm_sift_detect_describe[_batch] (all frames of the call) */
-#define NM_PROF_SITES 3
+#define NM_PROF_ORIENT 3        /* frame_orient_kernel of the same calls */
+#define NM_PROF_DETECT_O0 4     /* detect_stage_kernel of octave 0 of the same calls (per-octave launches, not the tail launch) */
+#define NM_PROF_SITES 5
 NM_API int nm_profile_events(int site, void *start_event, void *stop_event);
 /* The same with a caller-owned list of npairs (start, stop) hipEvent_t pairs, events[2k], events[2k+1], consumed by the
  * k-th launch of the site (a batched call launches the MFMA kernel once per pair; under the two-stage screen, whose coarse

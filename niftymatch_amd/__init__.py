@@ -161,6 +161,8 @@ def _dev(t, dtype=None):
 PROF_MATCH_TOP2 = 0
 PROF_PYRAMID_O0 = 1
 PROF_DESCRIBE = 2
+PROF_ORIENT = 3
+PROF_DETECT_O0 = 4
 
 
 def profile_events(site, start=None, stop=None):

@@ -516,7 +516,9 @@ int nm_launch_frame_describe(const NmDescribeArgs &a, hipStream_t stream)
     static const int env_db = [] { const char *e = getenv("NM_DESC_BLOCKS"); return e ? atoi(e) : 0; }();
     if (env_ob > 0 && a.o_begin < 2) ob = max(1, env_ob / a.n);
     if (env_db > 0 && a.o_begin < 2) db = max(1, env_db / a.n);
+    nm_prof_begin(NM_PROF_ORIENT, stream);
     hipLaunchKernelGGL(frame_orient_kernel, dim3(ob, a.n), dim3(256), 0, stream, a);
+    nm_prof_end(NM_PROF_ORIENT, stream);
     NM_LAUNCH_CHECK();
     nm_prof_begin(NM_PROF_DESCRIBE, stream);
     hipLaunchKernelGGL(frame_desc_kernel, dim3(db, a.n), dim3(64), 0, stream, a);

@@ -26,7 +26,18 @@ struct LevelPlanes {
     __device__ __forceinline__ float u(size_t i) const { return l3[i] - l2[i]; }
 };
 
-// keypoint.cu:108-180. The float/double mix of the reference is kept literally; a*b+c contractions are explicit.
+// keypoint.cu:108-180. The reference mixes float and double; every binary64 detour below is replaced by the binary32
+// expression that returns the SAME float for all inputs (the candidates are refined by a few lanes per wave while the others
+// wait, so the length of this dependent chain is what a detection workgroup's tail costs: 26 % of detect_stage_kernel):
+//   (float)(0.5 (double)d), (float)(0.25 (double)d)   = 0.5f d, 0.25f d: the scaling is exact, one rounding either way (also
+//                                                       when the result is subnormal: both round the same real number);
+//   (float)((double)s - 2.0 (double)c)                = fma(-2, c, s): when the exponents of s and 2 c differ by less than 29
+//                                                       the binary64 difference is exact; beyond, the small operand is below
+//                                                       2^-29 of the large one and both forms return the large one;
+//   (float)((double)c + 0.5 (double)t)                = fma(0.5, t, c), by the same argument;
+//   (double)a >= 1e-10                                <=> a >= 0x1.b7cdfep-34f, the smallest float that is >= 1e-10.
+// The elimination keeps the reference's order, pivot rule and IEEE divisions; its row swaps are selects and its early exits
+// are flags (a rejected candidate runs through divisions by zero whose results are never used).
 template <typename PL>
 __device__ __forceinline__ bool refine_at(const PL &pl, int x, int y, int w, float peak, float edge,
                                           float xper, float sigma0, int num_dogs, int level, float4 &out)
@@ -36,43 +47,49 @@ __device__ __forceinline__ bool refine_at(const PL &pl, int x, int y, int w, flo
 #define D_(dx, dy) pl.d(o + (dy) * w + (dx))
 #define U_(dx, dy) pl.u(o + (dy) * w + (dx))
     const float c = C_(0, 0);
-    const float fx = (float)(0.5 * (double)(C_(1, 0) - C_(-1, 0)));
-    const float fy = (float)(0.5 * (double)(C_(0, 1) - C_(0, -1)));
-    const float fs = (float)(0.5 * (double)(U_(0, 0) - D_(0, 0)));
-    const float fxx = (float)((double)(C_(1, 0) + C_(-1, 0)) - 2.0 * (double)c);
-    const float fyy = (float)((double)(C_(0, 1) + C_(0, -1)) - 2.0 * (double)c);
-    const float fss = (float)((double)(U_(0, 0) + D_(0, 0)) - 2.0 * (double)c);
-    const float fxy = (float)(0.25 * (double)(((C_(1, 1) + C_(-1, -1)) - C_(-1, 1)) - C_(1, -1)));
-    const float fxs = (float)(0.25 * (double)(((U_(1, 0) + D_(-1, 0)) - U_(-1, 0)) - D_(1, 0)));
-    const float fys = (float)(0.25 * (double)(((U_(0, 1) + D_(0, -1)) - U_(0, -1)) - D_(0, 1)));
+    const float cxp = C_(1, 0), cxm = C_(-1, 0), cyp = C_(0, 1), cym = C_(0, -1), u0 = U_(0, 0), d0 = D_(0, 0);
+    const float fx = 0.5f * (cxp - cxm);
+    const float fy = 0.5f * (cyp - cym);
+    const float fs = 0.5f * (u0 - d0);
+    const float fxx = fma32(-2.0f, c, cxp + cxm);
+    const float fyy = fma32(-2.0f, c, cyp + cym);
+    const float fss = fma32(-2.0f, c, u0 + d0);
+    const float fxy = 0.25f * (((C_(1, 1) + C_(-1, -1)) - C_(-1, 1)) - C_(1, -1));
+    const float fxs = 0.25f * (((U_(1, 0) + D_(-1, 0)) - U_(-1, 0)) - D_(1, 0));
+    const float fys = 0.25f * (((U_(0, 1) + D_(0, -1)) - U_(0, -1)) - D_(0, 1));
 #undef C_
 #undef D_
 #undef U_
-    float4 A0 = fxx > 0 ? make_float4(fxx, fxy, fxs, -fx) : make_float4(-fxx, -fxy, -fxs, fx);
-    float4 A1 = fxy > 0 ? make_float4(fxy, fyy, fys, -fy) : make_float4(-fxy, -fyy, -fys, fy);
-    float4 A2 = fxs > 0 ? make_float4(fxs, fys, fss, -fs) : make_float4(-fxs, -fys, -fss, fs);
-    float4 t;
-    const float max_a = __builtin_fmaxf(__builtin_fmaxf(A0.x, A1.x), A2.x);
-    if (!((double)max_a >= 1e-10)) return false;
-    if (max_a == A1.x)      { t = A1; A1 = A0; A0 = t; }
-    else if (max_a == A2.x) { t = A2; A2 = A0; A0 = t; }
+    constexpr float TINY = 0x1.b7cdfep-34f;      // bits 0x2EDBE6FF: the smallest float >= 1e-10
+    auto sel4 = [](bool k, const float4 &a, const float4 &b) { return make_float4(k ? a.x : b.x, k ? a.y : b.y, k ? a.z : b.z, k ? a.w : b.w); };
+    const float4 R0 = fxx > 0 ? make_float4(fxx, fxy, fxs, -fx) : make_float4(-fxx, -fxy, -fxs, fx);
+    const float4 R1 = fxy > 0 ? make_float4(fxy, fyy, fys, -fy) : make_float4(-fxy, -fyy, -fys, fy);
+    const float4 R2 = fxs > 0 ? make_float4(fxs, fys, fss, -fs) : make_float4(-fxs, -fys, -fss, fs);
+    const float max_a = __builtin_fmaxf(__builtin_fmaxf(R0.x, R1.x), R2.x);
+    bool good = max_a >= TINY;
+    const bool p1 = max_a == R1.x, p2 = !p1 && (max_a == R2.x);          // pivot row: 1, else 2, else 0
+    float4 A0 = sel4(p1, R1, sel4(p2, R2, R0));
+    float4 A1 = sel4(p1, R0, R1);
+    float4 A2 = sel4(p2, R0, R2);
     A0.y /= A0.x; A0.z /= A0.x; A0.w /= A0.x;
     A1.y = fma32(-A1.x, A0.y, A1.y); A1.z = fma32(-A1.x, A0.z, A1.z); A1.w = fma32(-A1.x, A0.w, A1.w);
     A2.y = fma32(-A2.x, A0.y, A2.y); A2.z = fma32(-A2.x, A0.z, A2.z); A2.w = fma32(-A2.x, A0.w, A2.w);
-    if (__builtin_fabsf(A2.y) > __builtin_fabsf(A1.y)) { t = A2; A2 = A1; A1 = t; }
-    if (!((double)__builtin_fabsf(A1.y) >= 1e-10)) return false;
-    A1.z /= A1.y; A1.w /= A1.y;
-    A2.z = fma32(-A2.y, A1.z, A2.z); A2.w = fma32(-A2.y, A1.w, A2.w);
-    if (!((double)__builtin_fabsf(A2.z) >= 1e-10)) return false;
-    const float ds = A2.w / A2.z;
-    const float dy = fma32(-ds, A1.z, A1.w);
+    const bool sw = __builtin_fabsf(A2.y) > __builtin_fabsf(A1.y);
+    const float b1y = sw ? A2.y : A1.y, b1z = sw ? A2.z : A1.z, b1w = sw ? A2.w : A1.w;
+    const float b2y = sw ? A1.y : A2.y, b2z = sw ? A1.z : A2.z, b2w = sw ? A1.w : A2.w;
+    good = good && (__builtin_fabsf(b1y) >= TINY);
+    const float e1z = b1z / b1y, e1w = b1w / b1y;
+    const float e2z = fma32(-b2y, e1z, b2z), e2w = fma32(-b2y, e1w, b2w);
+    good = good && (__builtin_fabsf(e2z) >= TINY);
+    const float ds = e2w / e2z;
+    const float dy = fma32(-ds, e1z, e1w);
     const float dx = fma32(-dy, A0.y, fma32(-ds, A0.z, A0.w));
     const float tt = fma32(ds, fs, fma32(dx, fx, dy * fy));
-    const float v = (float)((double)c + 0.5 * (double)tt);
+    const float v = fma32(0.5f, tt, c);
     const float tr = fxx + fyy;
     const float s = (tr * tr) / fma32(fxx, fyy, -(fxy * fxy));
     const float ethr = ((edge + 1) * (edge + 1)) / edge;
-    if ((__builtin_fabsf(v) > peak) && s < ethr && __builtin_fabsf(dx) < 1 && __builtin_fabsf(dy) < 1 &&
+    if (good && (__builtin_fabsf(v) > peak) && s < ethr && __builtin_fabsf(dx) < 1 && __builtin_fabsf(dy) < 1 &&
         __builtin_fabsf(ds) < 1) {
         out.x = ((float)x + dx) * xper;
         out.y = ((float)y + dy) * xper;

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void fill_u32_kernel(unsigned int *__restrict_
 
 }  // namespace
 
-thread_local NmProfSite nm_prof_sites[3] = {{nullptr, nullptr, nullptr, 0, 0}, {nullptr, nullptr, nullptr, 0, 0}, {nullptr, nullptr, nullptr, 0, 0}};
+thread_local NmProfSite nm_prof_sites[NM_PROF_SITES] = {};
 
 struct nm_sift_arena {
     int width, height, capacity;

@@ -291,10 +291,13 @@ int nm_launch_detect_octave(const NmDetectArgs &d, const NmScanArgs &s, const Nm
 {
     if (d.n_blocks <= 0 || d.n <= 0) return 0;
     const dim3 grid(d.nseg * nm_divup(d.oh, DET_ROWS), d.n);
+    const bool prof = s.octave == 0;
+    if (prof) nm_prof_begin(NM_PROF_DETECT_O0, stream);
     if (d.from_levels && d.any_mask) hipLaunchKernelGGL((detect_stage_kernel<false, true, true>), grid, dim3(256), 0, stream, d);
     else if (d.from_levels) hipLaunchKernelGGL((detect_stage_kernel<false, true, false>), grid, dim3(256), 0, stream, d);
     else if (d.any_mask) hipLaunchKernelGGL((detect_stage_kernel<false, false, true>), grid, dim3(256), 0, stream, d);
     else hipLaunchKernelGGL((detect_stage_kernel<false, false, false>), grid, dim3(256), 0, stream, d);
+    if (prof) nm_prof_end(NM_PROF_DETECT_O0, stream);
     NM_LAUNCH_CHECK();
     hipLaunchKernelGGL(scan_book_kernel, dim3(s.n), dim3(1024), 0, stream, s);
     NM_LAUNCH_CHECK();

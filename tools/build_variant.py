@@ -1,20 +1,23 @@
 """Scratch builds for A/B timing: recompile ONE kernel source with extra preprocessor flags and link it with the objects of
 the regular build into niftymatch_amd/lib/variants/libnm_hip_<name>.so (selected at run time with NM_HIP_LIB=<path>).
-    python tools/build_variant.py <name> <source.hip> -DFLAG=1 ...
+    python tools/build_variant.py <name> <source.hip>[,<source2.hip>] -DFLAG=1 ...
 Results of such variants may be wrong by design (pieces compiled out); only their times are read."""
 import os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 from niftymatch_amd import build as B
-name, src = sys.argv[1], sys.argv[2]
+name, srcs = sys.argv[1], sys.argv[2].split(",")
 flags = sys.argv[3:]
 B.build()
 out_dir = os.path.join(B.LIBDIR, "variants")
 os.makedirs(out_dir, exist_ok=True)
-obj = os.path.join(B.BUILD, "variant_%s_%s.o" % (name, os.path.basename(src)))
-subprocess.check_call([B.HIPCC] + B.FLAGS + flags + ["-c", os.path.join(B.CSRC, src), "-o", obj])
+vobjs = []
+for src in srcs:
+    obj = os.path.join(B.BUILD, "variant_%s_%s.o" % (name, os.path.basename(src)))
+    subprocess.check_call([B.HIPCC] + B.FLAGS + flags + ["-c", os.path.join(B.CSRC, src), "-o", obj])
+    vobjs.append(obj)
 objs = [os.path.join(B.BUILD, f) for f in os.listdir(B.BUILD)
-        if f.endswith(".o") and not f.startswith("variant_") and f != os.path.basename(src) + ".o"]
+        if f.endswith(".o") and not f.startswith("variant_") and f not in [os.path.basename(x) + ".o" for x in srcs]]
 lib = os.path.join(out_dir, "libnm_hip_%s.so" % name)
-subprocess.check_call([B.HIPCC, "--offload-arch=" + B.ARCH, "-shared", "-fPIC", "-o", lib, obj] + objs)
+subprocess.check_call([B.HIPCC, "--offload-arch=" + B.ARCH, "-shared", "-fPIC", "-o", lib] + vobjs + objs)
 print(lib)

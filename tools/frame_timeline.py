@@ -21,6 +21,23 @@ if sys.argv[1] == "run":
         for _ in range(5):
             a.detect_describe(f[0])
             s.synchronize()
+elif sys.argv[1] == "runpair":            # one PAIR at batch 1: a 2-frame call + the device-sized match (bench.latency_probe's pair)
+    import time
+    import torch
+    import bench
+    import niftymatch_amd as nm
+    dev = torch.device("cuda:0")
+    f = bench.make_frames(nm, torch, dev, [0, 1])
+    a = [nm.SiftArena(bench.W, bench.H, bench.CAP, device=dev) for _ in range(2)]
+    ws = nm.MatchBatchDevWorkspace(1, bench.CAP, bench.CAP, dev)
+    res = torch.full((bench.CAP,), -1, dtype=torch.int32, device=dev)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(5):
+            nm.detect_describe_batch(a, f)
+            nm.sift_match_batch_dev([a[0].desc], [a[0].num_items], [a[1].desc], [a[1].num_items], [res], 0.8, workspace=ws)
+            s.synchronize()
+            time.sleep(0.002)
 else:
     rows = []
     for fn in glob.glob(sys.argv[2] + "/**/*kernel_trace.csv", recursive=True):

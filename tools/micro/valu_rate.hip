@@ -55,6 +55,23 @@ __global__ __launch_bounds__(1024) void rate_kernel(float *out, int iters, float
                 if (KIND == 24) asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
                 if (KIND == 25) asm volatile("v_floor_f32 %0, %0" : "+v"(a[i]));
                 if (KIND == 26) asm volatile("v_cvt_i32_f32 %0, %1" : "+v"(n[i]) : "v"(a[i]));
+                if (KIND == 27) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+                if (KIND == 28) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+                if (KIND == 29) asm volatile("v_and_b32 %0, %0, %1" : "+v"(n[i]) : "v"(lane));
+                if (KIND == 30) asm volatile("v_or_b32 %0, %0, %1" : "+v"(n[i]) : "v"(lane));
+                if (KIND == 31) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(n[i]) : "v"(lane));
+                if (KIND == 32) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(n[i]));
+                if (KIND == 33) asm volatile("v_mov_b32 %0, %1" : "+v"(n[i]) : "v"(n[(i + 1) & 7]));
+                if (KIND == 34) asm volatile("v_min_u32 %0, %0, %1" : "+v"(n[i]) : "v"(lane));
+                if (KIND == 35) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(n[i]) : "v"(lane));
+                if (KIND == 36) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(m), "v"(c));
+                if (KIND == 37) asm volatile("v_mac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+                if (KIND == 38) asm volatile("v_add_f32 %0, |%0|, %1" : "+v"(a[i]) : "v"(c));
+                if (KIND == 39) asm volatile("v_mul_f32 %0, |%0|, %1" : "+v"(a[i]) : "v"(m));
+                if (KIND == 40) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(n[i]) : "v"(lane) : );
+                if (KIND == 41) asm volatile("v_cmp_lt_i32 vcc, %0, %1" : : "v"(n[i]), "v"(lane) : "vcc");
+                if (KIND == 42) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+                if (KIND == 43) asm volatile("v_subrev_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
             }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -104,5 +121,9 @@ int main()
     run<18>("v_min_i32", out, clk); run<19>("v_fmac_f64", out, clk); run<20>("v_add_f64", out, clk); run<21>("v_pk_add_f32", out, clk);
     run<22>("v_pk_mul_f32", out, clk); run<23>("v_cvt_f32_f64", out, clk); run<24>("v_mov_dpp", out, clk); run<25>("v_floor_f32", out, clk);
     run<26>("v_cvt_i32_f32", out, clk);
+    run<27>("v_min_f32", out, clk); run<28>("v_max_f32", out, clk); run<29>("v_and_b32", out, clk); run<30>("v_or_b32", out, clk);
+    run<31>("v_sub_u32", out, clk); run<32>("v_lshlrev_b32", out, clk); run<33>("v_mov_b32", out, clk); run<34>("v_min_u32", out, clk);
+    run<35>("v_xor_b32", out, clk); run<36>("v_fma_f32 acc", out, clk); run<38>("v_add_f32 |abs|", out, clk); run<39>("v_mul_f32 |abs|", out, clk);
+    run<41>("v_cmp_lt_i32", out, clk); run<42>("v_sub_f32", out, clk);
     return 0;
 }
