@@ -298,11 +298,13 @@ def roofline_pyramid(B, o0_ms, all_ms, traffic, nodog_ms=None, dogonly_ms=None):
     return out
 
 
-# VALU wave-instructions frame_desc_kernel executes per keypoint (rocprofv3 --pmc SQ_INSTS_VALU over tools/ksite.py,
-# profiles/r03_r_frame_desc_pmc_counters.txt: 455.15 M per 16-frame launch of 194 278 keypoints, ~9.6 executed 64-sample
-# passes x ~243; 2 410 before round 3's instruction-count work); stored, like the HBM traffic
-DESC_VALU_PER_KEYPOINT = 2343.0
-VALU_ISSUE_GHZ = 2.4 / 4.0           # a SIMD issues one VALU wave-instruction per 4 cycles (fp32, fp64 and packed alike)
+# VALU / LDS wave-instructions frame_desc_kernel executes per keypoint (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS over
+# tools/ksite.py, profiles/r04_m_frame_kernels_pmc_counters.txt: 428.43 M / 64.93 M per 16-frame launch of 194 278
+# keypoints; round 3: 455.15 M / 123.25 M, profiles/r03_r_*); stored, like the HBM traffic
+DESC_VALU_PER_KEYPOINT = 2205.2
+DESC_LDS_PER_KEYPOINT = 334.2
+VALU_ISSUE_GHZ = 2.4 / 4.0           # a SIMD issues one VALU wave-instruction per ~4 cycles (tools/micro/valu_rate.hip: 4.25 for
+                                     # everything but fp32 fma/add/mul, integer add/sub and the bitwise ops, which take 2.5)
 
 
 def roofline_describe(B, ms, keypoints, n_cu):
@@ -315,8 +317,10 @@ def roofline_describe(B, ms, keypoints, n_cu):
     return {"kernel": "frame_desc_kernel, %d frames per launch" % B, "bound": "valu_issue", "achieved": round(ach, 1),
             "peak": round(peak, 1), "unit": "G wave-instructions/s", "frac": round(ach / peak, 4), "avg_ms": round(ms, 4),
             "us_per_frame": round(1e3 * ms / B, 2), "keypoints": int(keypoints),
-            "valu_instructions_per_keypoint": DESC_VALU_PER_KEYPOINT,
-            "note": "instruction count from the rocprofv3 PMC pass in profiles/ (stored, not live); duration live"}
+            "valu_instructions_per_keypoint": DESC_VALU_PER_KEYPOINT, "lds_instructions_per_keypoint": DESC_LDS_PER_KEYPOINT,
+            "note": "instruction counts from the rocprofv3 PMC pass in profiles/ (stored, not live); duration live. The votes' "
+                    "LDS instructions bound the kernel beside the VALU issue rate (round 4: halving them took 10 % off the "
+                    "kernel where 10 % fewer VALU instructions took nothing)"}
 
 
 def launcher_command(gpus, argv, environ):
