@@ -226,10 +226,10 @@ __device__ __forceinline__ void desc_run(const DescSetup &d, float *__restrict__
 
     {   // zero the wave's partial histograms with 16-byte stores
         float4 *z = reinterpret_cast<float4 *>(part);
-        static_assert(DESC_LDS / 4 == 9 * 64 + 36, "zeroing pattern");
+        // (the landing rows behind the histogram only ever take +0 and are never read: they are not zeroed)
+        static_assert(DESC_DUMMY / 4 == 9 * 64, "zeroing pattern");
 #pragma unroll
         for (int i = 0; i < 9; ++i) z[i * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lane < 36) z[9 * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float *mine = part + 90 * DESC_PITCH + tx;    // origin at the centre cell (descriptor.cu:81: cell (2, 2) = row 9 * 10), partial tx
     // Per-lane constants of the sample grid. A lane's samples are (column tx of chunk c, row 4 q + tyg of chunk c):
@@ -314,8 +314,11 @@ __device__ __forceinline__ void desc_run(const DescSetup &d, float *__restrict__
                     wt[2 * c4] = w2s * at0;
                     wt[2 * c4 + 1] = w2s * at1;
                 }
+            // rounds none of whose 16 samples has a vote inside the grid are skipped (their votes are all +0 into the landing words)
+            const unsigned long long voters = __ballot(inwin && (okx[0] || okx[1]) && (oky[0] || oky[1]));
 #pragma unroll
             for (int k = 0; k < 4; ++k) {          // rows of this pass in increasing cy: 16 lanes per round, LDS in order
+                if (!((voters >> (16 * k)) & 0xFFFFull)) continue;
                 if (tyg == k) {
                     float o[8];
 #pragma unroll
