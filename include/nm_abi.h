@@ -426,7 +426,7 @@ NM_API int nm_sift_detect_describe(nm_sift_arena *arena, const float *gray, floa
  * then s3 -> s2 -> s1) crashes the capturing process inside hipStreamEndCapture / instantiate; s1 -> s2, s1 -> s3 or
  * s1 -> s2 -> s3 with s2 -> s1 and s3 -> s1 are safe (tools/capture_shapes.py reproduces both). The same holds for
  * nm_sift_match_batch[_dev]_f32, which run on `stream` alone.                                                           */
-#define NM_SIFT_MAX_BATCH 16
+#define NM_SIFT_MAX_BATCH 64
 NM_API int nm_sift_detect_describe_batch(nm_sift_arena *const *arenas, int n, const float *const *gray,
                                          float *const *desc, float *const *x, float *const *y, float *const *kpts,
                                          float *const *orients, int *const *d_num_items, void *stream);

@@ -638,7 +638,7 @@ def ransac(model, sx, sy, dx, dy, rand_list, thr):
     return pos, Hb, H_all, inl
 
 
-SIFT_MAX_BATCH = 16
+SIFT_MAX_BATCH = 64
 
 
 def detect_describe_batch(arenas, grays):

@@ -60,7 +60,7 @@ int nm_launch_convolve(float *result, const float *image, float *buffer, float *
 // The same Gaussian launch over up to NM_MAX_BATCH equally sized frames (one grid; the frame index is the slow part of
 // blockIdx.x): 1080p octave 0 is only ~4 workgroups per CU, a frame pair or quad fills the chip and amortises the
 // launch / drain phases that bound a single frame.
-#define NM_MAX_BATCH 16
+#define NM_MAX_BATCH 64
 struct NmConvBatch {
     float *result[NM_MAX_BATCH];
     const float *image[NM_MAX_BATCH];

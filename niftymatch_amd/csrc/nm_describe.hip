@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void frame_orient_kernel(NmDescribeArgs a)
     OriSamples cur, nxt;
     auto fetch = [&](int p, OriSamples &o) {
         const int oc = octave_of(book, a.num_octaves, p);
-        orient_fetch(kpts[p], reinterpret_cast<const float2 *>(a.grad[frame][oc]), a.geom[oc].ow, a.geom[oc].oh, 1.5f,
+        orient_fetch(kpts[p], reinterpret_cast<const float2 *>(a.grad0[frame] + a.grad_off[oc]), a.geom[oc].ow, a.geom[oc].oh, 1.5f,
                      a.geom[oc].xper, o);
     };
     if (pt < n) fetch(pt, cur);
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(64) void frame_desc_kernel(NmDescribeArgs a)
     const float2 *orients = reinterpret_cast<const float2 *>(a.orients[frame]);
     for (int pt = book->oct_base[a.o_begin] + blockIdx.x; pt < n; pt += gridDim.x) {
         const int o = octave_of(book, a.num_octaves, pt);
-        describe_wave(kpts[pt], orients[pt].x, reinterpret_cast<const float2 *>(a.grad[frame][o]), a.geom[o].ow,
+        describe_wave(kpts[pt], orients[pt].x, reinterpret_cast<const float2 *>(a.grad0[frame] + a.grad_off[o]), a.geom[o].ow,
                       a.geom[o].oh, a.num_dogs, a.geom[o].xper, a.desc[frame] + (size_t)pt * 128, a.x[frame] + pt,
                       a.y[frame] + pt, part);
     }

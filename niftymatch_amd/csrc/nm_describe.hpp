@@ -11,7 +11,10 @@ struct NmOctGeom {
 struct NmDescribeArgs {
     int n;                                       // frames
     NmOctGeom geom[20];
-    const float *grad[NM_MAX_BATCH][20];         // float2 planes of gradient levels 0..2 of octave o, stride ow*oh
+    const float *grad0[NM_MAX_BATCH];            // per frame: the arena's gradient block; octave o's three float2 planes (gradient
+    size_t grad_off[20];                         // levels 0..2, stride ow*oh) start grad_off[o] floats into it (64 x 20 pointers
+                                                 // do not fit the 4 KB of kernel arguments; a table in device memory would put a
+                                                 // dependent load in front of every keypoint)
     int num_octaves;
     int num_dogs;
     int o_begin, o_end;                          // this launch covers the keypoints of octaves [o_begin, o_end)

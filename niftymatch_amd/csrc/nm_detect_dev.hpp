@@ -143,9 +143,9 @@ struct DetectSmem {
 // What one unit group needs of one frame's octave (filled from NmDetectArgs by the launch wrapper, or from the tail
 // kernel's per-frame tables).
 struct DetectView {
-    const float *const *planes;     // LEV: Gaussian levels 0..5, else DoG planes 0..4: a pointer INTO THE KERNEL ARGUMENTS (the
-                                    // refinement indexes it with a run-time level: a copy in the view would live in scratch memory,
-                                    // which cost detect_stage_kernel 12 % when the body was first factored out)
+    const float *pl[6];             // LEV: Gaussian levels 0..5, else DoG planes 0..4 (pl[5] unused). Only ever indexed with
+                                    // compile-time constants (the refinement SELECTS its planes by the candidate's level): a
+                                    // run-time index would send this copy to scratch memory
     float *staging;                 // 3 x stage_stride float4
     size_t stage_stride;
     int *counts;                    // 3 x n_blocks
@@ -171,7 +171,9 @@ __device__ __forceinline__ void detect_stage_body(const DetectView &a, int blk, 
     DetectSmem &sm = sm_all[(NQ > 1) ? (threadIdx.x >> 8) : 0];
     auto &s_x = sm.s_x; auto &s_cnt = sm.s_cnt; auto &s_acc = sm.s_acc; auto &s_last = sm.s_last; auto &s_wtot = sm.s_wtot;
     auto &s_pref = sm.s_pref;
-    const float *const *dog = a.planes;                    // LEV: the six Gaussian levels, else the five DoG planes
+    const float *pl[6];                                    // LEV: the six Gaussian levels, else the five DoG planes
+#pragma unroll
+    for (int p = 0; p < 6; ++p) pl[p] = a.pl[p];
     const int seg = blk % a.nseg, yg = blk / a.nseg;
     const int y0 = yg * DET_ROWS;
     const int x = seg * 256 + tid;
@@ -195,7 +197,7 @@ __device__ __forceinline__ void detect_stage_body(const DetectView &a, int blk, 
             float lm[6], le[6];
 #pragma unroll
             for (int p = 0; p < 6; ++p) {
-                const float *row = dog[p] + (size_t)yr * ow;
+                const float *row = pl[p] + (size_t)yr * ow;
                 lm[p] = row[xc];
                 le[p] = 0.f;
                 if (edge_lane) le[p] = row[xe];
@@ -206,7 +208,7 @@ __device__ __forceinline__ void detect_stage_body(const DetectView &a, int blk, 
         }
 #pragma unroll
         for (int p = 0; p < 5; ++p) {
-            const float *row = dog[p] + (size_t)yr * ow;
+            const float *row = pl[p] + (size_t)yr * ow;
             raw_mid[buf][p] = row[xc];
             raw_ev[buf][p] = 0.f;
             if (edge_lane) raw_ev[buf][p] = row[xe];
@@ -301,11 +303,14 @@ __device__ __forceinline__ void detect_stage_body(const DetectView &a, int blk, 
             lvl = g - 3 * jr;
             px = seg * 256 + w * 64 + s_x[jr][lvl][w][c - s_cnt[lo]];
             py = y0 + jr;
+            // the candidate's planes: selected from the copies above (lvl is 0, 1 or 2) -- a table lookup with a run-time
+            // index would be one more dependent memory access at the head of the refinement's chain
+            auto plane = [&](int k) { return lvl == 0 ? pl[k] : (lvl == 1 ? pl[k + 1] : pl[k + 2]); };
             if (LEV)
-                acc = refine_at(LevelPlanes{dog[lvl], dog[lvl + 1], dog[lvl + 2], dog[lvl + 3]}, px, py, ow, a.peak, a.edge, a.xper,
+                acc = refine_at(LevelPlanes{plane(0), plane(1), plane(2), plane(3)}, px, py, ow, a.peak, a.edge, a.xper,
                                 a.sigma0, a.num_dogs, lvl, kp);
             else
-                acc = refine(dog[lvl + 1], dog[lvl], dog[lvl + 2], px, py, ow, a.peak, a.edge, a.xper, a.sigma0, a.num_dogs, lvl, kp);
+                acc = refine(plane(1), plane(0), plane(2), px, py, ow, a.peak, a.edge, a.xper, a.sigma0, a.num_dogs, lvl, kp);
         }
         if (DENSE) {
             if (c < total) reinterpret_cast<float4 *>(a.dense[lvl])[(size_t)py * ow + px] = kp;    // kp stays -1 when rejected

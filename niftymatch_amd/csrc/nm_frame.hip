@@ -44,6 +44,8 @@ struct nm_sift_arena {
     hipStream_t desc;          // orientation + descriptors of the large octaves, beside the small octaves' pyramids / detection
     hipEvent_t ev_pyr[20], ev_join, ev_det, ev_det0, ev_desc;
     float *grad[20];           // per octave: 3 float2 planes
+    size_t grad_off[20];       // grad[o] = grad[0] + grad_off[o]: the gradient planes of all octaves are one block
+    size_t plane_stride[20];   // floats between consecutive levels / DoG planes of an octave (one block per octave)
     float *staging; size_t stage_stride;
     int *counts, *offsets; int max_blocks;
     NmFrameBook *book;
@@ -164,16 +166,30 @@ int nm_sift_arena_create(int width, int height, int capacity, nm_sift_arena **ou
     };
     rc = upload(P._base_smooth, &a->taps_base, &a->base_radius);
     for (size_t i = 0; !rc && i < P._sigmas.size(); ++i) rc = upload(P._sigmas[i], &a->taps[i], &a->radii[i]);
-    for (int i = 0; !rc && i < 6; ++i) rc = a->alloc(&a->level[i], a->npix);
-    for (int i = 0; i < 6; ++i) a->lev[0][i] = a->level[i];
-    for (int o = 1; !rc && o < P._num_octaves; ++o)
-        for (int i = 0; !rc && i < 6; ++i) rc = a->alloc(&a->lev[o][i], (size_t)(width >> o) * (height >> o));
+    // an octave's six levels (and its five DoG planes) are ONE block, plane p at p * plane_stride[o]: the detection launches then
+    // take one pointer per frame (NmDetectArgs). The stride is the plane rounded up to 4 floats: every plane 16-byte aligned.
     for (int o = 0; !rc && o < P._num_octaves; ++o) {
         const size_t plane = (size_t)(width >> o) * (height >> o);
-        for (int i = 0; !rc && i < 5; ++i) rc = a->alloc(&a->dog[o][i], plane);
-        if (!rc) rc = a->alloc(&a->grad[o], 6 * plane);
-        if (!rc) rc = (int)hipEventCreateWithFlags(&a->ev_pyr[o], hipEventDisableTiming);
+        a->plane_stride[o] = (plane + 3) & ~(size_t)3;
+        float *blk = nullptr;
+        rc = a->alloc(&blk, 6 * a->plane_stride[o]);
+        for (int i = 0; i < 6; ++i) a->lev[o][i] = blk + i * a->plane_stride[o];
+        if (!rc) rc = a->alloc(&blk, 5 * a->plane_stride[o]);
+        for (int i = 0; i < 5; ++i) a->dog[o][i] = blk + i * a->plane_stride[o];
     }
+    for (int i = 0; i < 6; ++i) a->level[i] = a->lev[0][i];
+    {   // the gradient planes of all octaves: one block (NmDescribeArgs takes one pointer per frame and the offsets)
+        size_t total = 0;
+        for (int o = 0; o < 20; ++o) a->grad_off[o] = 0;
+        for (int o = 0; o < P._num_octaves; ++o) {
+            a->grad_off[o] = total;
+            total += (6 * (size_t)(width >> o) * (height >> o) + 3) & ~(size_t)3;
+        }
+        float *blk = nullptr;
+        if (!rc) rc = a->alloc(&blk, total);
+        for (int o = 0; o < P._num_octaves; ++o) a->grad[o] = blk + a->grad_off[o];
+    }
+    for (int o = 0; !rc && o < P._num_octaves; ++o) rc = (int)hipEventCreateWithFlags(&a->ev_pyr[o], hipEventDisableTiming);
     if (!rc) rc = (int)hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming);
     if (!rc) rc = (int)hipEventCreateWithFlags(&a->ev_det, hipEventDisableTiming);
     if (!rc) rc = (int)hipEventCreateWithFlags(&a->ev_det0, hipEventDisableTiming);
@@ -409,6 +425,7 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
     if (rc) return rc;
 
     NmDescribeArgs da{};
+    for (int o = 0; o < 20; ++o) da.grad_off[o] = as[0]->grad_off[o];      // same geometry => same offsets in every arena
     float *kp[NM_MAX_BATCH];
     da.n = n; da.num_octaves = P._num_octaves; da.num_dogs = P._num_dog_levels;
     for (int f = 0; f < n; ++f) {
@@ -462,7 +479,7 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
             const int ow = W >> o, oh = H >> o;
             const float xper = (float)std::pow(2.0, o);
             if (o >= first_tail) {                 // the tail launch below covers this octave; the describe pass needs its geometry
-                for (int f = 0; f < n; ++f) da.grad[f][o] = as[f]->grad[o];
+                for (int f = 0; f < n; ++f) da.grad0[f] = as[f]->grad[0];
                 da.geom[o].ow = ow; da.geom[o].oh = oh; da.geom[o].xper = xper;
                 continue;
             }
@@ -489,21 +506,21 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
             d.sigma0 = P._sigma_0; d.num_dogs = P._num_dog_levels; d.stage_stride = as[0]->stage_stride;
             d.n_blocks = n_blocks; d.nseg = nseg;
             d.from_levels = dogs ? 0 : 1;
+            d.plane_stride = as[0]->plane_stride[o];
             d.mask_w = W; d.mask_h = H;
             s.n_blocks = n_blocks; s.octave = o;
             g.stage_stride = as[0]->stage_stride; g.n_blocks = n_blocks; g.octave = o;
             s.capacity = as[0]->capacity; g.capacity = as[0]->capacity;
             for (int f = 0; f < n; ++f) {
                 nm_sift_arena *a = as[f];
-                for (int i = 0; i < 5; ++i) d.dog[f][i] = a->dog[o][i];
-                for (int i = 0; i < 6; ++i) d.lev[f][i] = a->lev[o][i];
+                d.plane0[f] = dogs ? a->dog[o][0] : a->lev[o][0];
                 d.staging[f] = a->staging; d.counts[f] = a->counts;
                 d.masks[f] = a->mask; d.any_mask |= a->mask ? 1 : 0;
                 s.counts[f] = a->counts; s.offsets[f] = a->offsets; s.book[f] = a->book;
                 s.d_num_items[f] = d_num_items ? d_num_items[f] : nullptr;
                 g.staging[f] = a->staging; g.counts[f] = a->counts; g.offsets[f] = a->offsets; g.book[f] = a->book;
                 g.kpts[f] = kp[f];
-                da.grad[f][o] = a->grad[o];
+                da.grad0[f] = a->grad[0];
             }
             e = nm_launch_detect_octave(d, s, g, side);
             if (e) return e;

@@ -229,7 +229,8 @@ __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
     __shared__ DetectSmem sm;
     const int frame = blockIdx.y;
     DetectView v;
-    v.planes = LEV ? a.lev[frame] : a.dog[frame];
+#pragma unroll
+    for (int p = 0; p < 6; ++p) v.pl[p] = a.plane0[frame] ? a.plane0[frame] + p * a.plane_stride : a.api_planes[p];
     v.staging = a.staging[frame]; v.stage_stride = a.stage_stride; v.counts = a.counts[frame];
     v.dense = a.dense;
     v.mask = MASKED ? (DENSE ? a.mask : a.masks[frame]) : nullptr; v.mask_w = a.mask_w; v.mask_h = a.mask_h;
@@ -344,7 +345,7 @@ int nm_find_keypoints3_compact_f32(const float *const dog[5], int width, int hei
     d.n = s.n = g.n = 1;
     d.ow = width; d.oh = height; d.peak = peak_threshold; d.edge = edge_threshold; d.xper = xper; d.sigma0 = sigma_0;
     d.num_dogs = num_dogs; d.stage_stride = stage_stride; d.n_blocks = n_blocks; d.nseg = nseg;
-    for (int i = 0; i < 5; ++i) { if (!dog[i]) return (int)hipErrorInvalidValue; d.dog[0][i] = dog[i]; }
+    for (int i = 0; i < 5; ++i) { if (!dog[i]) return (int)hipErrorInvalidValue; d.api_planes[i] = dog[i]; }
     d.staging[0] = staging; d.counts[0] = counts;
     s.counts[0] = counts; s.offsets[0] = offsets; s.book[0] = book; s.n_blocks = n_blocks; s.octave = 0; s.capacity = capacity;
     g.staging[0] = staging; g.counts[0] = counts; g.offsets[0] = offsets; g.book[0] = book; g.kpts[0] = out;
@@ -390,7 +391,7 @@ int nm_find_keypoints3_f32(const float *const dog[5], const float *mask, int mas
     d.n = 1; d.ow = width; d.oh = height; d.peak = peak_threshold; d.edge = edge_threshold; d.xper = xper;
     d.sigma0 = sigma_0; d.num_dogs = num_dogs;
     d.nseg = nm_divup(width, 256); d.n_blocks = height * d.nseg;
-    for (int i = 0; i < 5; ++i) { if (!dog[i]) return (int)hipErrorInvalidValue; d.dog[0][i] = dog[i]; }
+    for (int i = 0; i < 5; ++i) { if (!dog[i]) return (int)hipErrorInvalidValue; d.api_planes[i] = dog[i]; }
     for (int l = 0; l < 3; ++l) { if (!result[l]) return (int)hipErrorInvalidValue; d.dense[l] = result[l]; }
     d.mask = mask; d.mask_w = mask_width; d.mask_h = mask_height;
     hipLaunchKernelGGL(detect_stage_kernel<true>, dim3(d.nseg * nm_divup(height, DET_ROWS), 1), dim3(256), 0,

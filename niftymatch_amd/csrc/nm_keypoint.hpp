@@ -5,9 +5,15 @@
 // Per-frame pointers are arrays over the frames of a batched call (NM_MAX_BATCH); blockIdx selects the frame.
 struct NmDetectArgs {
     int n;                                  // frames
-    const float *dog[NM_MAX_BATCH][5];      // DoG planes 0..4 of the octave
-    const float *lev[NM_MAX_BATCH][6];      // from_levels: the octave's Gaussian levels 0..5 instead -- DoG i = lev[i + 1] - lev[i]
-    int from_levels;                        // is formed on the fly (the same fp32 subtraction the pyramid kernel stores)
+    // The planes a frame's detection reads: the octave's DoG planes 0..4, or -- from_levels -- its Gaussian levels 0..5 (DoG i =
+    // lev[i + 1] - lev[i] is then formed on the fly, the same fp32 subtraction the pyramid kernel stores). 64 x 11 pointers do
+    // not fit the 4 KB of kernel arguments, and a pointer table in device memory puts a dependent load at the head of every
+    // workgroup (measured: +30 % on the kernel): the frame driver passes ONE pointer per frame and a stride. API path (one
+    // frame, caller's planes): plane0[0] = NULL and the pointers travel in api_planes.
+    const float *plane0[NM_MAX_BATCH];      // frame driver: the frame's plane 0; plane p = plane0 + p * plane_stride (the arena
+    size_t plane_stride;                    // allocates an octave's levels / DoG planes as one block)
+    const float *api_planes[6];
+    int from_levels;
     int ow, oh;
     float peak, edge, xper, sigma0;
     int num_dogs;

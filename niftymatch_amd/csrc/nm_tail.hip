@@ -412,7 +412,8 @@ __device__ __forceinline__ void detect_item(const NmTailArgs &a, const NmTailOct
     const bool active = want < groups;
     const int blk = active ? want : groups - 1;
     nmdet::DetectView v;
-    v.planes = fr.lev[slot];
+#pragma unroll
+    for (int p = 0; p < 6; ++p) v.pl[p] = fr.lev[slot][p];
     v.staging = fr.staging[slot]; v.stage_stride = fr.stage_stride[slot]; v.counts = fr.counts[slot];
     v.dense = nullptr;
     v.mask = MASKED ? a.masks[f] : nullptr; v.mask_w = a.mask_w; v.mask_h = a.mask_h;

@@ -1,5 +1,6 @@
-"""Parity on EXACTLY what bench.py times (BASELINE configs[2] / configs[3]): 16-frame 1080p nm_sift_detect_describe_batch
-calls (16 pointers per kernarg block, blockIdx.y = 16 detect grids) and 16-pair nm_sift_match_batch_f32 calls on the
+"""Parity on what bench.py times (BASELINE configs[2] / configs[3]): many-frame 1080p nm_sift_detect_describe_batch calls (16
+frames per call here; the bench's own 64-frame calls -- 64 pointers per kernarg block, blockIdx.y = 64 detect grids -- in
+test_detect_256_loop_of_the_bench) and 16-pair nm_sift_match_batch_f32 calls on the
 real, un-normalised ~12k x ~12k SIFT descriptors of those frames (the MFMA selector + margin logic on real data).
 Reference semantics: sift/siftfunctions.cu:100-181 (detect/describe orchestration), kernels/match.cu:83-117 (scan)."""
 import numpy as np
@@ -146,7 +147,8 @@ def test_match_batch_dev_16_pairs_on_real_descriptors(nm, oracle, cuda, bench16)
 
 def test_detect_256_loop_of_the_bench(nm, oracle, cuda):
     """BASELINE configs[3] exactly as bench.detect_256 runs it (sift/siftfunctions.cu:100-181 per frame): 256 distinct 1080p
-    frames in sixteen 16-frame calls over 4 streams, each stream re-using its 16 arenas four times per pass, several passes.
+    frames in four 64-frame calls (bench.py's default call size since round 4: NM_SIFT_MAX_BATCH frames per launch sequence)
+    re-using the same 64 arenas four times per pass, several passes.
     The first, a middle and the last frame against the oracle (every output, bit for bit); all 256 keypoint counts and
     descriptor checksums against single-frame calls."""
     import torch
@@ -168,7 +170,8 @@ def test_detect_256_loop_of_the_bench(nm, oracle, cuda):
             if b + k in keep:
                 keep[b + k] = (a.kpts.clone(), a.orients.clone(), a.x.clone(), a.y.clone(), a.desc.clone())
 
-    out = bench.detect_256(nm, torch, None, cuda, cuda, 0, 1, arenas, streams, 16, passes=2, frames=frames, after_call=after_call)
+    out = bench.detect_256(nm, torch, None, cuda, cuda, 0, 1, arenas, streams, bench.parse_args([]).batch, passes=2, frames=frames,
+                           after_call=after_call)
     torch.cuda.synchronize()
     assert out["frames_per_s"] > 0 and out["frames_per_s_sustained"] > 0 and len(out["ms_per_pass"]) == 2
     counts = counts.cpu().numpy()
