@@ -28,6 +28,16 @@ def test_library_exports_every_declared_symbol(nm):
     assert set(nm.ABI_SYMBOLS) <= set(declared)
 
 
+def test_batch_limit_is_the_same_in_the_header_and_the_binding(nm):
+    """NM_SIFT_MAX_BATCH (include/nm_abi.h) = niftymatch_amd.SIFT_MAX_BATCH = the kernels' NM_MAX_BATCH: the per-frame pointer
+    arrays of every frame-driver launch are sized by it (static_asserts keep them inside the 4 KB of kernel arguments)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = int(re.search(r"#define NM_SIFT_MAX_BATCH (\d+)", open(os.path.join(root, "include", "nm_abi.h")).read()).group(1))
+    dev = int(re.search(r"#define NM_MAX_BATCH (\d+)", open(os.path.join(root, "niftymatch_amd", "csrc", "nm_common.hpp")).read()).group(1))
+    assert hdr == dev == nm.SIFT_MAX_BATCH == 64
+
+
 def test_integer_helpers(nm):
     lib = nm.lib()            # kernels/cudamath.cu:5-23
     assert [lib.DivUp(5, 2), lib.DivUp(4, 2), lib.DivDown(5, 2)] == [3, 2, 2]
