@@ -71,8 +71,8 @@ NM_API int nm_profile_event_pairs(int site, void *const *events, int npairs);
  * inputs. Must be 0. */
 NM_API int nm_selftest_sqrt(unsigned long long *d_mismatches, void *stream);
 /* Self-test (no reference counterpart): the descriptor's window weight (float)exp((nx^2 + ny^2) / 8) (kernels/descriptor.cu:108)
- * is evaluated on voting samples by a table form whose result is proven equal to the spec's binary64 sequence unless it
- * reports a nearby binary32 rounding boundary (then the spec sequence runs). Every float of the form's domain [0, 12.875] is
+ * is evaluated on voting samples by a division-free form whose result is proven equal to the spec's binary64 sequence unless
+ * it reports a nearby binary32 rounding boundary (then the spec sequence runs). Every float of the form's domain [0, 12.875] is
  * compared. d_out (device, 3 x unsigned long long): [0] unreported differences (must be 0), [1] inputs that report a nearby
  * boundary, [2] inputs tested. */
 NM_API int nm_selftest_expw(unsigned long long *d_out, void *stream);

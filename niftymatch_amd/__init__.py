@@ -528,7 +528,7 @@ def selftest_sqrt():
 
 def selftest_expw():
     """nm_selftest_expw: (unreported differences, inputs reporting a nearby rounding boundary, inputs tested) of the descriptor
-    weight's table form against the spec sequence over its whole domain. The first must be 0."""
+    weight's fast form against the spec sequence over its whole domain. The first must be 0."""
     torch = _torch()
     out = torch.zeros(3, dtype=torch.int64, device="cuda")
     _check(lib().nm_selftest_expw(_dev(out), _stream()), "nm_selftest_expw")

@@ -7,9 +7,11 @@
 //                lane sums its <= 7 votes per bin in increasing cy into a private LDS histogram; lane b then adds
 //                the 63 partials of bin b in strip order.
 //   descriptor : the samples of column tx (0..15) of a 16x16 chunk vote into partial histogram tx in increasing cy
-//                (4 rows per wave pass, issued as 4 exec-masked read-add-write groups in row order: LDS executes a
-//                wave's instructions in order), 8 votes per sample in (dbinx, dbiny, dbint) order; the 16 partials
-//                are combined by a balanced pairwise tree (strides 1,2,4,8) by the lane that owns the bin.
+//                (4 rows per wave pass, issued as 4 exec-masked read-add-write rounds in row order: LDS executes a
+//                wave's instructions in order), 8 votes per sample in (dbinx, dbiny, dbint) order; a partial histogram
+//                has NINE temporal slots per cell (slot 8 = the votes that wrap round to orientation bin 0), so that the two
+//                temporal votes of a sample are one two-word LDS access; the 16 partials of every slot are combined by a
+//                balanced pairwise tree (strides 1,2,4,8) by the lane that owns the bin, bin 0 = tree(slot 0) + tree(slot 8).
 #include <cstdlib>
 #include "nm_common.hpp"
 #include "nm_fpspec.hpp"

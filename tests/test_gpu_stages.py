@@ -57,9 +57,10 @@ def test_fast_sqrt_is_correctly_rounded_everywhere(nm):
     assert nm.selftest_sqrt() == 0
 
 
-def test_descriptor_weight_table_form_equals_the_spec_sequence_everywhere(nm):
-    """The descriptor kernel evaluates (float)exp(t / 8) on voting samples from a 104-entry table and a degree-4 polynomial
-    and falls back to the spec's binary64 sequence when a binary32 rounding boundary is near: every float t in [0, 12.875]."""
+def test_descriptor_weight_fast_form_equals_the_spec_sequence_everywhere(nm):
+    """The descriptor kernel evaluates (float)exp(t / 8) on voting samples by a division-free form (ln 2 reduction + Taylor
+    degree 10) and falls back to the spec's binary64 sequence when a binary32 rounding boundary is near: every float t in
+    [0, 12.875] is compared on the device."""
     bad, near, n = nm.selftest_expw()
     assert bad == 0
     assert n == int(np.float32(12.875).view(np.uint32)) + 1
