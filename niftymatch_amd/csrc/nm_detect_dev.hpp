@@ -182,7 +182,6 @@ __device__ __forceinline__ void detect_stage_body(const DetectView &a, int blk, 
     const bool xin = x < ow;
     const int xc = xin ? x : ow - 1;                       // clamped column for safe addressing
     const int xe = (lane == 0) ? max(xc - 1, 0) : min(xc + 1, ow - 1);
-    const bool edge_lane = (lane == 0) || (lane == 63);
     const float thr = 0.8f * a.peak;
     const float *const mask = MASKED ? a.mask : nullptr;
 
@@ -191,16 +190,25 @@ __device__ __forceinline__ void detect_stage_body(const DetectView &a, int blk, 
     // global-load latency of row y+2 hides behind the tests of row y instead of stalling every iteration.
     float rmax[5][3], rmin[5][3], cmid[5][2], clr_max[5][2], clr_min[5][2];
     float raw_mid[2][5], raw_ev[2][5];
+    // Every lane loads its own column and ONE neighbour column (the left neighbour on lane 0, the right one elsewhere): only the
+    // two edge lanes of a wave use the second value (the DPP shifts below take it where they run off the wave), but a load under
+    // `if (edge_lane)` costs the same instruction slot plus an EXEC save / branch / restore and a zeroing move per load -- 42 of
+    // each per workgroup. The addresses are a uniform row base + a 32-bit lane offset (one scalar-base load form each; the
+    // 64-bit per-lane pointer arithmetic of `row[xc]` was 84 VALU instructions per workgroup).
+    const unsigned xb = 4u * (unsigned)xc, eb = 4u * (unsigned)xe;
+    // (Measured and not kept: raw buffer loads -- plane descriptor, row as the scalar offset -- remove the last 36 address
+    // instructions too and ran 270 against 263 us; loading BOTH neighbour columns instead of shifting by DPP removes 70 DPP
+    // moves and their 52 set-up moves per workgroup and ran 371 us: the kernel has no room for 50 % more load instructions.)
     auto fetch_row = [&](int yy, int buf) {
         const int yr = min(max(yy, 0), oh - 1);
+        const size_t rofs = (size_t)yr * (size_t)ow * 4;      // uniform
         if (LEV) {                              // DoG p = level p + 1 - level p, formed here instead of read
             float lm[6], le[6];
 #pragma unroll
             for (int p = 0; p < 6; ++p) {
-                const float *row = pl[p] + (size_t)yr * ow;
-                lm[p] = row[xc];
-                le[p] = 0.f;
-                if (edge_lane) le[p] = row[xe];
+                const char *row = reinterpret_cast<const char *>(pl[p]) + rofs;
+                lm[p] = *reinterpret_cast<const float *>(row + xb);
+                le[p] = *reinterpret_cast<const float *>(row + eb);
             }
 #pragma unroll
             for (int p = 0; p < 5; ++p) { raw_mid[buf][p] = lm[p + 1] - lm[p]; raw_ev[buf][p] = le[p + 1] - le[p]; }
@@ -208,10 +216,9 @@ __device__ __forceinline__ void detect_stage_body(const DetectView &a, int blk, 
         }
 #pragma unroll
         for (int p = 0; p < 5; ++p) {
-            const float *row = pl[p] + (size_t)yr * ow;
-            raw_mid[buf][p] = row[xc];
-            raw_ev[buf][p] = 0.f;
-            if (edge_lane) raw_ev[buf][p] = row[xe];
+            const char *row = reinterpret_cast<const char *>(pl[p]) + rofs;
+            raw_mid[buf][p] = *reinterpret_cast<const float *>(row + xb);
+            raw_ev[buf][p] = *reinterpret_cast<const float *>(row + eb);
         }
     };
     auto absorb_row = [&](int buf, int slot, int cslot) {
