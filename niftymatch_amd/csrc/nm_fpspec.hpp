@@ -196,13 +196,20 @@ __device__ __forceinline__ float expw_fast(float t, bool &near)
     const double nd = __builtin_rint(x * 1.4426950408889634073599);
     double r = fma64(nd, -6.93145751953125e-1, x);
     r = fma64(nd, -1.42860682030941723212e-6, r);
-    double p = fma64(r, 1.0 / 3628800.0, 1.0 / 362880.0);
-    p = fma64(p, r, 1.0 / 40320.0);
-    p = fma64(p, r, 1.0 / 5040.0);
-    p = fma64(p, r, 1.0 / 720.0);
-    p = fma64(p, r, 1.0 / 120.0);
-    p = fma64(p, r, 1.0 / 24.0);
-    p = fma64(p, r, 1.0 / 6.0);
+    // Horner steps p = fma(p, r, c) with the coefficient as a SCALAR operand (the compiler keeps such constants in vector
+    // registers and copies one into the accumulator ahead of every v_fmac_f64: ten extra moves per sample)
+    auto step = [](double pp, double rr, double c) {
+        double o;
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(pp), "v"(rr), "s"(c));
+        return o;
+    };
+    double p = step(1.0 / 3628800.0, r, 1.0 / 362880.0);
+    p = step(p, r, 1.0 / 40320.0);
+    p = step(p, r, 1.0 / 5040.0);
+    p = step(p, r, 1.0 / 720.0);
+    p = step(p, r, 1.0 / 120.0);
+    p = step(p, r, 1.0 / 24.0);
+    p = step(p, r, 1.0 / 6.0);
     p = fma64(p, r, 0.5);
     p = fma64(p, r, 1.0);
     p = fma64(p, r, 1.0);
