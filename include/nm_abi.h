@@ -398,6 +398,15 @@ NM_API int nm_sift_arena_set_mask(nm_sift_arena *arena, const float *mask, int m
 NM_API int nm_sift_arena_tail_trace(const nm_sift_arena *arena, unsigned long long *out, int max_items, int *segments,
                                     int max_segments);
 NM_API int nm_sift_arena_tail_segments(const nm_sift_arena *arena);
+/* Failure reporting of the octave-tail launch. Every wait inside it is bounded (~2 s); a wait that times out sets a sticky
+ * error word, the remaining work items of THAT launch are drained without working, and the launch leaves its state clean for
+ * the next call. What the caller sees: d_num_items of every frame of that call reads -1 (outputs of that call are invalid;
+ * the device-sized matcher entries treat a negative size as 0), and nm_sift_arena_tail_status -- on the first arena of the
+ * call, whose state words the launch used -- writes *status = 1 (0 after a complete launch; synchronises `stream`). The
+ * call after a failed one is unaffected. nm_sift_arena_tail_inject_error is a TEST HOOK that sets the sticky word as a
+ * timed-out wait would (synchronises the device).                                                                       */
+NM_API int nm_sift_arena_tail_status(const nm_sift_arena *arena, int *status, void *stream);
+NM_API int nm_sift_arena_tail_inject_error(nm_sift_arena *arena);
 /* HOST function: the number of kernel launches one nm_sift_detect_describe[_batch] call of n frames on this arena issues
  * (1080p: 23 for n <= 2, where the octave tail is used; 51 above). */
 NM_API int nm_sift_arena_launches_per_call(const nm_sift_arena *arena, int n);

@@ -9,7 +9,13 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("NM_HIP_LIB") or os.path.join(_HERE, "lib", "libnm_hip.so")     # NM_HIP_LIB: A/B diagnostics only
+LIB_PATH = os.path.join(_HERE, "lib", "libnm_hip.so")
+# A/B diagnostics (tools/build_variant.py builds libraries with pieces compiled out: wrong results by design). A stray
+# NM_HIP_LIB alone must never redirect the product or its tests, so the override also needs NM_DIAGNOSTIC=1.
+if os.environ.get("NM_HIP_LIB"):
+    if os.environ.get("NM_DIAGNOSTIC") != "1":
+        raise RuntimeError("NM_HIP_LIB is set without NM_DIAGNOSTIC=1: refusing to load a diagnostic library build")
+    LIB_PATH = os.environ["NM_HIP_LIB"]
 _lib = None
 
 _F = C.c_float
@@ -88,6 +94,8 @@ _SIGNATURES = {
     "nm_sift_arena_bytes": (_SZ, [_P]),
     "nm_sift_arena_tail_trace": (_I, [_P, _P, _I, _P, _I]),
     "nm_sift_arena_tail_segments": (_I, [_P]),
+    "nm_sift_arena_tail_status": (_I, [_P, _P, _P]),
+    "nm_sift_arena_tail_inject_error": (_I, [_P]),
     "nm_sift_arena_launches_per_call": (_I, [_P, _I]),
     "nm_sift_tail_plan": (_I, [_I, _I, _I, _P, _I, _P]),
     "nm_sift_arena_set_params": (_I, [_P, _F, _F]),
@@ -733,6 +741,15 @@ class SiftArena:
         self._mask = mask
         _check(lib().nm_sift_arena_set_mask(self._h, _dev(mask, torch.float32) if mask is not None else None,
                                             self.width, self.height), "nm_sift_arena_set_mask")
+
+    def tail_status(self):
+        """0 / 1: whether the last octave-tail launch on this arena's state words timed out (synchronises the stream)."""
+        v = C.c_int(0)
+        _check(lib().nm_sift_arena_tail_status(self._h, C.byref(v), _stream()), "nm_sift_arena_tail_status")
+        return v.value
+
+    def tail_inject_error(self):
+        _check(lib().nm_sift_arena_tail_inject_error(self._h), "nm_sift_arena_tail_inject_error")
 
     def octave_pyramid(self, ow, oh):
         _check(lib().nm_sift_octave_pyramid(self._h, ow, oh, _stream()), "nm_sift_octave_pyramid")

@@ -42,7 +42,7 @@ struct nm_sift_arena {
     float *dog[20][5];         // DoG planes PER OCTAVE: detection of octave o overlaps the pyramid of octave o+1
     hipStream_t side;          // detection / compaction stream forked off the caller's stream
     hipStream_t desc;          // orientation + descriptors of the large octaves, beside the small octaves' pyramids / detection
-    hipEvent_t ev_pyr[20], ev_join, ev_det, ev_det0, ev_desc;
+    hipEvent_t ev_pyr[20], ev_join, ev_det, ev_desc;
     float *grad[20];           // per octave: 3 float2 planes
     size_t grad_off[20];       // grad[o] = grad[0] + grad_off[o]: the gradient planes of all octaves are one block
     size_t plane_stride[20];   // floats between consecutive levels / DoG planes of an octave (one block per octave)
@@ -145,7 +145,7 @@ int nm_sift_arena_create(int width, int height, int capacity, nm_sift_arena **ou
     if (!a) return (int)hipErrorOutOfMemory;
     a->width = width; a->height = height; a->capacity = capacity;
     a->side = nullptr; a->ev_join = nullptr;
-    a->desc = nullptr; a->ev_det = nullptr; a->ev_det0 = nullptr; a->ev_desc = nullptr;
+    a->desc = nullptr; a->ev_det = nullptr; a->ev_desc = nullptr;
     a->mask = nullptr;
     a->device = -1;
     (void)hipGetDevice(&a->device);
@@ -192,7 +192,6 @@ int nm_sift_arena_create(int width, int height, int capacity, nm_sift_arena **ou
     for (int o = 0; !rc && o < P._num_octaves; ++o) rc = (int)hipEventCreateWithFlags(&a->ev_pyr[o], hipEventDisableTiming);
     if (!rc) rc = (int)hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming);
     if (!rc) rc = (int)hipEventCreateWithFlags(&a->ev_det, hipEventDisableTiming);
-    if (!rc) rc = (int)hipEventCreateWithFlags(&a->ev_det0, hipEventDisableTiming);
     if (!rc) rc = (int)hipEventCreateWithFlags(&a->ev_desc, hipEventDisableTiming);
     if (!rc) rc = (int)hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking);
     if (!rc) rc = (int)hipStreamCreateWithFlags(&a->desc, hipStreamNonBlocking);
@@ -252,7 +251,6 @@ void nm_sift_arena_destroy(nm_sift_arena *a)
     if (a->side) { (void)hipStreamSynchronize(a->side); (void)hipStreamDestroy(a->side); }
     if (a->desc) { (void)hipStreamSynchronize(a->desc); (void)hipStreamDestroy(a->desc); }
     if (a->ev_det) (void)hipEventDestroy(a->ev_det);
-    if (a->ev_det0) (void)hipEventDestroy(a->ev_det0);
     if (a->ev_desc) (void)hipEventDestroy(a->ev_desc);
     for (int o = 0; o < 20; ++o)
         if (a->ev_pyr[o]) (void)hipEventDestroy(a->ev_pyr[o]);
@@ -276,6 +274,8 @@ int nm_sift_arena_tail_trace(const nm_sift_arena *a, unsigned long long *out, in
         int *r = segments + 5 * i;
         r[0] = g.kind; r[1] = g.slot; r[2] = g.per_frame; r[3] = g.first_per_frame; r[4] = a->tail.oct[g.slot].o;
     }
+    // the trace buffer holds NM_TAIL_MAX_FRAMES * items_per_frame records of 128 bytes: never copy past it
+    max_items = std::min(max_items, NM_TAIL_MAX_FRAMES * a->tail.items_per_frame);
     if (out && a->tail.trace && max_items > 0) {
         // layout of the launch's record: 4 words per item for all n_frames * items_per_frame items, then 12 phase stamps per item
         // (conv items only); max_items must be that product, out holds 16 words per item
@@ -285,6 +285,30 @@ int nm_sift_arena_tail_trace(const nm_sift_arena *a, unsigned long long *out, in
     return a->tail.items_per_frame;
 }
 int nm_sift_arena_tail_segments(const nm_sift_arena *a) { return (a && a->tail_ok) ? a->tail.n_seg : 0; }
+
+// Status of the last octave-tail launch that used this arena's state words (the FIRST arena of a call of <= 2 frames lends
+// them): 0 = complete, 1 = a wait inside the launch hit its spin limit and the octaves >= T of that call's frames were dropped
+// (their d_num_items read -1). Synchronises `stream`. An arena without a tail plan reports 0.
+int nm_sift_arena_tail_status(const nm_sift_arena *a, int *status, void *stream)
+{
+    if (!a || !status) return (int)hipErrorInvalidValue;
+    *status = 0;
+    if (!a->tail_ok) return 0;
+    NM_RETURN_IF(hipStreamSynchronize(nm_stream(stream)));
+    NM_RETURN_IF(hipMemcpy(status, a->tail_state + 3, sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// TEST HOOK: sets the sticky error word of the arena's tail state, as a timed-out wait would, so that the NEXT tail launch on
+// it drains without working (tests/test_gpu_tail.py: the call must report failure and the call after it must be correct).
+int nm_sift_arena_tail_inject_error(nm_sift_arena *a)
+{
+    if (!a || !a->tail_ok) return (int)hipErrorInvalidValue;
+    const int one = 1;
+    NM_RETURN_IF(hipDeviceSynchronize());
+    NM_RETURN_IF(hipMemcpy(a->tail_state + 2, &one, sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+}
 
 // Kernel launches one nm_sift_detect_describe[_batch] call of n frames on this arena issues (HOST function): base blur, five
 // Gaussian launches + detect / scan / gather per octave, orientation + descriptors; with the octave tail (calls of up to
@@ -455,7 +479,10 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
     // and runs at a better efficiency than the tail's LDS-fused tiles (halo recomputed per tile), so those keep them
     // (16 frames per call, MI355X: 160 vs 171 us per frame). NM_FRAME_TAIL_MAX_BATCH moves the threshold.
     bool use_tail = !dogs && !split && n <= tail_max_batch() && n <= NM_TAIL_MAX_FRAMES;
-    for (int f = 0; f < n; ++f) use_tail = use_tail && as[f]->tail_ok;
+    // (the first arena's plan is paired with every arena's own plane table: the plans must be the same plan -- T comes from
+    // NM_FRAME_TAIL at arena creation, so arenas of one geometry CAN differ -- or the call takes the per-octave launches)
+    for (int f = 0; f < n; ++f)
+        use_tail = use_tail && as[f]->tail_ok && as[f]->tail.T == as[0]->tail.T && as[f]->tail.n_oct == as[0]->tail.n_oct;
     const int first_tail = use_tail ? as[0]->tail.T : P._num_octaves;
     // With the tail, the octaves < T (98 % of a frame's keypoints) are described on the description stream as soon as octave
     // T - 1 has been detected, BESIDE the tail launch; the few keypoints of the tail octaves follow behind its scans.

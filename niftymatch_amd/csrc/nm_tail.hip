@@ -309,6 +309,9 @@ __device__ void scan_gather_all(const NmTailArgs &a, const NmTailFrame &fr, int 
     int *s_off = li, *s_tot = li + base_of[NM_TAIL_MAX_OCT];     // s_tot[3 j + l]: total; [32 + ..]: lvl_n; [64 + ..]: lvl_base
     // the book's running count after octave T - 1 (an earlier launch of this stream): requested now, used after the scans
     const int items_before = (tid == 0 && a.oct[0].o != 0) ? fr.book->num_items : 0;
+    // status of the tail launch this scan follows on its stream (state[3], nm_tail.hpp): non-zero = a wait timed out and the
+    // items behind it were drained without working, so the staged lists and counts of the tail octaves are not this frame's
+    const int tail_failed = (tid == 0) ? load_i32_agent(a.state + 3) : 0;
     {   // every octave's counts with ALL of a thread's loads in flight before the first LDS store: this launch is a chain of
         // memory round trips on the critical path of a single-frame call (a loop of load -> store pairs made it eleven of them)
         constexpr int MAXK = 12;
@@ -367,7 +370,7 @@ __device__ void scan_gather_all(const NmTailArgs &a, const NmTailFrame &fr, int 
             b->oct_base[o] = num_items;
             bool live = true;                             // sift/siftfunctions.cu:145,160: an empty level ends the octave
             for (int l = 0; l < 3; ++l) {
-                const int cnt = live ? s_tot[3 * j + l] : 0;
+                const int cnt = (live && !tail_failed) ? s_tot[3 * j + l] : 0;
                 if (cnt == 0) live = false;
                 int n = cnt;
                 if (n + num_items > a.capacity) n = a.capacity - num_items;       // siftfunctions.cu:165-169
@@ -379,7 +382,8 @@ __device__ void scan_gather_all(const NmTailArgs &a, const NmTailFrame &fr, int 
             b->oct_base[o + 1] = num_items;
         }
         b->num_items = num_items;
-        if (a.d_num_items[f]) *a.d_num_items[f] = num_items;
+        // a failed tail launch: the book stays consistent (the tail octaves are empty), the caller's count says -1 = invalid
+        if (a.d_num_items[f]) *a.d_num_items[f] = tail_failed ? -1 : num_items;
         s_tot[96] = num_items - s_tot[64];                // keypoints of the tail octaves (their output slots are contiguous)
     }
     __syncthreads();
@@ -431,13 +435,17 @@ __global__ __launch_bounds__(NT) void tail_kernel(NmTailArgs a)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int &s_ticket = reinterpret_cast<int *>(lds + (a.lds_bytes >> 2))[0];
     int &s_flag = reinterpret_cast<int *>(lds + (a.lds_bytes >> 2))[1];
+    int &s_err = reinterpret_cast<int *>(lds + (a.lds_bytes >> 2))[2];
     int *const state = a.state;
     const int total = a.n * a.items_per_frame;
     __builtin_amdgcn_s_setprio(2);                          // a latency chain beside the other stream's throughput kernels
     for (;;) {
-        if (threadIdx.x == 0) s_ticket = add_i32_agent(state + 0, 1);
+        // the sticky error word is read ONCE per item, by the thread that draws the ticket: every wave of the workgroup then
+        // takes the same branch below (a per-thread load could split the waves between `continue` and an item's barriers)
+        if (threadIdx.x == 0) { s_ticket = add_i32_agent(state + 0, 1); s_err = load_i32_agent(state + 2); }
         __syncthreads();
         const int t = s_ticket;
+        const bool failed = s_err != 0;
         __syncthreads();
         if (t >= total) break;
         const unsigned long long tr0 = a.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -460,7 +468,7 @@ __global__ __launch_bounds__(NT) void tail_kernel(NmTailArgs a)
         }
         if (c0 || c1) {
             if (!wait_counters(c0, t0, c1, t1, state + 2, &s_flag)) continue;      // error: drain the tickets without working
-        } else if (load_i32_agent(state + 2) != 0) {
+        } else if (failed) {
             continue;
         }
         const unsigned long long tr1 = a.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -488,12 +496,18 @@ __global__ __launch_bounds__(NT) void tail_kernel(NmTailArgs a)
             r[1] = tr0; r[2] = tr1; r[3] = __builtin_amdgcn_s_memrealtime();
         }
     }
-    // the last workgroup out leaves the state words zero for the next launch (or replay) on these arenas
+    // the last workgroup out leaves the state words zero for the next launch (or replay) on these arenas -- the sticky error
+    // word included: it moves to state[3], the STATUS of this launch (0 / 1), which the scan launch behind this one turns into
+    // num_items = -1 for every frame of the call and nm_sift_arena_tail_status reports to the host; the next launch starts clean
     if (threadIdx.x == 0) s_flag = (add_i32_agent(state + 1, 1) == (int)gridDim.x - 1) ? 1 : 0;
     __syncthreads();
     if (s_flag) {
         for (int i = NM_TAIL_STATE_HEAD + threadIdx.x; i < NM_TAIL_STATE_INTS; i += NT) store_i32_agent(state + i, 0);
-        if (threadIdx.x == 0) { store_i32_agent(state + 0, 0); store_i32_agent(state + 1, 0); }
+        if (threadIdx.x == 0) {
+            store_i32_agent(state + 3, load_i32_agent(state + 2) != 0 ? 1 : 0);
+            store_i32_agent(state + 2, 0);
+            store_i32_agent(state + 0, 0); store_i32_agent(state + 1, 0);
+        }
     }
 }
 
@@ -558,8 +572,8 @@ bool nm_tail_plan(NmTailArgs &a, int width, int height, int num_octaves, int T, 
     }
     a.scan_lds_bytes += 128 * 4;
     if (a.scan_lds_bytes > 60 * 1024) return false;
-    if (lds > lds_budget) return false;
     a.lds_bytes = (lds + 255) & ~255;
+    if (a.lds_bytes + NM_TAIL_LDS_CTRL > lds_budget) return false;   // the launch asks for the items' scratch + the control words
     // segments in topological order: sorted by the step at which their inputs exist (A of slot j: 3 j + 3, B: 3 j + 5,
     // GRAD: 3 j + 4, DETECT: 3 j + 6); every dependency of a segment has a smaller key
     struct Key { int key, kind, slot, count; } keys[4 * NM_TAIL_MAX_OCT];
@@ -589,18 +603,16 @@ bool nm_tail_plan(NmTailArgs &a, int width, int height, int num_octaves, int T, 
 int nm_launch_tail(const NmTailArgs &a, hipStream_t stream)
 {
     if (a.n <= 0 || a.items_per_frame <= 0) return 0;
-    static int attr_set_for = 0;                            // benign race: every thread sets the same attribute
-    if (attr_set_for < a.lds_bytes) {
-        NM_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void *>(tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         144 * 1024));
-        attr_set_for = 144 * 1024;
-    }
+    // per call, like the matcher's launches: the attribute belongs to the (function, device) pair and a process may drive
+    // several devices; lds_bytes + NM_TAIL_LDS_CTRL is what the launch asks for and what nm_tail_plan budgeted
+    NM_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void *>(tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     a.lds_bytes + NM_TAIL_LDS_CTRL));
     // persistent workgroups: about as many as items can run side by side (the widest segment of a frame is its first), never
     // more than one per CU; a workgroup that waits for a counter still holds its CU's LDS
     const int total = a.n * a.items_per_frame;
     const int widest = a.seg[0].per_frame + (a.n_seg > 1 ? a.seg[1].per_frame / 2 : 0);
     const int grid = std::max(1, std::min(std::min(total, nm_cu_count()), a.n * widest));
-    hipLaunchKernelGGL(tail_kernel, dim3(grid), dim3(NT), a.lds_bytes + 16, stream, a);
+    hipLaunchKernelGGL(tail_kernel, dim3(grid), dim3(NT), a.lds_bytes + NM_TAIL_LDS_CTRL, stream, a);
     NM_LAUNCH_CHECK();
     return 0;
 }

@@ -64,7 +64,10 @@ struct NmTailArgs {
 };
 static_assert(sizeof(NmTailArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
-// state words: [0] ticket, [1] workgroups that have left, [2] sticky error, then per (frame, slot) four counters
+// state words: [0] ticket, [1] workgroups that have left, [2] sticky error of the RUNNING launch (a wait that hit its spin
+// limit; the items behind it are drained without working), [3] status of the LAST COMPLETED launch (the last workgroup out
+// moves [2] there and zeroes [2]), then per (frame, slot) four counters. [0], [1], [2] and the counters are zero between launches.
+#define NM_TAIL_LDS_CTRL 16          // bytes of control words behind the items' LDS scratch (ticket, flag, error)
 #define NM_TAIL_STATE_HEAD 4
 #define NM_TAIL_STATE_INTS (NM_TAIL_STATE_HEAD + NM_TAIL_MAX_FRAMES * NM_TAIL_MAX_OCT * 4)
 

@@ -309,6 +309,47 @@ NMO_API int nmo_compact_keypoints(const float *dense, int num_pixels, float *out
  * 7) votes per bin in increasing cy; a bin is the sum of its 63 strip partials taken in increasing p, starting
  * from the first. Smoothing is the race-free circular 3-tap mean of :181-192. `result` is float2 per keypoint and
  * must be pre-filled with (-1,-1) by the caller (pyramidata.cu:90).                                           */
+/* The raw (unsmoothed) 36-bin histogram of one keypoint in the FIXED ORDER above. Optionally also the ORDER-FREE envelope data
+ * of the same votes: h64[i] = binary64 sum of the float votes of bin i (exact to 1e-16 relative, whatever the order), nv[i] =
+ * their number -- any order the reference's shared-memory atomicAdd may take lies within (nv[i] - 1) u of h64[i]
+ * (tests/test_oracle_order_envelope.py).                                                                          */
+static inline void nmo_orient_raw_hist(const float *kp, const float *grad, int ow, int oh, float gauss_factor, float xper,
+                                       float hist[36], double *h64, int *nv)
+{
+    const int NBINS = 36;
+    const float x = kp[0] / xper, y = kp[1] / xper, s = kp[2] / xper;
+    const int xi = (int)((double)x + 0.5), yi = (int)((double)y + 0.5);
+    const float sigma_w = gauss_factor * s;
+    int W = std::max((int)std::floor(3 * sigma_w), 1);
+    W = std::min(22 / 2 - 1, W);                              /* blockDim (22,22) -> 10 (orientation.cu:29-30) */
+    const long grad_index = ((long)kp[3] * oh + yi) * ow + xi; /* Q10: integer arithmetic */
+    const float *g = grad + 2 * grad_index;
+    float part[63][NBINS];
+    for (int p = 0; p < 63; ++p) for (int i = 0; i < NBINS; ++i) part[p][i] = 0.f;
+    if (h64) for (int i = 0; i < NBINS; ++i) { h64[i] = 0.0; nv[i] = 0; }
+    const int xmin = std::max(-W, -xi), xmax = std::min(W, ow - 1 - xi);
+    const int ymin = std::max(-W, -yi), ymax = std::min(W, oh - 1 - yi);
+    const float denom = (2 * sigma_w) * sigma_w;
+    for (int cy = ymin; cy <= ymax; ++cy)
+        for (int cx = xmin; cx <= xmax; ++cx) {
+            const float dx = (float)(cx + xi) - x, dy = (float)(cy + yi) - y;
+            const float r2 = std::fmaf(dx, dx, dy * dy);
+            if (!((double)r2 < (double)(W * W) + 0.6)) continue;
+            const float wgt = nmo_expf(r2 / denom);                               /* exp(+...) per Q11 */
+            const float *gp = g + 2 * ((long)cy * ow + cx);
+            const float q = (float)((double)(36.0f * gp[1]) / NMO_2PI_D);
+            const int bin = (int)std::floor(q);
+            const float vote = gp[0] * wgt;
+            part[(cx - xmin) + 21 * ((cy - ymin) / 7)][bin % NBINS] += vote;
+            if (h64) { h64[bin % NBINS] += (double)vote; nv[bin % NBINS] += 1; }
+        }
+    for (int i = 0; i < NBINS; ++i) {
+        float h = part[0][i];
+        for (int p = 1; p < 63; ++p) h += part[p][i];
+        hist[i] = h;
+    }
+}
+
 NMO_API void nmo_detect_orientations(const float *key_pts, const float *grad, int num_pts, int ow, int oh,
                                      float gauss_factor, float xper, float *result)
 {
@@ -317,35 +358,8 @@ NMO_API void nmo_detect_orientations(const float *key_pts, const float *grad, in
     for (int pt = 0; pt < num_pts; ++pt) {
         const float *kp = key_pts + 4 * (size_t)pt;
         if (kp[3] < 0) continue;
-        const float x = kp[0] / xper, y = kp[1] / xper, s = kp[2] / xper;
-        const int xi = (int)((double)x + 0.5), yi = (int)((double)y + 0.5);
-        const float sigma_w = gauss_factor * s;
-        int W = std::max((int)std::floor(3 * sigma_w), 1);
-        W = std::min(22 / 2 - 1, W);                              /* blockDim (22,22) -> 10 (orientation.cu:29-30) */
-        const long grad_index = ((long)kp[3] * oh + yi) * ow + xi; /* Q10: integer arithmetic */
-        const float *g = grad + 2 * grad_index;
         float hist[NBINS];
-        float part[63][NBINS];
-        for (int p = 0; p < 63; ++p) for (int i = 0; i < NBINS; ++i) part[p][i] = 0.f;
-        const int xmin = std::max(-W, -xi), xmax = std::min(W, ow - 1 - xi);
-        const int ymin = std::max(-W, -yi), ymax = std::min(W, oh - 1 - yi);
-        const float denom = (2 * sigma_w) * sigma_w;
-        for (int cy = ymin; cy <= ymax; ++cy)
-            for (int cx = xmin; cx <= xmax; ++cx) {
-                const float dx = (float)(cx + xi) - x, dy = (float)(cy + yi) - y;
-                const float r2 = std::fmaf(dx, dx, dy * dy);
-                if (!((double)r2 < (double)(W * W) + 0.6)) continue;
-                const float wgt = nmo_expf(r2 / denom);                               /* exp(+...) per Q11 */
-                const float *gp = g + 2 * ((long)cy * ow + cx);
-                const float q = (float)((double)(36.0f * gp[1]) / NMO_2PI_D);
-                const int bin = (int)std::floor(q);
-                part[(cx - xmin) + 21 * ((cy - ymin) / 7)][bin % NBINS] += gp[0] * wgt;
-            }
-        for (int i = 0; i < NBINS; ++i) {
-            float h = part[0][i];
-            for (int p = 1; p < 63; ++p) h += part[p][i];
-            hist[i] = h;
-        }
+        nmo_orient_raw_hist(kp, grad, ow, oh, gauss_factor, xper, hist, nullptr, nullptr);
         for (int iter = 0; iter < 6; ++iter) {
             float prev = hist[NBINS - 1];
             const float first = hist[0];
@@ -373,6 +387,22 @@ NMO_API void nmo_detect_orientations(const float *key_pts, const float *grad, in
     }
 }
 
+/* Envelope of the orientation histograms (test infrastructure for the summation-order freedom, Q11): per keypoint the raw
+ * 36 bins as the oracle sums them (hist32), the order-free binary64 sums of the same votes (hist64) and the votes per bin. */
+NMO_API void nmo_orientation_envelope(const float *key_pts, const float *grad, int num_pts, int ow, int oh, float gauss_factor,
+                                      float xper, float *hist32, double *hist64, int *nvotes)
+{
+    for (int pt = 0; pt < num_pts; ++pt) {
+        const float *kp = key_pts + 4 * (size_t)pt;
+        if (kp[3] < 0) {
+            for (int i = 0; i < 36; ++i) { hist32[36 * (size_t)pt + i] = 0.f; hist64[36 * (size_t)pt + i] = 0.0; nvotes[36 * (size_t)pt + i] = 0; }
+            continue;
+        }
+        nmo_orient_raw_hist(kp, grad, ow, oh, gauss_factor, xper, hist32 + 36 * (size_t)pt, hist64 + 36 * (size_t)pt,
+                            nvotes + 36 * (size_t)pt);
+    }
+}
+
 /* ---------------------------------------------------------------------------------------------------------- */
 /* descriptors -- kernels/descriptor.cu:32-145, Q12. Only the DIAGONAL 16x16 chunks of the window vote (cx and
  * cy advance together, :142-143); exp(+...) window; no normalisation; first orientation only.
@@ -380,6 +410,30 @@ NMO_API void nmo_detect_orientations(const float *key_pts, const float *grad, in
  * tx = cx - chunk origin (0..15) vote into partial histogram tx in increasing cy, each sample's 8 votes in
  * (dbinx, dbiny, dbint) order; chunks in increasing order. bin = balanced pairwise tree over the 16 partials:
  * stride 1,2,4,8: v[i] += v[i+stride].                                                                      */
+/* One window sample of the descriptor (descriptor.cu:102-117), with the reference's float / double promotions: everything
+ * a vote needs except the 8 trilinear factors. Shared by the fixed-order oracle below and by the order-free envelope.   */
+struct nmo_desc_sample { float mod, win, rbinx, rbiny, rbint; int binx, biny, bint; };
+static inline nmo_desc_sample nmo_desc_sample_at(const float *gptr, int ow, int cx, int cy, int xi, int yi, float x, float y,
+                                                 float angle0, double st0, double ct0, float SBP)
+{
+    nmo_desc_sample r;
+    r.mod = gptr[2 * ((long)cy * ow + cx)];
+    const float ang = gptr[2 * ((long)cy * ow + cx) + 1];
+    const float theta = nmo_mod_2pi_f(ang - angle0);
+    const float dx = (float)(xi + cx) - x, dy = (float)(yi + cy) - y;
+    const float nx = (float)(std::fma(ct0, (double)dx, st0 * (double)dy) / (double)SBP);
+    const float ny = (float)(std::fma(-st0, (double)dx, ct0 * (double)dy) / (double)SBP);
+    const float nt = (float)((double)(8.0f * theta) / NMO_2PI_D);
+    r.win = (float)nmo_exp((double)std::fmaf(nx, nx, ny * ny) / 8.0);
+    r.binx = (int)std::floor((double)nx - 0.5);
+    r.biny = (int)std::floor((double)ny - 0.5);
+    r.bint = (int)std::floor(nt);
+    r.rbinx = (float)((double)nx - ((double)r.binx + 0.5));
+    r.rbiny = (float)((double)ny - ((double)r.biny + 0.5));
+    r.rbint = nt - (float)r.bint;
+    return r;
+}
+
 NMO_API void nmo_compute_sift_descriptors(const float *key_pts, const float *orients, const float *grad,
                                           int num_pts, int ow, int oh, int num_dogs, float xper, float *desc,
                                           float *xp, float *yp)
@@ -413,20 +467,9 @@ NMO_API void nmo_compute_sift_descriptors(const float *key_pts, const float *ori
                     const int p = 64 * q + L;
                     const int cx = (p & 15) + xmin + 16 * c, cy = (p >> 4) + ymin + 16 * c;
                     if (!(cx <= xmax && cy <= ymax)) continue;
-                    const float mod = gptr[2 * ((long)cy * ow + cx)];
-                    const float ang = gptr[2 * ((long)cy * ow + cx) + 1];
-                    const float theta = nmo_mod_2pi_f(ang - angle0);
-                    const float dx = (float)(xi + cx) - x, dy = (float)(yi + cy) - y;
-                    const float nx = (float)(std::fma(ct0, (double)dx, st0 * (double)dy) / (double)SBP);
-                    const float ny = (float)(std::fma(-st0, (double)dx, ct0 * (double)dy) / (double)SBP);
-                    const float nt = (float)((double)(8.0f * theta) / NMO_2PI_D);
-                    const float win = (float)nmo_exp((double)std::fmaf(nx, nx, ny * ny) / 8.0);
-                    const int binx = (int)std::floor((double)nx - 0.5);
-                    const int biny = (int)std::floor((double)ny - 0.5);
-                    const int bint = (int)std::floor(nt);
-                    const float rbinx = (float)((double)nx - ((double)binx + 0.5));
-                    const float rbiny = (float)((double)ny - ((double)biny + 0.5));
-                    const float rbint = nt - (float)bint;
+                    const nmo_desc_sample sm = nmo_desc_sample_at(gptr, ow, cx, cy, xi, yi, x, y, angle0, st0, ct0, SBP);
+                    const float mod = sm.mod, win = sm.win, rbinx = sm.rbinx, rbiny = sm.rbiny, rbint = sm.rbint;
+                    const int binx = sm.binx, biny = sm.biny, bint = sm.bint;
                     for (int dbx = 0; dbx < 2; ++dbx)
                         for (int dby = 0; dby < 2; ++dby)
                             for (int dbt = 0; dbt < 2; ++dbt) {
@@ -449,6 +492,62 @@ NMO_API void nmo_compute_sift_descriptors(const float *key_pts, const float *ori
                 desc[128 * (size_t)pt + e] = (t == 0) ? part[9 * cell] + part[9 * cell + 8] : part[9 * cell + t];
             }
     }
+}
+
+/* Envelope of the descriptors (test infrastructure for the summation-order freedom, Q12): a LITERAL walk of the reference's
+ * kernel -- 16 x 16 threads, cx and cy advancing together per chunk (descriptor.cu:86-87,142-143), location
+ * (binx + dbinx) binxo + (biny + dbiny) binyo + ((bint + dbint) binto) % NBO relative to the centre (:81,136) -- that adds every
+ * float vote into a binary64 accumulator: sum64[128 pt + e] is the order-free value of descriptor element e (exact to 1e-16
+ * relative), nvotes its number of votes. Any order of the reference's global atomicAdd (:137), the oracle's nine-slot order
+ * included, lies within (nvotes - 1) u of it. Returns the number of samples whose bint is outside [0, NBO] (must be 0: the
+ * nine-slot layout's `bint & 7` equals the reference's `% NBO` only for those).                                          */
+NMO_API int nmo_descriptor_envelope(const float *key_pts, const float *orients, const float *grad, int num_pts, int ow, int oh,
+                                    int num_dogs, float xper, double *sum64, int *nvotes)
+{
+    const int NBO = 8, NBP = 4;
+    const int binto = 1, binyo = NBO * NBP, binxo = NBO;
+    int bad = 0;
+    for (int pt = 0; pt < num_pts; ++pt) {
+        double *d64 = sum64 + 128 * (size_t)pt;
+        int *nv = nvotes + 128 * (size_t)pt;
+        for (int e = 0; e < 128; ++e) { d64[e] = 0.0; nv[e] = 0; }
+        const float *kp = key_pts + 4 * (size_t)pt;
+        const float x = kp[0] / xper, y = kp[1] / xper, s = kp[2] / xper;
+        const int xi = (int)((double)x + 0.5), yi = (int)((double)y + 0.5), si = (int)kp[3];
+        if (xi < 0 || xi >= ow || yi < 0 || yi >= oh || si < 0 || si >= num_dogs) continue;
+        const float SBP = (float)((double)(3 * s) + 1.e-07);
+        const int W = (int)std::floor(std::sqrt(2.0) * (double)SBP * (NBP + 1) / 2.0 + 0.5);
+        const int xmin = std::max(-W, -xi), xmax = std::min(W, ow - 1 - xi);
+        const int ymin = std::max(-W, -yi), ymax = std::min(W, oh - 1 - yi);
+        const int max_dims = std::max(xmax - xmin, ymax - ymin);
+        const int chunks = (int)std::ceil((max_dims + 1.f) / 16);
+        const float *gptr = grad + 2 * (((long)si * oh + yi) * ow + xi);
+        const float angle0 = orients[2 * (size_t)pt];
+        const double st0 = (double)nmo_sinf(angle0), ct0 = (double)nmo_cosf(angle0);
+        const int centre = (NBP / 2) * binyo + (NBP / 2) * binxo;
+        for (int ty = 0; ty < 16; ++ty)
+            for (int tx = 0; tx < 16; ++tx) {
+                int cx = tx + xmin, cy = ty + ymin;
+                for (int i = 0; i < chunks; ++i, cx += 16, cy += 16) {
+                    if (!(cx <= xmax && cy <= ymax)) continue;
+                    const nmo_desc_sample sm = nmo_desc_sample_at(gptr, ow, cx, cy, xi, yi, x, y, angle0, st0, ct0, SBP);
+                    if (sm.bint < 0 || sm.bint > NBO) { ++bad; continue; }
+                    for (int dbinx = 0; dbinx < 2; ++dbinx)
+                        for (int dbiny = 0; dbiny < 2; ++dbiny)
+                            for (int dbint = 0; dbint < 2; ++dbint)
+                                if (sm.binx + dbinx >= -(NBP / 2) && sm.binx + dbinx < (NBP / 2) &&
+                                    sm.biny + dbiny >= -(NBP / 2) && sm.biny + dbiny < (NBP / 2)) {
+                                    const float wt = sm.win * sm.mod * std::fabs((1.f - dbinx) - sm.rbinx) *
+                                                     std::fabs((1.f - dbiny) - sm.rbiny) * std::fabs((1.f - dbint) - sm.rbint);
+                                    const int loc = (sm.binx + dbinx) * binxo + (sm.biny + dbiny) * binyo +
+                                                    ((sm.bint + dbint) * binto) % NBO;
+                                    d64[centre + loc] += (double)wt;
+                                    nv[centre + loc] += 1;
+                                }
+                }
+            }
+    }
+    return bad;
 }
 
 /* ---------------------------------------------------------------------------------------------------------- */
@@ -606,9 +705,12 @@ NMO_API int nmo_sift_detect_describe(const float *gray, int width, int height, i
                                        ys, kpts_out, orient_out, counts_out);
 }
 
-NMO_API int nmo_sift_detect_describe_ex(const float *gray, int width, int height, int capacity, float peak_threshold,
-                                        float edge_threshold, const float *mask, float *desc, float *xs, float *ys,
-                                        float *kpts_out, float *orient_out, int *counts_out)
+/* optional envelope outputs of the driver (nmo_sift_detect_describe_envelope), indexed by output item */
+struct nmo_envelope_out { double *desc64; int *desc_nv; float *ohist32; double *ohist64; int *ohist_nv; int bad_bint; };
+
+static int nmo_detect_describe_impl(const float *gray, int width, int height, int capacity, float peak_threshold,
+                                    float edge_threshold, const float *mask, float *desc, float *xs, float *ys,
+                                    float *kpts_out, float *orient_out, int *counts_out, nmo_envelope_out *env)
 {
     nmo_params P; nmo_sift_params(width, height, &P);
     P.peak_threshold = peak_threshold; P.edge_threshold = edge_threshold;
@@ -662,6 +764,14 @@ NMO_API int nmo_sift_detect_describe_ex(const float *gray, int width, int height
                 nmo_compute_sift_descriptors(coll[l].data(), orient[l].data(), grad.data(), n, ow, oh,
                                              P.num_dog_levels, xper, desc + 128 * (size_t)num_items,
                                              xs + num_items, ys + num_items);
+                if (env) {
+                    env->bad_bint += nmo_descriptor_envelope(coll[l].data(), orient[l].data(), grad.data(), n, ow, oh,
+                                                             P.num_dog_levels, xper, env->desc64 + 128 * (size_t)num_items,
+                                                             env->desc_nv + 128 * (size_t)num_items);
+                    nmo_orientation_envelope(coll[l].data(), grad.data(), n, ow, oh, 1.5f, xper,
+                                             env->ohist32 + 36 * (size_t)num_items, env->ohist64 + 36 * (size_t)num_items,
+                                             env->ohist_nv + 36 * (size_t)num_items);
+                }
                 if (kpts_out) std::memcpy(kpts_out + 4 * (size_t)num_items, coll[l].data(), 16 * (size_t)n);
                 if (orient_out) std::memcpy(orient_out + 2 * (size_t)num_items, orient[l].data(), 8 * (size_t)n);
                 num_items += n;
@@ -669,6 +779,29 @@ NMO_API int nmo_sift_detect_describe_ex(const float *gray, int width, int height
         }
     }
     return num_items;
+}
+
+NMO_API int nmo_sift_detect_describe_ex(const float *gray, int width, int height, int capacity, float peak_threshold,
+                                        float edge_threshold, const float *mask, float *desc, float *xs, float *ys,
+                                        float *kpts_out, float *orient_out, int *counts_out)
+{
+    return nmo_detect_describe_impl(gray, width, height, capacity, peak_threshold, edge_threshold, mask, desc, xs, ys, kpts_out,
+                                    orient_out, counts_out, nullptr);
+}
+
+/* The same client loop, additionally reporting the ORDER-FREE envelope of both histogram stages for every output item (see
+ * nmo_descriptor_envelope / nmo_orientation_envelope): desc64 / desc_nv 128 per item, ohist32 / ohist64 / ohist_nv 36 per item.
+ * *bad_bint receives the number of descriptor samples whose temporal bin left [0, 8] (must be 0).                       */
+NMO_API int nmo_sift_detect_describe_envelope(const float *gray, int width, int height, int capacity, float *desc, float *xs,
+                                              float *ys, float *kpts_out, float *orient_out, double *desc64, int *desc_nv,
+                                              float *ohist32, double *ohist64, int *ohist_nv, int *bad_bint)
+{
+    nmo_params P; nmo_sift_params(width, height, &P);
+    nmo_envelope_out env{desc64, desc_nv, ohist32, ohist64, ohist_nv, 0};
+    const int n = nmo_detect_describe_impl(gray, width, height, capacity, P.peak_threshold, P.edge_threshold, nullptr, desc, xs,
+                                           ys, kpts_out, orient_out, nullptr, &env);
+    if (bad_bint) *bad_bint = env.bad_bint;
+    return n;
 }
 
 /* Stage-level pyramid only (Gaussian levels + DoG + gradients of one octave), for stage parity tests and the

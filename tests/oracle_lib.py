@@ -218,6 +218,24 @@ def sift_detect_describe(gray, capacity=16384, peak=None, edge=None, mask=None):
                 counts=counts.reshape(-1, 3))
 
 
+def sift_detect_describe_envelope(gray, capacity=16384):
+    """nmo_sift_detect_describe_envelope: the frame driver's outputs plus, per output item, the ORDER-FREE binary64 sums and
+    vote counts of the descriptor elements and of the raw orientation bins (and the oracle's own raw orientation bins)."""
+    gray = _f32(gray)
+    h, w = gray.shape
+    desc = np.zeros((capacity, 128), np.float32)
+    xs, ys = np.zeros(capacity, np.float32), np.zeros(capacity, np.float32)
+    kp, ori = np.zeros((capacity, 4), np.float32), np.zeros((capacity, 2), np.float32)
+    d64, dnv = np.zeros((capacity, 128), np.float64), np.zeros((capacity, 128), np.int32)
+    o32, o64, onv = np.zeros((capacity, 36), np.float32), np.zeros((capacity, 36), np.float64), np.zeros((capacity, 36), np.int32)
+    bad = C.c_int(-1)
+    n = lib().nmo_sift_detect_describe_envelope(_fp(gray), C.c_int(w), C.c_int(h), C.c_int(capacity), _fp(desc), _fp(xs),
+                                                _fp(ys), _fp(kp), _fp(ori), _fp(d64), _fp(dnv), _fp(o32), _fp(o64), _fp(onv),
+                                                C.byref(bad))
+    return dict(n=n, desc=desc[:n], kpts=kp[:n], orient=ori[:n], desc64=d64[:n], desc_nv=dnv[:n], ohist32=o32[:n],
+                ohist64=o64[:n], ohist_nv=onv[:n], bad_bint=bad.value)
+
+
 def _sift_detect_describe_ex(gray, capacity, peak, edge, mask, p):
     h, w = gray.shape
     desc = np.zeros((capacity, 128), np.float32)

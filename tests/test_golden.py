@@ -8,7 +8,7 @@ import pytest
 
 import helpers as H
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f*.npz")))
 
 
 def _frames(g):

@@ -169,6 +169,62 @@ def test_config5_shard_scale_100k_by_12k5(nm, cuda):
     assert torch.allclose(m2[q].double(), top.values[:, 1], rtol=1e-5)
 
 
+def test_config5_full_size_eight_shards_merge_equals_the_unsharded_call(nm, cuda):
+    """BASELINE configs[4] at FULL size on one GPU: all-pairs 100 000 x 100 000, candidates cut into 8 shards of 12 500 rows as
+    8 ranks would hold them. The 8 shard calls (offsets 0 ... 87 500) merged -- shard-major triples through
+    nm_sift_match_merge_f32 AND the rank-major packed layout an ncclAllGather leaves, through nm_sift_match_merge_packed_f32
+    (what nm_sift_match_allgather_f32 merges) -- must equal the single unsharded nm_sift_match_f32 call index for index.
+    Planted cross-shard duplicates: the lowest GLOBAL index wins a tie (match.cu:94-105), and with two exact copies min2 = 0
+    leaves the prior untouched (match.cu:107-116). 64 rows are checked against a binary64 evaluation of all 100 000 candidates."""
+    import torch
+    n, n_shards, amb = 100_000, 8, 0.8
+    per = n // n_shards
+    g = torch.Generator(device=cuda).manual_seed(5)
+    A = torch.rand((n, 128), device=cuda, generator=g)
+    B = torch.rand((n, 128), device=cuda, generator=g)
+    # (a) candidate 90 001 (shard 7) is an exact copy of candidate 13 000 (shard 1); query 7 sits 1e-3 off both: two equal
+    #     minima in different shards, lower global index must win, and the ratio (= 1) only passes an ambiguity > 1
+    B[90_001] = B[13_000]
+    A[7] = B[13_000] + 1e-3
+    # (b) query 11 IS candidate 50 000 (shard 4) and candidate 99 999 (shard 7) is a copy of it too: min1 = min2 = 0 across shards
+    B[99_999] = B[50_000]
+    A[11] = B[50_000]
+    # (c) query 13 is an exact copy of candidate 0 only: distance 0 at global index 0, the clamped-min2 corner (match.cu:91)
+    A[13] = B[0]
+    ws_full = nm.MatchWorkspace(n, n, cuda)
+    ws_shard = nm.MatchWorkspace(n, per, cuda)
+    for ambiguity in (amb, 1.5):
+        prior = torch.full((n,), -7, dtype=torch.int32, device=cuda)
+        want, _ = nm.sift_match(A, B, ambiguity, prior=prior.clone(), workspace=ws_full)
+        m1s, ixs, m2s, blocks = [], [], [], []
+        for r in range(n_shards):
+            m1, ix, m2 = nm.sift_match_shard(A, B[r * per:(r + 1) * per], r * per, workspace=ws_shard)
+            m1s.append(m1); ixs.append(ix); m2s.append(m2)
+            blocks.append(torch.stack([m1.view(torch.int32), ix, m2.view(torch.int32)]))
+        got = nm.sift_match_merge(torch.stack(m1s), torch.stack(ixs), torch.stack(m2s), ambiguity, prior=prior.clone())
+        packed = torch.stack(blocks).contiguous()                 # (rank, 3, nA): the all-gather's receive buffer
+        got_p = prior.clone()
+        assert nm.lib().nm_sift_match_merge_packed_f32(packed.data_ptr(), n_shards, n, got_p.data_ptr(), ambiguity, None) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(got, want) and torch.equal(got_p, want), ambiguity
+        assert int(want[11]) == -7                                # min2 == 0: result left untouched
+        assert int(want[13]) == 0                                 # unique exact copy at global index 0
+        assert int(want[7]) == (13_000 if ambiguity > 1 else -1)  # cross-shard tie: lowest global index, ratio exactly 1
+        assert int((want >= 0).sum()) > 0 if ambiguity > 1 else True
+    # 64 random rows + the planted ones against binary64 over ALL candidates (the last loop's ambiguity is 1.5)
+    q = torch.cat([torch.randint(0, n, (64,), device=cuda, generator=g), torch.tensor([7, 13], device=cuda)])
+    d = torch.empty((q.numel(), n), dtype=torch.float64, device=cuda)
+    for c0 in range(0, n, 12_500):
+        d[:, c0:c0 + 12_500] = ((A[q].double()[:, None, :] - B[c0:c0 + 12_500].double()[None]) ** 2).sum(-1)
+    top = d.topk(2, dim=1, largest=False)
+    ratio_ok = top.values[:, 0] / top.values[:, 1] < 1.5 * (1 - 1e-6)
+    exp = torch.where(ratio_ok, top.indices[:, 0], torch.full_like(top.indices[:, 0], -1))
+    clear = (top.values[:, 0] / top.values[:, 1] - 1.5).abs() > 1e-5      # rows whose ratio test binary64 decides safely
+    tie = (top.values[:, 1] - top.values[:, 0]) < 1e-9 * top.values[:, 1]  # exact ties: lowest index, topk's pick is arbitrary
+    sel = clear & ~tie
+    assert torch.equal(want[q].long()[sel], exp[sel])
+
+
 def test_match_random_shapes_sweep(nm, oracle, cuda):
     """Ragged sizes around every tiling boundary of the fused kernel (256 queries / 128 candidates / chunking)."""
     rng = np.random.default_rng(2026)

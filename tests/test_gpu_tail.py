@@ -167,3 +167,61 @@ def test_launch_count_of_a_single_frame_call(nm, cuda):
     assert nm.lib().nm_sift_arena_launches_per_call(a._h, 2) == 23
     assert nm.lib().nm_sift_arena_launches_per_call(a._h, 16) == 1 + 6 * 8 + 2
     a.close()
+
+
+def test_a_failed_tail_launch_is_reported_and_the_next_call_is_correct(nm, cuda):
+    """ADVICE r4 (nm_tail.hip): a wait that times out sets a sticky error word and the rest of the launch drains without working.
+    The word must not outlive its launch and the call must not look successful: d_num_items reads -1, the status query says 1,
+    and the NEXT call on the same arenas is bit-identical to a clean arena's. (The timeout itself takes ~2 s of spinning to
+    provoke; the test hook sets the word as the timed-out wait would.)"""
+    import torch
+    w, h = 640, 480
+    frames = [torch.from_numpy(H.blurred_frame(s, w, h, sigma=3.0)).to(cuda) for s in (40, 41)]
+    ref = _arena(nm, cuda, w, h, 0, 8192)
+    want = []
+    for f in frames:
+        ref.detect_describe(f)
+        torch.cuda.synchronize()
+        want.append(_out(ref))
+    ars = [_arena(nm, cuda, w, h, None, 8192) for _ in range(2)]
+    assert ars[0].tail_status() == 0
+    for n_frames in (1, 2):
+        ars[0].tail_inject_error()
+        if n_frames == 1:
+            ars[0].detect_describe(frames[0])
+        else:
+            nm.detect_describe_batch(ars, frames)
+        torch.cuda.synchronize()
+        assert ars[0].tail_status() == 1
+        for a in ars[:n_frames]:
+            assert int(a.num_items.item()) == -1
+        # the call after the failed one: clean state, correct results, status back to 0
+        nm.detect_describe_batch(ars, frames)
+        torch.cuda.synchronize()
+        assert ars[0].tail_status() == 0
+        assert _same(_out(ars[0]), want[0]) and _same(_out(ars[1]), want[1])
+        ars[1].detect_describe(frames[0])
+        torch.cuda.synchronize()
+        assert ars[1].tail_status() == 0 and _same(_out(ars[1]), want[0])
+    for a in ars + [ref]:
+        a.close()
+
+
+def test_arenas_with_different_tail_plans_take_the_per_octave_launches(nm, cuda):
+    """ADVICE r4 (nm_frame.hip): the first arena's plan is paired with every arena's own plane table, so arenas created under
+    different NM_FRAME_TAIL settings must not share a tail launch."""
+    import torch
+    w, h = 640, 480
+    frames = [torch.from_numpy(H.blurred_frame(s, w, h, sigma=3.0)).to(cuda) for s in (42, 43)]
+    ref = _arena(nm, cuda, w, h, 0, 8192)
+    want = []
+    for f in frames:
+        ref.detect_describe(f)
+        torch.cuda.synchronize()
+        want.append(_out(ref))
+    ars = [_arena(nm, cuda, w, h, 2, 8192), _arena(nm, cuda, w, h, 3, 8192)]
+    nm.detect_describe_batch(ars, frames)
+    torch.cuda.synchronize()
+    assert _same(_out(ars[0]), want[0]) and _same(_out(ars[1]), want[1])
+    for a in ars + [ref]:
+        a.close()
