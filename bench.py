@@ -342,10 +342,14 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=32, help="frame pairs per GPU per step")
-    ap.add_argument("--frame-sets", type=int, default=32,
-                    help="distinct sets of 2 x pairs synthetic frames held in HBM (8.3 MB per frame); step k runs on set "
-                         "k mod frame-sets, so with warmup + steps <= frame-sets no frame is ever seen twice")
+    ap.add_argument("--pairs", type=int, default=32, help="frame pairs per GPU per ROUND (one detect call sequence + its matches)")
+    ap.add_argument("--rounds", type=int, default=5,
+                    help="rounds per step: a step is `rounds` x `pairs` frame pairs per GPU, every round on frames of its own "
+                         "(the arenas are reused round after round, as they are step after step). 5 x 32 pairs = 55 ms per step: "
+                         "the driver's 20 timed steps then span > 1 s (a 0.2 s window sits inside the clock ramp)")
+    ap.add_argument("--frame-sets", type=int, default=128,
+                    help="distinct sets of 2 x pairs synthetic frames held in HBM (8.3 MB per frame, 68 GB at the default); round "
+                         "q runs on set q mod frame-sets, so with (warmup + steps) x rounds <= frame-sets no frame is ever seen twice")
     ap.add_argument("--streams", type=int, default=4)
     ap.add_argument("--batch", type=int, default=64,
                     help="frames per nm_sift_detect_describe_batch call (64 = NM_SIFT_MAX_BATCH: the whole step's 32 pairs in ONE "
@@ -509,7 +513,8 @@ def main():
     S = max(1, min(args.streams, NB))
     # Fresh frames every step: n_sets distinct sets of 2P frames; step k (warm-up included) runs on set k mod n_sets.
     # Seeds are distinct per set, rank and pair: (2i, 2i+1) is a pair; set 0 of rank 0 starts at seed 0.
-    total_steps = args.warmup + args.steps
+    R = max(1, args.rounds)                           # rounds per step; everything below counts ROUNDS ("sub-steps")
+    total_steps = (args.warmup + args.steps) * R
     n_sets = max(1, min(total_steps, args.frame_sets))
 
     def seeds_of(s):
@@ -538,8 +543,9 @@ def main():
     ev_prep = [torch.cuda.Event() for _ in range(NCALLS)]
     ev_screen = [torch.cuda.Event() for _ in range(NCALLS)]
     results = [torch.full((CAP,), -1, dtype=torch.int32, device=dev) for _ in range(P)]
-    EV_STEPS = min(args.steps, 64)                    # steps whose match launches are event-timed
-    hist = torch.zeros((max(1, args.steps), 2 * P), dtype=torch.int32, device=dev)    # the counts of every timed step
+    NSUB = args.steps * R                             # timed rounds
+    EV_STEPS = min(NSUB, 128)                         # rounds whose match launches are event-timed
+    hist = torch.zeros((max(1, NSUB), 2 * P), dtype=torch.int32, device=dev)    # the counts of every timed round
 
     def mk_events(n):
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
@@ -638,10 +644,11 @@ def main():
         torch.cuda.synchronize()
 
     def timed_loop(k0, evs_all, hist_rows):
-        """EXACTLY args.steps steps bracketed by barrier + synchronize; returns (max-over-ranks seconds, per-rank ms)."""
+        """EXACTLY args.steps steps (= args.steps x R rounds) bracketed by barrier + synchronize; returns (max-over-ranks
+        seconds, per-rank ms)."""
         barrier()
         t0 = time.perf_counter()
-        for j in range(args.steps):
+        for j in range(NSUB):
             step(k0 + j, evs_all[j * P:(j + 1) * P] if (evs_all and j < EV_STEPS) else None,
                  hist_rows[j] if hist_rows is not None else None)
         barrier()
@@ -663,9 +670,9 @@ def main():
 
     screen = nm.get_match_screen()
     evs = mk_events(EV_STEPS * P)
-    for k in range(args.warmup):
+    for k in range(args.warmup * R):
         step(k, None, None)
-    dt, ranks_ms = timed_loop(args.warmup, evs, hist)
+    dt, ranks_ms = timed_loop(args.warmup * R, evs, hist)
     torch.cuda.synchronize()
     counts_host = hist.cpu().tolist()                 # [step][frame]: read AFTER the timed region
     match_ms, match_fl = launch_times(evs, counts_host)
@@ -673,7 +680,7 @@ def main():
     # what the timed loop left in the arenas / results of pair 0, for the oracle check below
     snap = None
     if rank == 0:
-        nA, nB = counts_host[args.steps - 1][0], counts_host[args.steps - 1][1]
+        nA, nB = counts_host[NSUB - 1][0], counts_host[NSUB - 1][1]
         snap = {"n": (nA, nB), "seeds": tuple(seeds_of(last_set)[:2]),
                 "kpts": [arenas[k].kpts[:n].cpu().numpy() for k, n in ((0, nA), (1, nB))],
                 "desc": [arenas[k].desc[:n].cpu().numpy() for k, n in ((0, nA), (1, nB))],
@@ -683,8 +690,8 @@ def main():
         except Exception:
             snap["rows"] = None
 
-    kp_rank = float(sum(sum(row) for row in counts_host[:args.steps]))
-    cmp_rank = float(sum(row[2 * i] * row[2 * i + 1] for row in counts_host[:args.steps] for i in range(P)))
+    kp_rank = float(sum(sum(row) for row in counts_host[:NSUB]))
+    cmp_rank = float(sum(row[2 * i] * row[2 * i + 1] for row in counts_host[:NSUB] for i in range(P)))
     tot = torch.tensor([kp_rank, cmp_rank], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -709,7 +716,7 @@ def main():
             for i0 in range(0, P, MB):
                 match_call(list(range(i0, min(i0 + MB, P))), None, mstream, bwss[0], res2)
             torch.cuda.synchronize()
-            row = c32[args.steps - 1]
+            row = c32[NSUB - 1]
             same = all(torch.equal(res2[i][:row[2 * i]], results[i][:row[2 * i]]) for i in range(P))
             f32 = {"dt": dt32, "ms": ms32, "fl": fl32, "same": bool(same)}
         except Exception as exc:
@@ -783,7 +790,8 @@ def main():
         try:
             import ctypes as C
             dropin = {"workload": "drop-in C++ API client loop on the 1080p pair (nm/src/nm_client.cpp: 2 x per-octave "
-                                  "detect+describe + compute_sift_matches), single host thread, NULL stream"}
+                                  "detect+describe + compute_sift_matches), single host thread, NULL stream",
+                      "distance_mode": nm.get_distance_mode()}
             for key, wd, reps, nstreams in (("distance_null", 0, 10, 1), ("distance_materialised", 1, 4, 1),
                                             ("distance_null_two_streams", 0, 10, 2), ("distance_materialised_two_streams", 1, 4, 2)):
                 n3 = (C.c_int * 3)()
@@ -811,7 +819,7 @@ def main():
             extra = {"error": repr(exc)}
 
     if rank == 0:
-        pairs_total = P * world * args.steps
+        pairs_total = P * R * world * args.steps
         nA, nB = snap["n"]
         m_ms = sum(match_ms) / len(match_ms)            # every event-timed MFMA launch of the timed region
         p_ms = sum(pyr_ms) / len(pyr_ms) if pyr_ms else float("nan")
@@ -877,9 +885,10 @@ def main():
             "config": {"workload": "configs[2]: SIFT detect+describe x2 + fused BF L2 match per 1920x1080 pair",
                        "match_screen": {"f16": "two-stage: f16 coarse pass + bf16x3 second pass on the unproven rows"}.get(screen, screen),
                        "match_sizes": "device",
-                       "frames": "fresh every step: %d distinct sets of %d frames per rank, step k on set k mod %d "
-                                 "(warmup + steps = %d)" % (n_sets, 2 * P, n_sets, total_steps),
-                       "pairs_per_gpu_per_step": P, "detect_streams": S, "frames_per_detect_call": B,
+                       "frames": "fresh every round: %d distinct sets of %d frames per rank, round q on set q mod %d "
+                                 "((warmup + steps) x rounds = %d)" % (n_sets, 2 * P, n_sets, total_steps),
+                       "pairs_per_gpu_per_step": P * R, "rounds_per_step": R, "pairs_per_round": P,
+                       "detect_streams": S, "frames_per_detect_call": B,
                        "host_enqueue_threads": T, "match_streams": MS, "pairs_per_match_call": MB,
                        "phases": "overlapped" if (args.overlap and B % 2 == 0) else "detect then match",
                        "match_pipeline": ("PREP / FINISH of neighbouring calls on a helper stream beside the MFMA launches" if pipeline
@@ -925,7 +934,26 @@ def main():
                             for k, r in ((0, r0), (1, r1)))
             ok = ok and np.array_equal(snap["match"], m)
             out["verified_pair0_vs_oracle"] = bool(ok)
+        # share of the step each roofline object's kernel (family) accounts for: its solo duration x launches per step over
+        # the measured step (the kernels of a step run one after the other: the step is the sum of their solo times)
+        step_ms = 1e3 * dt / args.steps
+        roof["share_of_step"] = round(sum(match_ms) / max(1, EV_STEPS) * NSUB / args.steps / step_ms, 4)
+        rp = out["roofline_pyramid"]
+        if isinstance(rp, dict) and rp.get("frame_driver_chain"):
+            rp["share_of_step"] = round(rp["frame_driver_chain"]["avg_ms"] * NB * R / step_ms, 4)
+            rp["share_of_step_note"] = "the chain the frame driver runs (frame_driver_chain.avg_ms) x detect calls per step / ms_per_step"
+        if isinstance(desc_roof, dict) and desc_roof.get("avg_ms"):
+            desc_roof["share_of_step"] = round(desc_roof["avg_ms"] * NB * R / step_ms, 4)
         # the figures a reader needs first go to the head of the line: the driver keeps only a tail of a long stdout
+        head.update({"roofline_pyramid_frac": (rp or {}).get("frac"),
+                     "roofline_pyramid_levels_dog_only_frac": ((rp or {}).get("levels_dog_only") or {}).get("frac"),
+                     "frame_driver_chain_us_per_frame": ((rp or {}).get("frame_driver_chain") or {}).get("us_per_frame"),
+                     "frame_desc_us_per_frame": (desc_roof or {}).get("us_per_frame"),
+                     "dropin_api_pairs_per_s": ({k: (dropin.get(k) or {}).get("pairs_per_s") for k in
+                                                 ("distance_null", "distance_materialised", "distance_null_two_streams",
+                                                  "distance_materialised_two_streams")} if isinstance(dropin, dict) and "error" not in dropin else None),
+                     "value_is": "batch ABI (nm_sift_detect_describe_batch + nm_sift_match_batch_dev_f32); the reference's own C++ API "
+                                 "call sequence is dropin_api_pairs_per_s"})
         head.update({"roofline_frac": roof.get("frac"), "roofline_kernel": roof.get("kernel"),
                      "verified_pair0_vs_oracle": out.get("verified_pair0_vs_oracle"),
                      "latency_us": ({k: latency.get(k) for k in ("launches_per_frame_call", "frame_us_eager", "frame_us_graph", "pair_us_eager", "pair_us_graph", "pair_us_eager_two_streams")}

@@ -58,7 +58,8 @@ NM_API int nm_fill_u32(void *dst, size_t count, unsigned int pattern, void *stre
 #define NM_PROF_DESCRIBE 2      /* frame_desc_kernel inside nm_sift_detect_describe[_batch] (all frames of the call) */
 #define NM_PROF_ORIENT 3        /* frame_orient_kernel of the same calls */
 #define NM_PROF_DETECT_O0 4     /* detect_stage_kernel of octave 0 of the same calls (per-octave launches, not the tail launch) */
-#define NM_PROF_SITES 5
+#define NM_PROF_DISTANCE 5      /* distance_mfma_kernel inside nm_sift_match_f32 when `distance` is materialised on the MFMA */
+#define NM_PROF_SITES 6
 NM_API int nm_profile_events(int site, void *start_event, void *stop_event);
 /* The same with a caller-owned list of npairs (start, stop) hipEvent_t pairs, events[2k], events[2k+1], consumed by the
  * k-th launch of the site (a batched call launches the MFMA kernel once per pair; under the two-stage screen, whose coarse
@@ -187,6 +188,22 @@ NM_API int nm_compute_sift_descriptors_levels(int n_levels, const float *const *
                                               const int *num_pts, const float *grad, int octave_width, int octave_height,
                                               int num_dogs, float xper, float *const *desc, float *const *x,
                                               float *const *y, void *stream);
+/* Device-sized forms of the two (round 5): the three level counts of the octave are read ON THE DEVICE (d_counts: what
+ * nm_compact_keypoints3 left there), so the host needs no count to issue them -- the reference's client synchronises once
+ * per level for it (thrust::copy_if, sift/pyramidata.cu:84-91). An empty level ends the octave (siftfunctions.cu:145,160);
+ * max_pts bounds a level's count (grid size; the lists hold at least as many entries). Descriptors go to the CONTAINER's
+ * arrays: slot = running count + kept keypoints of the earlier levels + index, the running count read from *d_base_in (NULL:
+ * host_base) and clipped at `capacity` (siftfunctions.cu:165-169); the new running count is written to *d_items_out. h_counts
+ * (3 ints) / h_items (1 int): device-accessible pointers of pinned host memory that receive the raw counts / the new running
+ * count, valid once `stream` has reached the launch (or NULL). nm/lazy_count.h is the C++ layer's use of them.            */
+NM_API int nm_detect_orientations_levels_dev(const float *const *key_pts, const int *d_counts, int max_pts, const float *grad,
+                                             int octave_width, int octave_height, float gauss_factor, float xper,
+                                             float *const *result, int *h_counts, void *stream);
+NM_API int nm_compute_sift_descriptors_levels_dev(const float *const *key_pts, const float *const *orients, const int *d_counts,
+                                                  int max_pts, const int *d_base_in, int host_base, int capacity,
+                                                  int *d_items_out, int *h_items, const float *grad, int octave_width,
+                                                  int octave_height, int num_dogs, float xper, float *desc, float *x, float *y,
+                                                  void *stream);
 
 /* ---- matcher ---- */
 /* transpose<float> (kernels/transpose.h:16-21, transpose.cu:33-40): odata[x*height+y] = idata[y*width+x]. */
@@ -213,6 +230,24 @@ NM_API int nm_get_sift_matches_f32(const float *distance, int rows, int cols, in
  * overwrites it with the old minimum at every replacement (:97), so its initial value 2139095040.0f only bounds a row whose
  * minimum sits at candidate 0. Such calls are correct, not fast (one exact 128-D distance per pair of rows).        */
 NM_API size_t nm_sift_match_workspace_bytes(int nA, int nB);
+/* How nm_sift_match_f32 fills a requested `distance` (process-wide; NM_MATCH_DISTANCE=exact|mfma sets the initial value):
+ *   1 (default) = on the fp32 matrix cores, as the squared-norm expansion of the rows centred on the mean row of B
+ *       (compute_brute_force_distance, kernels/match.cu:14-80, is the reference this replaces: 3 flop per (i, j, k) on scalar
+ *       ALUs). EVERY entry is within 1e-4 relative of the reference's chain acc = fma(t, t, acc), t = a_k - b_k: an entry is
+ *       kept only if a rigorous bound on the contraction's rounding error stays below that; all others
+ *       -- near-duplicates, exact copies, cancellation, non-finite values -- are recomputed by the reference's own chain and
+ *       are bit-equal to it (should the list of 32 x 32 blocks holding such entries overflow, the whole matrix is). The pass
+ *       uses the same `workspace`.
+ *   0 = the exact VALU kernel: every entry bit-equal to the reference's chain (what nm_bf_distance_f32, the building block,
+ *       always computes).
+ * result[] does not depend on the mode: match decisions are made on exactly recomputed distances either way.
+ * nm_sift_match_distance_listed: diagnostics of the LAST such pass on `workspace` (same nA, nB): 32 x 32 blocks of the matrix
+ * that held an entry outside the bound and were re-examined (-1 if the pass took the exact kernel for lack of scratch: fewer
+ * than ~80 query rows), and the capacity of the block list (more listed than that = the whole matrix came from the exact
+ * kernel). Synchronises `stream`. */
+NM_API int nm_sift_match_set_distance_mode(int mode);
+NM_API int nm_sift_match_get_distance_mode(void);
+NM_API int nm_sift_match_distance_listed(const void *workspace, int nA, int nB, int *listed, int *capacity, void *stream);
 /* Which MFMA screen the fused matcher runs before its exact finalize (process-wide; results are identical):
  * 0 = fp32 (v_mfma_f32_32x32x2_f32 on the descriptors themselves), 1 = bf16x3 (v_mfma_f32_32x32x16_bf16 on operands
  * split into two bf16 pieces: ~3x faster, a few more rows take the exact fallback), 2 = two-stage (a coarse pass with one

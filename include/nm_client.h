@@ -29,6 +29,13 @@ __attribute__((visibility("default"))) double nm_client_pair_loop_ex(const float
  * object. gray: width*height fp32 (host). Returns the descriptor count when all variants agree, -2 on a mismatch, -1 on an
  * exception (a double free aborts the process). */
 __attribute__((visibility("default"))) int nm_client_copy_semantics(const float *gray, int width, int height, int capacity);
+/* Lazy counts (niftymatch_amd/nm/lazy_count.h) against the reference's observable state: the frame through the per-octave loop
+ * (a) without looking at a count before the end, (b) looking at _orientations[l].size() / _num_items after every call, (c) with
+ * one synchronisation per octave (NM_EAGER_COUNTS). watch: 4 ints per octave (three sizes, running item count) as (b) saw
+ * them -- identical to (c)'s or the call returns -2; pending_seen: how many of (b)'s looks resolved a pending value. Returns
+ * the item count (all three runs agree on counts, descriptors and coordinates), -2 on a mismatch, -1 on an exception. */
+__attribute__((visibility("default"))) int nm_client_lazy_counts(const float *gray, int width, int height, int capacity,
+                                                                int *watch, int max_octaves, int *pending_seen);
 /* A: nA*128, B: nB*128 (host). distance: nA*nB (host) or NULL. result: nA ints, pre-filled by the caller. */
 __attribute__((visibility("default"))) int nm_client_match(const float *A, int nA, const float *B, int nB,
                                                           float *distance, int *result, float ambiguity);

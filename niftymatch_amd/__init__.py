@@ -45,6 +45,8 @@ _SIGNATURES = {
     "nm_compact_keypoints3": (_I, [_P, _I, _P, _P, _P, _P]),
     "nm_detect_orientations_levels": (_I, [_I, _P, _P, _P, _I, _I, _F, _F, _P, _P]),
     "nm_compute_sift_descriptors_levels": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P]),
+    "nm_detect_orientations_levels_dev": (_I, [_P, _P, _I, _P, _I, _I, _F, _F, _P, _P, _P]),
+    "nm_compute_sift_descriptors_levels_dev": (_I, [_P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P]),
     "nm_compact_workspace_bytes": (_SZ, [_I]),
     "nm_compact_keypoints": (_I, [_P, _I, _P, _P, _P, _P]),
     "nm_detect_orientations": (_I, [_P, _P, _I, _I, _I, _F, _F, _P, _P]),
@@ -63,6 +65,9 @@ _SIGNATURES = {
     "nm_sift_match_workspace_bytes": (_SZ, [_I, _I]),
     "nm_sift_match_set_screen": (_I, [_I]),
     "nm_sift_match_get_screen": (_I, []),
+    "nm_sift_match_set_distance_mode": (_I, [_I]),
+    "nm_sift_match_get_distance_mode": (_I, []),
+    "nm_sift_match_distance_listed": (_I, [_P, _I, _I, _P, _P, _P]),
     "nm_sift_match_f32": (_I, [_P, _I, _P, _I, _P, _P, _F, _P, _P]),
     "nm_sift_match_fallback_count": (_I, [_P, _I, _I, _P, _P]),
     "nm_sift_match_second_pass_count": (_I, [_P, _I, _I, _P, _P]),
@@ -110,6 +115,7 @@ _SIGNATURES = {
     "nm_client_detect_describe": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "nm_client_match": (_I, [_P, _I, _P, _I, _P, _P, _F]),
     "nm_client_copy_semantics": (_I, [_P, _I, _I, _I]),
+    "nm_client_lazy_counts": (_I, [_P, _I, _I, _I, _P, _I, _P]),
     "nm_client_pair_loop_ex": (C.c_double, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "nm_client_pair_loop": (C.c_double, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "nm_client_ransac": (_I, [_I, _P, _P, _P, _P, _I, _F, _I, C.c_uint, _P]),
@@ -171,6 +177,7 @@ PROF_PYRAMID_O0 = 1
 PROF_DESCRIBE = 2
 PROF_ORIENT = 3
 PROF_DETECT_O0 = 4
+PROF_DISTANCE = 5
 
 
 def profile_events(site, start=None, stop=None):
@@ -422,6 +429,29 @@ def set_match_screen(name):
 def get_match_screen():
     v = lib().nm_sift_match_get_screen()
     return [k for k, x in MATCH_SCREENS.items() if x == v][0]
+
+
+DISTANCE_MODES = {"exact": 0, "mfma": 1}
+
+
+def set_distance_mode(name):
+    """How sift_match(..., want_distance=True) fills the matrix: "mfma" (default: fp32 matrix cores, every entry within 1e-4
+    relative of the reference's chain, near-duplicates recomputed exactly) or "exact" (VALU kernel, bit-equal)."""
+    _check(lib().nm_sift_match_set_distance_mode(DISTANCE_MODES[name]), "nm_sift_match_set_distance_mode")
+
+
+def get_distance_mode():
+    v = lib().nm_sift_match_get_distance_mode()
+    return [k for k, x in DISTANCE_MODES.items() if x == v][0]
+
+
+def match_distance_listed(workspace, nA, nB):
+    """(32 x 32 blocks of the matrix the last MFMA distance pass on `workspace` listed for re-examination, capacity of its
+    list); (-1, 0) when the pass took the exact kernel for lack of scratch."""
+    n, cap = C.c_int(0), C.c_int(0)
+    _check(lib().nm_sift_match_distance_listed(_dev(workspace.buf), nA, nB, C.byref(n), C.byref(cap), _stream()),
+           "nm_sift_match_distance_listed")
+    return n.value, cap.value
 
 
 def match_fallback_count(workspace, nA, nB):

@@ -31,7 +31,7 @@ static inline hipStream_t nm_stream(void *s) { return reinterpret_cast<hipStream
 // Either one (start, stop) pair, re-recorded by every launch of the site, or a caller-owned list of pairs consumed in
 // launch order (a batched call launches the site several times).
 struct NmProfSite { hipEvent_t start, stop; void *const *list; int n, next; };
-extern thread_local NmProfSite nm_prof_sites[5];
+extern thread_local NmProfSite nm_prof_sites[6];   // NM_PROF_SITES (include/nm_abi.h)
 static inline void nm_prof_begin(int site, hipStream_t st)
 {
     NmProfSite &p = nm_prof_sites[site];

@@ -403,14 +403,47 @@ struct NmLevelLists {
     float *desc[3], *x[3], *y[3];
     int num_pts[3];
     int n_levels;
+    // Device-sized form (round 5; lazy_count.h): d_counts != NULL -- the three raw level counts live on the device (what
+    // nm_compact_keypoints3 left), num_pts[] is ignored and the grid is sized for an upper bound. An empty level ends the octave
+    // (sift/siftfunctions.cu:145,160). Descriptors: output slot of level l's keypoint pt = base + (kept keypoints of the levels
+    // before it) + pt, base = *d_base_in (or host_base when NULL), clipped at `capacity` (siftfunctions.cu:165-169); desc[0] /
+    // x[0] / y[0] are then the container's arrays from slot 0. One lane mirrors the counts / the new running count into
+    // mapped host words.
+    const int *d_counts;
+    const int *d_base_in; int host_base, capacity;
+    int *d_items_out;
+    int *h_counts, *h_items;           // mapped pinned host words (or NULL)
 };
+
+// kept keypoints (n) and first output slot (base) of level l in the device-sized form
+__device__ __forceinline__ void level_extent_dev(const NmLevelLists &a, int l, bool clip, int &n, int &base, int &run_out)
+{
+    int run = clip ? (a.d_base_in ? *a.d_base_in : a.host_base) : 0;
+    bool live = true;
+    n = 0; base = run;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int cnt = live ? a.d_counts[k] : 0;
+        if (cnt <= 0) { live = false; cnt = 0; }
+        int keep = cnt;
+        if (clip) { if (keep + run > a.capacity) keep = a.capacity - run; if (keep < 0) keep = 0; }
+        if (k == l) { n = keep; base = run; }
+        run += clip ? keep : 0;
+    }
+    run_out = run;
+}
 
 __global__ __launch_bounds__(256) void orientations_levels_kernel(NmLevelLists a, const float2 *__restrict__ grad, int ow,
                                                                  int oh, float gauss_factor, float xper)
 {
     __shared__ __attribute__((aligned(16))) float s_part[4][ORI_LDS];
     const int wave = threadIdx.x >> 6, l = blockIdx.y;
-    const int n = a.num_pts[l];
+    int n = a.num_pts[l];
+    if (a.d_counts) {
+        int base, run;
+        level_extent_dev(a, l, false, n, base, run);
+        if (a.h_counts && blockIdx.x == 0 && l == 0 && threadIdx.x < 3) a.h_counts[threadIdx.x] = a.d_counts[threadIdx.x];
+    }
     for (int pt = blockIdx.x * 4 + wave; pt < n; pt += gridDim.x * 4) {
         float th0, th1;                           // unset components are -1, as the pre-fill of pyramidata.cu:90 leaves them
         orient_wave(a.key_pts[l][pt], grad, ow, oh, gauss_factor, xper, th0, th1, s_part[wave]);
@@ -423,10 +456,20 @@ __global__ __launch_bounds__(64) void descriptors_levels_kernel(NmLevelLists a, 
 {
     __shared__ __attribute__((aligned(16))) float part[DESC_LDS];
     const int l = blockIdx.y;
-    const int n = a.num_pts[l];
+    int n = a.num_pts[l];
+    float *desc = a.desc[l], *xs = a.x[l], *ys = a.y[l];
+    if (a.d_counts) {
+        int base, run;
+        level_extent_dev(a, l, true, n, base, run);
+        desc = a.desc[0] + (size_t)base * 128; xs = a.x[0] + base; ys = a.y[0] + base;
+        if (blockIdx.x == 0 && l == 0 && threadIdx.x == 0) {
+            if (a.d_items_out) *a.d_items_out = run;
+            if (a.h_items) *a.h_items = run;
+        }
+    }
     for (int pt = blockIdx.x; pt < n; pt += gridDim.x)
-        describe_wave(a.key_pts[l][pt], a.orients[l][pt].x, grad, ow, oh, num_dogs, xper, a.desc[l] + (size_t)pt * 128,
-                      a.x[l] + pt, a.y[l] + pt, part);
+        describe_wave(a.key_pts[l][pt], a.orients[l][pt].x, grad, ow, oh, num_dogs, xper, desc + (size_t)pt * 128, xs + pt,
+                      ys + pt, part);
 }
 
 // ---- frame-driver kernels: all octaves of a frame in one launch, counts read from the device-side book ----
@@ -576,6 +619,50 @@ int nm_detect_orientations_levels(int n_levels, const float *const *key_pts, con
     hipLaunchKernelGGL(orientations_levels_kernel, dim3(min(nm_divup(most, 4), 4096), n_levels), dim3(256), 0,
                        nm_stream(stream), a, reinterpret_cast<const float2 *>(grad), octave_width, octave_height,
                        gauss_factor, xper);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+// The device-sized forms (lazy_count.h): the three level counts are read on the device, nothing comes back to the host except
+// through the mapped words h_counts[3] / h_items[1] (device-accessible pointers of pinned host memory, or NULL).
+// max_pts: upper bound of a level's count (sizes the grid; the lists hold at least that many entries).
+int nm_detect_orientations_levels_dev(const float *const *key_pts, const int *d_counts, int max_pts, const float *grad,
+                                      int octave_width, int octave_height, float gauss_factor, float xper, float *const *result,
+                                      int *h_counts, void *stream)
+{
+    if (!key_pts || !d_counts || !result || max_pts <= 0) return (int)hipErrorInvalidValue;
+    NmLevelLists a{};
+    a.n_levels = 3;
+    for (int l = 0; l < 3; ++l) {
+        a.key_pts[l] = reinterpret_cast<const float4 *>(key_pts[l]);
+        a.orients[l] = reinterpret_cast<float2 *>(result[l]);
+    }
+    a.d_counts = d_counts; a.h_counts = h_counts;
+    hipLaunchKernelGGL(orientations_levels_kernel, dim3(min(nm_divup(max_pts, 4), 1024), 3), dim3(256), 0, nm_stream(stream), a,
+                       reinterpret_cast<const float2 *>(grad), octave_width, octave_height, gauss_factor, xper);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+// desc / x / y: the CONTAINER's arrays (slot 0); the running item count is read from d_base_in (NULL: host_base) and the new
+// one written to d_items_out and *h_items.
+int nm_compute_sift_descriptors_levels_dev(const float *const *key_pts, const float *const *orients, const int *d_counts,
+                                           int max_pts, const int *d_base_in, int host_base, int capacity, int *d_items_out,
+                                           int *h_items, const float *grad, int octave_width, int octave_height, int num_dogs,
+                                           float xper, float *desc, float *x, float *y, void *stream)
+{
+    if (!key_pts || !orients || !d_counts || !desc || !x || !y || max_pts <= 0 || capacity <= 0) return (int)hipErrorInvalidValue;
+    NmLevelLists a{};
+    a.n_levels = 3;
+    for (int l = 0; l < 3; ++l) {
+        a.key_pts[l] = reinterpret_cast<const float4 *>(key_pts[l]);
+        a.orients[l] = const_cast<float2 *>(reinterpret_cast<const float2 *>(orients[l]));
+    }
+    a.desc[0] = desc; a.x[0] = x; a.y[0] = y;
+    a.d_counts = d_counts; a.d_base_in = d_base_in; a.host_base = host_base; a.capacity = capacity;
+    a.d_items_out = d_items_out; a.h_items = h_items;
+    hipLaunchKernelGGL(descriptors_levels_kernel, dim3(min(min(max_pts, capacity), 2048), 3), dim3(64), 0, nm_stream(stream), a,
+                       reinterpret_cast<const float2 *>(grad), octave_width, octave_height, num_dogs, xper);
     NM_LAUNCH_CHECK();
     return 0;
 }

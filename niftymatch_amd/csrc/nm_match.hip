@@ -530,35 +530,55 @@ __device__ __forceinline__ void select_half(const f32x16 &acc0, const f32x16 &ac
 // MFMAs of k-group t. hipcc's own schedule of the equivalent builtins waits for every read right after issuing it and
 // runs the chains one after the other.
 #define NM_MFMA "v_mfma_f32_32x32x2_f32 "
-__device__ __forceinline__ void mfma_half(f32x16 &acc0, f32x16 &acc1, const float *rowp, const float *normp,
-                                          const float4 (&qf)[16], float nq)
+// k-groups T0 .. T1 - 1 (8 values of k each) of both accumulators; NORMS: the chain starts with the augmented k-pair, otherwise
+// from the inline constant 0. mfma_half = all 16 groups (the matcher's screen). The distance pass splits k into two chains.
+template <int T0, int T1, bool NORMS>
+__device__ __forceinline__ void mfma_kgroups(f32x16 &acc0, f32x16 &acc1, const float *rowp, const float *normp,
+                                             const float4 (&qf)[16], float nq)
 {
     const float *r0 = rowp, *r1 = rowp + 32 * KP;
-    float4 c0 = *reinterpret_cast<const float4 *>(r0), c1 = *reinterpret_cast<const float4 *>(r1);
-    const float cn0 = normp[0], cn1 = normp[32 * KP];  // column 128 + h: (nb_j, 1) for h = (0, 1)
-    // augmented k-pair: (nb_j * 1) + (1 * na_i), accumulators start from the inline constant 0
-    asm volatile(NM_MFMA "%0, %2, %4, 0\n\t" NM_MFMA "%1, %3, %4, 0"
-                 : "=&v"(acc0), "=&v"(acc1) : "v"(cn0), "v"(cn1), "v"(nq) : "memory");
+    float4 c0 = *reinterpret_cast<const float4 *>(r0 + 8 * T0), c1 = *reinterpret_cast<const float4 *>(r1 + 8 * T0);
+    if (NORMS) {
+        const float cn0 = normp[0], cn1 = normp[32 * KP];  // column 128 + h: (nb_j, 1) for h = (0, 1)
+        // augmented k-pair: (nb_j * 1) + (1 * na_i), accumulators start from the inline constant 0
+        asm volatile(NM_MFMA "%0, %2, %4, 0\n\t" NM_MFMA "%1, %3, %4, 0"
+                     : "=&v"(acc0), "=&v"(acc1) : "v"(cn0), "v"(cn1), "v"(nq) : "memory");
+    }
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
+    for (int t = T0; t < T1; ++t) {
         float4 n0 = c0, n1 = c1;
-        if (t + 1 < 16) {                               // next k-group's fragments fly during this group's 8 MFMAs
+        if (t + 1 < T1) {                               // next k-group's fragments fly during this group's 8 MFMAs
             n0 = *reinterpret_cast<const float4 *>(r0 + 8 * (t + 1));
             n1 = *reinterpret_cast<const float4 *>(r1 + 8 * (t + 1));
         }
-        asm volatile(NM_MFMA "%0, %2, %10, %0\n\t" NM_MFMA "%1, %6, %10, %1\n\t"
-                     NM_MFMA "%0, %3, %11, %0\n\t" NM_MFMA "%1, %7, %11, %1\n\t"
-                     NM_MFMA "%0, %4, %12, %0\n\t" NM_MFMA "%1, %8, %12, %1\n\t"
-                     NM_MFMA "%0, %5, %13, %0\n\t" NM_MFMA "%1, %9, %13, %1"
-                     : "+v"(acc0), "+v"(acc1)
-                     : "v"(c0.x), "v"(c0.y), "v"(c0.z), "v"(c0.w), "v"(c1.x), "v"(c1.y), "v"(c1.z), "v"(c1.w),
-                       "v"(qf[t].x), "v"(qf[t].y), "v"(qf[t].z), "v"(qf[t].w)
-                     : "memory");
+        if (!NORMS && t == T0)                          // first instruction of a chain without the norm pair: C = 0
+            asm volatile(NM_MFMA "%0, %2, %10, 0\n\t" NM_MFMA "%1, %6, %10, 0\n\t"
+                         NM_MFMA "%0, %3, %11, %0\n\t" NM_MFMA "%1, %7, %11, %1\n\t"
+                         NM_MFMA "%0, %4, %12, %0\n\t" NM_MFMA "%1, %8, %12, %1\n\t"
+                         NM_MFMA "%0, %5, %13, %0\n\t" NM_MFMA "%1, %9, %13, %1"
+                         : "=&v"(acc0), "=&v"(acc1)
+                         : "v"(c0.x), "v"(c0.y), "v"(c0.z), "v"(c0.w), "v"(c1.x), "v"(c1.y), "v"(c1.z), "v"(c1.w),
+                           "v"(qf[t].x), "v"(qf[t].y), "v"(qf[t].z), "v"(qf[t].w)
+                         : "memory");
+        else
+            asm volatile(NM_MFMA "%0, %2, %10, %0\n\t" NM_MFMA "%1, %6, %10, %1\n\t"
+                         NM_MFMA "%0, %3, %11, %0\n\t" NM_MFMA "%1, %7, %11, %1\n\t"
+                         NM_MFMA "%0, %4, %12, %0\n\t" NM_MFMA "%1, %8, %12, %1\n\t"
+                         NM_MFMA "%0, %5, %13, %0\n\t" NM_MFMA "%1, %9, %13, %1"
+                         : "+v"(acc0), "+v"(acc1)
+                         : "v"(c0.x), "v"(c0.y), "v"(c0.z), "v"(c0.w), "v"(c1.x), "v"(c1.y), "v"(c1.z), "v"(c1.w),
+                           "v"(qf[t].x), "v"(qf[t].y), "v"(qf[t].z), "v"(qf[t].w)
+                         : "memory");
         c0 = n0; c1 = n1;
     }
     // an MFMA's result may be read by a non-MFMA instruction only 18 wait states after its issue (16-pass XDL op):
     // the compiler does not see inside the asm statements, so the padding is explicit
     asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc0), "+v"(acc1));
+}
+__device__ __forceinline__ void mfma_half(f32x16 &acc0, f32x16 &acc1, const float *rowp, const float *normp,
+                                          const float4 (&qf)[16], float nq)
+{
+    mfma_kgroups<0, 16, true>(acc0, acc1, rowp, normp, qf, nq);
 }
 #undef NM_MFMA
 
@@ -1785,8 +1805,11 @@ __device__ __forceinline__ void xd_step(v2f &acc, v2f xpair, v2f y, bool hi)
 template <bool X_KMAJOR, bool Y_KMAJOR>
 __global__ __launch_bounds__(256) void exact_distance_kernel(const float *__restrict__ X, int nX,
                                                             const float *__restrict__ Y, int nY,
-                                                            float *__restrict__ out, size_t ld)
+                                                            float *__restrict__ out, size_t ld,
+                                                            const int *__restrict__ only_if_above, int threshold)
 {
+    // (behind the MFMA distance pass: runs only when that pass's list of uncovered entries overflowed -- uniform scalar load)
+    if (only_if_above && *only_if_above <= threshold) return;
     __shared__ __attribute__((aligned(16))) float sX[XD_KC * XD_PITCH];
     __shared__ __attribute__((aligned(16))) float sY[XD_KC * XD_PITCH];
     const int tid = threadIdx.x;
@@ -1829,6 +1852,248 @@ __global__ __launch_bounds__(256) void exact_distance_kernel(const float *__rest
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 if (col + j < nY) o[j] = (j & 1) ? acc[i][j >> 1].y : acc[i][j >> 1].x;
+        }
+    }
+}
+
+// ---- the materialised distance matrix on the fp32 MFMA (round 5; reference: kernels/match.cu:14-80, siftfunctions.cu:28-34) ----
+// D[i][j] = |x_i - y_j|^2 as |x'_i|^2 + |y'_j|^2 - 2 x'_i . y'_j on v_mfma_f32_32x32x2_f32 with the store fused into the
+// kernel, where x' = x - mu, y' = y - mu are the rows CENTRED on the mean row of Y: distances are translation-invariant, and
+// the contraction's rounding error scales with the norms of what is multiplied, not with the distance (uniform all-positive
+// rows: without the centring every entry would fail the test below; SIFT descriptors: 5 x fewer do).
+// Every entry is within 1e-4 relative of the reference's chain (acc = fma(t, t, acc), t = x_k - y_k, match.cu:36-42):
+//   * the value v is the sum of TWO accumulator chains (k = 0..63 with the norm pair, k = 64..127): no term passes through more
+//     than 67 roundings (2 + 64 steps of a chain, the final add), and the tabulated norms carry 8 (distance_center_kernel), so
+//     with d' the exact distance of the centred rows  |v - d'| <= (gamma_67 + gamma_8) (sqrt nx + sqrt ny)^2 = 4.47e-6 (..)^2;
+//     DIST_C = 5.15e-6 is that with 15 % of slack. (Premise, as for the matcher's fp32 screen: an instruction is two fused
+//     steps, C + a0 b0 + a1 b1 with at most two roundings -- nm_selftest_mfma_model(f32) measures it.)
+//   * centring rounds once per element, |x'_k - (x_k - mu_k)| <= u |x'_k|: sqrt d differs from sqrt d' by at most
+//     u (sqrt nx + sqrt ny);
+//   * the reference's own chain is within gamma_130 d <= 7.8e-6 d of the true d.
+//   An entry is ACCEPTED iff v >= K (sqrt nx + sqrt ny)^2, K = DIST_C / 7.8e-5 = 0.066: then |v - d'| <= 7.8e-5 v, the centring
+//   moves d by < 4.7e-7 d', and |v - d_ref| < (7.8e-5 + 4.7e-7 + 7.8e-6 + products) d_ref < 8.7e-5 d_ref.
+//   Every other entry -- near-duplicates, exact copies, negative or NaN values from cancellation or overflow -- belongs to a
+//   32 x 32 block that is LISTED; distance_fixup_kernel re-applies the test to the block's stored values and recomputes what
+//   fails it by the reference's own chain: bit-equal to the exact kernel. If the list overflows, the whole matrix is
+//   (exact_distance_kernel launched behind it runs only then). Uncorrelated rows have d' ~ nx + ny >= (sqrt nx + sqrt ny)^2 / 2;
+//   only pairs whose centred rows correlate above ~0.87 fail (1.7e-4 of the pairs of two 1080p frames' descriptors, 5 % of the
+//   blocks). The test is v_add + v_mul + v_cmp per entry (sqrt(K n) is tabulated, rounded up).
+// Layout: rows of the MFMA result = the STREAMED set X (128-row tiles through LDS, registers), columns = the RESIDENT set Y
+// (32 rows per wave, fragments in VGPRs, lanes): a store instruction writes 128 contiguous bytes of D per half wave.
+struct DistArgs {
+    const float *Xc, *Yc;         // centred rows (n x 128)
+    const float *nx, *ny;         // their squared norms
+    const float *tx, *ty;         // sqrt(K norm), rounded up: the acceptance test is v >= (tx_i + ty_j)^2
+    float *D; size_t ldd;         // D[i * ldd + j], i over X, j over Y
+    int nX, nY;
+    int *fix_count; int2 *fix_list; int fix_cap;
+    int *fix_report;              // where the fix-up pass leaves the number of listed blocks (the list's memory is reused)
+};
+constexpr int DIST_P = 64;        // row slices of the column-sum pass
+constexpr float DIST_C = 5.15e-6f;                    // |v - d'| <= DIST_C (sqrt nx + sqrt ny)^2
+constexpr float DIST_K = DIST_C / 7.8e-5f;            // acceptance: v >= DIST_K (sqrt nx + sqrt ny)^2
+
+// column sums of Y in DIST_P slices: part[slice][k] = sum of y[r][k] over rows r = slice, slice + DIST_P, ... (fixed order)
+__global__ __launch_bounds__(128) void distance_colsum_kernel(const float *__restrict__ Y, int nY, float *__restrict__ part)
+{
+    const int k = threadIdx.x, sl = blockIdx.x;
+    float s = 0.f;
+    for (int r = sl; r < nY; r += DIST_P) s += Y[(size_t)r * DIM + k];
+    part[sl * DIM + k] = s;
+}
+
+// blockIdx.y = 0: X, 1: Y. One wave per row: x' = x - mu, |x'|^2 (fma pair + wave tree: 8 roundings), sqrt(K |x'|^2) rounded up.
+__global__ __launch_bounds__(256) void distance_center_kernel(const float *__restrict__ X, int nX, const float *__restrict__ Y, int nY,
+                                                             const float *__restrict__ part, float *__restrict__ Xc,
+                                                             float *__restrict__ Yc, float *__restrict__ nx, float *__restrict__ ny,
+                                                             float *__restrict__ tx, float *__restrict__ ty, int *__restrict__ fix_count)
+{
+    __shared__ float mu[DIM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < DIM) {
+        float s = 0.f;
+        for (int p = 0; p < DIST_P; ++p) s += part[p * DIM + tid];
+        mu[tid] = s / (float)nY;
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *fix_count = 0;
+    __syncthreads();
+    const bool second = blockIdx.y != 0;
+    const float *S = second ? Y : X;
+    float *Sc = second ? Yc : Xc, *nn = second ? ny : nx, *tt = second ? ty : tx;
+    const int n = second ? nY : nX;
+    const float2 m2 = *reinterpret_cast<const float2 *>(&mu[2 * lane]);
+    for (int r = blockIdx.x * 4 + wave; r < n; r += gridDim.x * 4) {
+        const float2 v = *reinterpret_cast<const float2 *>(S + (size_t)r * DIM + 2 * lane);
+        const float2 c = make_float2(v.x - m2.x, v.y - m2.y);
+        *reinterpret_cast<float2 *>(Sc + (size_t)r * DIM + 2 * lane) = c;
+        float q = __builtin_fmaf(c.x, c.x, c.y * c.y);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) q += __shfl_xor(q, d);
+        if (lane == 0) { nn[r] = q; tt[r] = __builtin_sqrtf(q * DIST_K) * 1.000002f; }
+    }
+}
+
+// Epilogue of one 32 x 32 accumulator: register e holds tile row rb + 8 (e / 4) + 4 h + (e % 4), column = this lane's j.
+// Every value is stored. If ANY value of the 32 x 32 block is outside the bound, the BLOCK is listed (one atomic by one lane):
+// distance_fixup_kernel reads the block's stored values back, applies the same test to the same values and recomputes exactly
+// what fails it. FULL: all 128 rows of the tile exist (only the last row tile of X is ragged; its missing rows are masked).
+template <bool FULL>
+__device__ __forceinline__ void dist_emit(const f32x16 &acc, const DistArgs &a, __amdgpu_buffer_rsrc_t rsD, const float *tab,
+                                          int rb, int h, unsigned long long jmask, float tyj, unsigned vo, unsigned ld4,
+                                          int i_blk, int j_blk, int rows_here)
+{
+    // vo: this lane's byte offset inside the tile's rows of D, 0x80000000 for a lane whose column does not exist -- the
+    // descriptor's range check (voffset IS part of it; soffset is not) drops that lane's stores. jmask = lanes with a column.
+    unsigned long long listed = 0;
+#pragma unroll
+    for (int e4 = 0; e4 < 4; ++e4) {
+        const float4 t4 = *reinterpret_cast<const float4 *>(tab + rb + 8 * e4 + 4 * h);
+        const float tv[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+        for (int e1 = 0; e1 < 4; ++e1) {
+            const int e = 4 * e4 + e1;
+            // lanes whose value is NOT >= the acceptance term (unordered-or-less-than: a NaN is listed), as a wave mask
+            const float sq = tv[e1] + tyj;
+            const unsigned long long below = __builtin_amdgcn_fcmpf(acc[e], sq * sq, 12 /* FCMP_ULT */);
+            if (FULL) {
+                listed |= below;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[e]), rsD, vo, (rb + 8 * e4 + e1) * ld4, 0);
+            } else {                                        // last row tile of X: rows >= rows_here do not exist
+                const bool ok = rb + 8 * e4 + 4 * h + e1 < rows_here;
+                listed |= below & __ballot(ok);
+                if (ok) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[e]), rsD, vo, (rb + 8 * e4 + e1) * ld4, 0);
+            }
+        }
+    }
+    if (__builtin_expect((listed & jmask) != 0, 0)) {       // near-duplicates, cancellation, non-finite values
+        if ((threadIdx.x & 63) == 0) {
+            const int at = atomicAdd(a.fix_count, 1);
+            if (at < a.fix_cap) a.fix_list[at] = make_int2(i_blk, j_blk);
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 1) void distance_mfma_kernel(DistArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *const tabuf = lds + 2 * TILE_C * KP;             // 2 x 128 acceptance terms of the streamed rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int srow = tid >> 5, scol = (tid & 31) * 4;       // staging coordinates: 16 rows x 32 float4 per pass
+    const int nX = a.nX, nY = a.nY;
+    const int n_rt = nm_divup_dev(nX, TILE_C), n_cb = nm_divup_dev(nY, QB);
+    const long long U = (long long)n_rt * n_cb;
+    const long long u0 = U * blockIdx.x / gridDim.x, u1 = U * (blockIdx.x + 1) / gridDim.x;
+    if (u0 >= u1) return;
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.Xc), 0, nX * (DIM * 4), 0x00020000);
+    const int voff = (srow * DIM + scol) * 4;
+
+    u32x4 st[8];
+    float stn = 0.f, stt = 0.f;
+    auto stage_load = [&](int rt) {                         // rows rt * 128 .. + 127 of X -> registers (rows >= nX read as zeros)
+        const int ib = rt * TILE_C;
+#pragma unroll
+        // (the row offset rides in voffset: soffset is excluded from the descriptor's range check)
+        for (int it = 0; it < 8; ++it) st[it] = __builtin_amdgcn_raw_buffer_load_b128(rsX, voff + (ib + 16 * it) * (DIM * 4), 0, 0);
+        if (tid < TILE_C) {
+            const bool ok = ib + tid < nX;
+            stn = ok ? a.nx[ib + tid] : 0.f;
+            stt = ok ? a.tx[ib + tid] : 0.f;
+        }
+    };
+    auto stage_write = [&](int b) {
+        float *buf = lds + b * (TILE_C * KP);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) *reinterpret_cast<u32x4 *>(&buf[(srow + 16 * it) * KP + scol]) = st[it];
+        if (tid < TILE_C) {                                 // augmented k-pair (|x'|^2, 1) and the row's acceptance term
+            *reinterpret_cast<float2 *>(&buf[tid * KP + DIM]) = make_float2(stn, 1.0f);
+            tabuf[b * TILE_C + tid] = stt;
+        }
+    };
+
+    float4 qf[16];
+    float nq = 0.f, tyj = 0.f;
+    int cb_held = -1;
+    const int jw = wave * 32 + r;                           // this lane's column inside the 256-column block
+    stage_load((int)(u0 % n_rt));
+    stage_write(0);
+    __syncthreads();
+    int b = 0;
+    for (long long u = u0; u < u1; ++u) {
+        const int cb = (int)(u / n_rt), rt = (int)(u - (long long)cb * n_rt);
+        if (u + 1 < u1) stage_load((int)((u + 1) % n_rt));
+        const int j = cb * QB + jw;
+        const bool j_ok = j < nY;
+        if (cb != cb_held) {                                // resident fragments of this wave's 32 columns, scaled by -2 (exact)
+            cb_held = cb;
+            const float4 *yr = reinterpret_cast<const float4 *>(a.Yc + (size_t)(j_ok ? j : 0) * DIM) + h;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float4 v = j_ok ? yr[2 * t] : make_float4(0.f, 0.f, 0.f, 0.f);
+                qf[t] = make_float4(-2.f * v.x, -2.f * v.y, -2.f * v.z, -2.f * v.w);
+            }
+            const float nyj = j_ok ? a.ny[j] : 0.f;
+            tyj = j_ok ? a.ty[j] : 0.f;
+            nq = (h == 0) ? 1.0f : nyj;
+        }
+        const int i0 = rt * TILE_C;
+        const float *buf = lds + b * (TILE_C * KP);
+        const float *rowp = buf + r * KP + 4 * h, *normp = buf + r * KP + DIM + h;
+        const float *tab = tabuf + b * TILE_C;
+        // the tile's rows of D as a range-checked view: rows >= nX are dropped by the hardware (32-bit byte range: 128 ldd 4)
+        const int rows_here = min(TILE_C, nX - i0);
+        const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(a.D + (size_t)i0 * a.ldd, 0,
+                                                                             (int)((size_t)rows_here * a.ldd * 4), 0x00020000);
+        unsigned ld4 = (unsigned)(a.ldd * 4);
+        asm volatile("" : "+s"(ld4));                       // per unit: keeps the 128 row offsets (row x ld4) out of loop-invariant SGPRs
+        const unsigned vo = j_ok ? (unsigned)j * 4u + (unsigned)(4 * h) * ld4 : 0x80000000u;
+        const unsigned long long jmask = __ballot(j_ok);
+        f32x16 a0, a1;
+        const bool full = rows_here == TILE_C;              // uniform: only the last row tile of X is ragged
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            // two chains per accumulator: k = 0..63 with the norm pair, k = 64..127 from zero, one add (the error bound above)
+            f32x16 b0, b1;
+            mfma_kgroups<0, 8, true>(a0, a1, rowp + 64 * half * KP, normp + 64 * half * KP, qf, nq);
+            mfma_kgroups<8, 16, false>(b0, b1, rowp + 64 * half * KP, normp + 64 * half * KP, qf, nq);
+            a0 += b0; a1 += b1;
+            const int jb = cb * QB + wave * 32;
+            if (full) {
+                dist_emit<true>(a0, a, rsD, tab, 64 * half, h, jmask, tyj, vo, ld4, i0 + 64 * half, jb, rows_here);
+                dist_emit<true>(a1, a, rsD, tab, 64 * half + 32, h, jmask, tyj, vo, ld4, i0 + 64 * half + 32, jb, rows_here);
+            } else {
+                dist_emit<false>(a0, a, rsD, tab, 64 * half, h, jmask, tyj, vo, ld4, i0 + 64 * half, jb, rows_here);
+                dist_emit<false>(a1, a, rsD, tab, 64 * half + 32, h, jmask, tyj, vo, ld4, i0 + 64 * half + 32, jb, rows_here);
+            }
+        }
+        if (u + 1 < u1) stage_write(b ^ 1);
+        __syncthreads();
+        b ^= 1;
+    }
+}
+
+// The listed 32 x 32 blocks: one wave per block reads the block's stored values back, applies the acceptance test of the MFMA
+// pass to them (same values, same tabulated terms: the same decision) and overwrites what fails it with the reference's own
+// chain (the rows come from L2).
+__global__ __launch_bounds__(256) void distance_fixup_kernel(const float *__restrict__ X, const float *__restrict__ Y, DistArgs a)
+{
+    const int n = *a.fix_count;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.fix_report) *a.fix_report = n;
+    if (n > a.fix_cap) return;                              // overflow: the exact kernel behind this launch fills everything
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int jl = lane & 31, ih = lane >> 5;
+    for (int q = blockIdx.x * 4 + wave; q < n; q += gridDim.x * 4) {
+        const int2 blk = a.fix_list[q];
+        const int j = blk.y + jl;
+        if (j >= a.nY) continue;
+        const float tyj = a.ty[j];
+        for (int rr = ih; rr < 32; rr += 2) {
+            const int i = blk.x + rr;
+            if (i >= a.nX) break;
+            float *d = a.D + (size_t)i * a.ldd + j;
+            const float sq = a.tx[i] + tyj;
+            if (!(*d >= sq * sq))
+                *d = exact_dist(reinterpret_cast<const float4 *>(X + (size_t)i * DIM), reinterpret_cast<const float4 *>(Y + (size_t)j * DIM));
         }
     }
 }
@@ -1939,6 +2204,82 @@ static size_t pair_workspace_bytes(int nA, int nB)
            align256((size_t)nA * MAX_CHUNKS * sizeof(float)) + 256 + align256((size_t)nA * 4) + 256 +
            align256((size_t)nA * DIM * 4) + align256((size_t)nB * DIM * 4) + align256(((size_t)nB + TILE_C) * sizeof(uint4)) +
            align256((size_t)nA * DIM * 2) + align256((size_t)nB * DIM * 2) + 3 * align256((size_t)nA * 4) + align256((size_t)nB * 4);
+}
+
+// How nm_sift_match_f32 fills a requested `distance` matrix: 1 = on the fp32 MFMA (distance_mfma_kernel: every entry within
+// 1e-4 relative of the reference's chain, listed entries bit-equal to it), 0 = exact_distance_kernel (VALU; every entry
+// bit-equal). NM_MATCH_DISTANCE=exact|mfma or nm_sift_match_set_distance_mode() select it (process-wide). The match indexes do
+// not depend on it: they are decided on exactly recomputed distances either way.
+static std::atomic<int> g_dist_mode{-1};
+static int distance_mode()
+{
+    int v = g_dist_mode.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("NM_MATCH_DISTANCE");
+        v = (e && (!strcmp(e, "exact") || !strcmp(e, "0"))) ? 0 : 1;
+        g_dist_mode.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
+// The scratch of the MFMA distance pass lives INSIDE the matcher's workspace of the same (nA, nB): the pass runs before the
+// fused matcher on the same stream, and every region it uses is (re)written by the matcher's own prep / screen kernels
+// afterwards -- centred copies in the bf16 split images (same 512 bytes per row), norms and acceptance terms in the fp16
+// images, column sums + counter + list in the partial lists. Returns false when the partial-list pool is too small for that
+// (a few dozen query rows): the caller then takes the exact kernel.
+static bool distance_scratch(const MatchWs &w, int nA, DistArgs &a, float **part)
+{
+    char *pool = reinterpret_cast<char *>(w.partial);
+    const size_t pool_bytes = align256((size_t)nA * MAX_CHUNKS * sizeof(float4)) + align256((size_t)nA * MAX_CHUNKS * sizeof(float));
+    const size_t head = (size_t)DIST_P * DIM * sizeof(float) + 256;
+    if (pool_bytes < head + 65536) return false;
+    *part = reinterpret_cast<float *>(pool);
+    a.fix_count = reinterpret_cast<int *>(pool + (size_t)DIST_P * DIM * sizeof(float));
+    a.fix_list = reinterpret_cast<int2 *>(pool + head);
+    const size_t cap = (pool_bytes - head) / sizeof(int2);
+    a.fix_cap = (int)(cap > 0x3fffffff ? 0x3fffffff : cap);
+    a.Xc = reinterpret_cast<const float *>(w.As); a.Yc = reinterpret_cast<const float *>(w.Bs);
+    a.nx = reinterpret_cast<const float *>(w.Ah); a.tx = a.nx + nA;                 // nA x 256 bytes available
+    a.ny = reinterpret_cast<const float *>(w.Bh); a.ty = nullptr;                   // set by the caller (needs nB)
+    a.fix_report = w.fb_count + 60;                        // a free word of the pair's 256-byte counter block
+    return true;
+}
+
+static int run_distance(const float *A, int nA, const float *B, int nB, float *distance, const MatchWs &w, hipStream_t st)
+{
+    DistArgs a{};
+    float *part = nullptr;
+    const dim3 xgrid(nm_divup(nB, XD_TILE), nm_divup(nA, XD_TILE));
+    if (distance_mode() == 0 || nA >= MATCH_MAX_ROWS || nB >= MATCH_MAX_ROWS || !distance_scratch(w, nA, a, &part)) {
+        hipLaunchKernelGGL((exact_distance_kernel<false, false>), xgrid, dim3(256), 0, st, A, nA, B, nB, distance, (size_t)nB, nullptr, 0);
+        NM_LAUNCH_CHECK();
+        return 0;
+    }
+    a.ty = a.ny + nB;
+    a.D = distance; a.ldd = (size_t)nB; a.nX = nA; a.nY = nB;
+    hipLaunchKernelGGL(distance_colsum_kernel, dim3(DIST_P), dim3(128), 0, st, B, nB, part);
+    NM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(distance_center_kernel, dim3(min(1024, nm_divup(max(nA, nB), 4)), 2), dim3(256), 0, st, A, nA, B, nB, part,
+                       const_cast<float *>(a.Xc), const_cast<float *>(a.Yc), const_cast<float *>(a.nx), const_cast<float *>(a.ny),
+                       const_cast<float *>(a.tx), const_cast<float *>(a.ty), a.fix_count);
+    NM_LAUNCH_CHECK();
+    const size_t lds_bytes = (size_t)2 * TILE_C * KP * sizeof(float) + 2 * TILE_C * sizeof(float);
+    NM_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void *>(distance_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds_bytes));
+    const long long units = (long long)nm_divup(nA, TILE_C) * nm_divup(nB, QB);
+    const int grid = (int)std::min<long long>(units, nm_cu_count());
+    nm_prof_begin(NM_PROF_DISTANCE, st);
+    hipLaunchKernelGGL(distance_mfma_kernel, dim3(grid), dim3(512), lds_bytes, st, a);
+    nm_prof_end(NM_PROF_DISTANCE, st);
+    NM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(distance_fixup_kernel, dim3(2048), dim3(256), 0, st, A, B, a);
+    NM_LAUNCH_CHECK();
+    // a list that overflowed (more 32 x 32 blocks with an entry outside the bound than the partial-list pool holds): the exact kernel fills the whole matrix;
+    // otherwise its workgroups return at once
+    hipLaunchKernelGGL((exact_distance_kernel<false, false>), xgrid, dim3(256), 0, st, A, nA, B, nB, distance, (size_t)nB,
+                       a.fix_count, a.fix_cap);
+    NM_LAUNCH_CHECK();
+    return 0;
 }
 
 struct MatchJob {                 // host-side description of one pair of a (possibly batched) call
@@ -2104,7 +2445,7 @@ int nm_bf_distance_f32(const float *A, int size_A, const float *B, int size_B, i
     // rows of the (transposed) output = candidates j, columns = queries i: result[j * size_A + i]; A arrives k-major
     dim3 grid(nm_divup(size_A, XD_TILE), nm_divup(size_B, XD_TILE));
     hipLaunchKernelGGL((exact_distance_kernel<false, true>), grid, dim3(256), 0, nm_stream(stream), B, size_B, A, size_A,
-                       result, (size_t)size_A);
+                       result, (size_t)size_A, nullptr, 0);
     NM_LAUNCH_CHECK();
     return 0;
 }
@@ -2130,6 +2471,28 @@ int nm_sift_match_set_screen(int screen)
     return 0;
 }
 int nm_sift_match_get_screen(void) { return match_screen(); }
+
+int nm_sift_match_set_distance_mode(int mode)
+{
+    if (mode < 0 || mode > 1) return (int)hipErrorInvalidValue;
+    g_dist_mode.store(mode, std::memory_order_relaxed);
+    return 0;
+}
+int nm_sift_match_get_distance_mode(void) { return distance_mode(); }
+// Diagnostics: entries of the last MFMA distance pass on `workspace` (same nA, nB) that were listed for the exact recomputation,
+// and the capacity of the list (more listed than that = the whole matrix was filled by the exact kernel). Synchronises.
+int nm_sift_match_distance_listed(const void *workspace, int nA, int nB, int *listed, int *capacity, void *stream)
+{
+    if (!workspace || !listed || nA <= 0 || nB <= 0) return (int)hipErrorInvalidValue;
+    DistArgs a{};
+    float *part = nullptr;
+    *listed = -1;
+    if (capacity) *capacity = 0;
+    if (!distance_scratch(carve(const_cast<void *>(workspace), nA, nB), nA, a, &part)) return 0;
+    if (capacity) *capacity = a.fix_cap;
+    NM_RETURN_IF(hipStreamSynchronize(nm_stream(stream)));
+    return (int)hipMemcpy(listed, a.fix_report, sizeof(int), hipMemcpyDeviceToHost);
+}
 
 size_t nm_sift_match_batch_workspace_bytes(int n, const int *nA, const int *nB)
 {
@@ -2247,9 +2610,9 @@ int nm_sift_match_f32(const float *A, int nA, const float *B, int nB, float *dis
     if (nA <= 0 || nB <= 0) return 0;
     hipStream_t st = nm_stream(stream);
     if (distance) {                     // distance[i * nB + j]: rows = queries, columns = candidates
-        dim3 grid(nm_divup(nB, XD_TILE), nm_divup(nA, XD_TILE));
-        hipLaunchKernelGGL((exact_distance_kernel<false, false>), grid, dim3(256), 0, st, A, nA, B, nB, distance, (size_t)nB);
-        NM_LAUNCH_CHECK();
+        if (!workspace) return (int)hipErrorInvalidValue;
+        const int rc = run_distance(A, nA, B, nB, distance, carve(workspace, nA, nB), st);
+        if (rc) return rc;
     }
     return run_fused(A, nA, B, nB, 0, 0, ambiguity, result, nullptr, nullptr, nullptr, workspace, st);
 }

@@ -10,9 +10,11 @@
 
 #include <cstddef>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #include "exception.h"
+#include "lazy_count.h"
 
 extern "C" int nm_fill_u32(void *dst, size_t count, unsigned int pattern, void *stream);
 
@@ -32,26 +34,49 @@ public:
         if (_n) nm_check((int)hipMemcpy(_p, host.data(), _n * sizeof(T), hipMemcpyHostToDevice), "device_vector H2D");
     }
     device_vector(const device_vector &o) : _p(nullptr), _n(0), _cap(0) { copy_from(o); }
-    device_vector(device_vector &&o) noexcept : _p(o._p), _n(o._n), _cap(o._cap) { o._p = nullptr; o._n = 0; o._cap = 0; }
+    device_vector(device_vector &&o) noexcept : _p(o._p), _n(o._n), _cap(o._cap), _pend(std::move(o._pend)), _pend_idx(o._pend_idx)
+    {
+        o._p = nullptr; o._n = 0; o._cap = 0;
+    }
     device_vector &operator=(const device_vector &o) { if (this != &o) copy_from(o); return *this; }
     device_vector &operator=(device_vector &&o) noexcept
     {
-        if (this != &o) { release(); _p = o._p; _n = o._n; _cap = o._cap; o._p = nullptr; o._n = 0; o._cap = 0; }
+        if (this != &o) {
+            release(); _p = o._p; _n = o._n; _cap = o._cap; _pend = std::move(o._pend); _pend_idx = o._pend_idx;
+            o._p = nullptr; o._n = 0; o._cap = 0;
+        }
         return *this;
     }
     ~device_vector() { release(); }
 
-    size_t size() const { return _n; }
-    bool empty() const { return _n == 0; }
+    size_t size() const { settle(); return _n; }
+    bool empty() const { return size() == 0; }
     T *data() { return _p; }
     const T *data() const { return _p; }
     T *begin() { return _p; }
-    T *end() { return _p + _n; }
+    T *end() { return _p + size(); }
     const T *begin() const { return _p; }
-    const T *end() const { return _p + _n; }
+    const T *end() const { return _p + size(); }
+    //! Deferred size (lazy_count.h): size() will be word `index` of `p` once the device has produced it -- or 0 if one of the
+    //! words before it is 0: an empty level ends its octave (sift/siftfunctions.cu:145). The allocation must already hold the
+    //! largest possible count (reserve_uninitialized).
+    void defer_size(std::shared_ptr<pending_counts> p, int index) { _pend = std::move(p); _pend_idx = index; }
+    bool size_pending() const { return bool(_pend); }
+    //! the pending record (or null): lets the owner check that a deferred size is still the one it installed
+    const std::shared_ptr<pending_counts> &pending_record() const { return _pend; }
+    //! capacity >= n, size and contents untouched (no-op when already large enough; otherwise the contents are lost)
+    void reserve_uninitialized(size_t n)
+    {
+        if (n > _cap) {
+            const size_t keep = size();
+            release();
+            allocate(n);
+            _n = keep < n ? keep : n;
+        }
+    }
     void clear() { release(); }
     void assign(size_t n, const T &value) { release(); allocate(n); fill(value); }
-    void resize(size_t n) { if (n != _n) { release(); allocate(n); zero(); } }
+    void resize(size_t n) { if (n != size()) { release(); allocate(n); zero(); } }
     size_t capacity() const { return _cap; }
     //! size() becomes n WITHOUT touching the device: the allocation is kept while it is large enough (grow-only, with
     //! headroom), the contents are unspecified. For buffers a kernel fills completely right afterwards -- no
@@ -59,6 +84,7 @@ public:
     //! sift/pyramidata.cu:90).
     void resize_uninitialized(size_t n)
     {
+        _pend.reset();
         if (n > _cap) {
             release();
             allocate(n + n / 2 + 64);
@@ -68,6 +94,7 @@ public:
 
     void fill(const T &value)
     {
+        settle();
         if (!_n) return;
         unsigned int w[sizeof(T) / 4];
         std::memcpy(w, &value, sizeof(T));
@@ -83,6 +110,7 @@ public:
     }
     std::vector<T> to_host() const
     {
+        settle();
         std::vector<T> h(_n);
         if (_n) nm_check((int)hipMemcpy(h.data(), _p, _n * sizeof(T), hipMemcpyDeviceToHost), "device_vector D2H");
         return h;
@@ -106,15 +134,33 @@ private:
         _p = nullptr;
         _n = 0;
         _cap = 0;
+        _pend.reset();
+    }
+    //! a deferred size becomes a number: waits for the producing stream (once per pending record)
+    void settle() const
+    {
+        if (!_pend) return;
+        _pend->resolve();
+        bool live = true;
+        for (int k = 0; k < _pend_idx; ++k) live = live && _pend->values[k] != 0;
+        // an empty level ends its octave (sift/siftfunctions.cu:145): the levels behind it count as empty (SURVEY Q9 -- the
+        // reference leaves their previous sizes in place, which nothing reads: compute_descriptors stops at the empty level too)
+        const size_t n = (live && _pend->values[_pend_idx] > 0) ? (size_t)_pend->values[_pend_idx] : 0;
+        _n = n < _cap ? n : _cap;
+        _pend.reset();
     }
     void copy_from(const device_vector &o)
     {
+        o.settle();
         release();
         allocate(o._n);
         if (_n) nm_check((int)hipMemcpy(_p, o._p, _n * sizeof(T), hipMemcpyDeviceToDevice), "device_vector D2D");
     }
     T *_p;
-    size_t _n, _cap;
+    mutable size_t _n;
+    size_t _cap;
+    mutable std::shared_ptr<pending_counts> _pend;
+    int _pend_idx = 0;
 };
 
 }  // namespace nm

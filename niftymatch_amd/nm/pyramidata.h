@@ -6,9 +6,11 @@
 #include <hip/hip_runtime_api.h>
 #include <hip/hip_vector_types.h>
 
+#include <memory>
 #include <vector>
 
 #include "device_vector.h"
+#include "lazy_count.h"
 #include "siftparams.h"
 
 #define MAX_KERNEL_LENGTH 91
@@ -42,11 +44,46 @@ private:
     void release() { if (_p) (void)hipHostFree(_p); _p = nullptr; }
     int *_p;
 };
+
+//! A ring of NM_LAZY_SLOTS x 4 mapped pinned host words for lazy_count.h: a kernel writes a slot, the host reads it after it
+//! has waited for that kernel's stream. A slot is handed out again only once the record that used it last has been resolved
+//! (or dropped). Same value semantics as pinned_counts: a copy starts with a ring of its own, a move takes the ring along.
+class pinned_ring {
+public:
+    enum { SLOTS = 64 };
+    pinned_ring() : _host(nullptr), _dev(nullptr), _next(0) {}
+    pinned_ring(const pinned_ring &) : _host(nullptr), _dev(nullptr), _next(0) {}
+    pinned_ring(pinned_ring &&o) noexcept : _host(o._host), _dev(o._dev), _next(o._next)
+    {
+        for (int i = 0; i < SLOTS; ++i) _last[i] = std::move(o._last[i]);
+        o._host = nullptr; o._dev = nullptr;
+    }
+    pinned_ring &operator=(const pinned_ring &) { return *this; }
+    pinned_ring &operator=(pinned_ring &&o) noexcept
+    {
+        if (this != &o) {
+            release();
+            _host = o._host; _dev = o._dev; _next = o._next;
+            for (int i = 0; i < SLOTS; ++i) _last[i] = std::move(o._last[i]);
+            o._host = nullptr; o._dev = nullptr;
+        }
+        return *this;
+    }
+    ~pinned_ring() { release(); }
+    //! a fresh pending record on `stream`; *dev_words = the slot's four words as the DEVICE addresses them
+    std::shared_ptr<pending_counts> take(hipStream_t stream, int **dev_words);
+
+private:
+    void release();
+    int *_host, *_dev;
+    int _next;
+    std::weak_ptr<pending_counts> _last[SLOTS];
+};
 }  // namespace nm
 
 class PyramidData {
 public:
-    PyramidData() : _base_radius(0), _num_octaves(0), _num_dogs(0), _num_kernels(0) { for (auto &d : _dirty) d = 0; }
+    PyramidData() : _base_radius(0), _num_octaves(0), _num_dogs(0), _num_kernels(0), _lazy_octave(-1) { for (auto &d : _dirty) d = 0; }
     PyramidData(const SiftParams &params);
     // copy / move / destruction: member-wise (every member owns its memory and knows how to copy itself)
 
@@ -79,6 +116,16 @@ public:
     void gpu_collate_keypoints_for_octave(int num_pixels, int counts[3], hipStream_t stream = 0);
     //! compute_keypoints bookkeeping: _key_pts[l][i] may differ from -1 only for i < _dirty[l].
     size_t _dirty[19];
+
+    //! Lazy counts (lazy_count.h): what compute_orientations left pending for compute_descriptors of the same octave -- the
+    //! record its three _orientations sizes wait on, and the octave. Reset by any eager collation.
+    std::shared_ptr<nm::pending_counts> _lazy_rec;
+    int _lazy_octave;
+    //! device words of the collation counts (3 ints, as nm_compact_keypoints3 leaves them)
+    int *lazy_counts_dev() { return _count.data(); }
+    //! the three-level collation without reading the counts back (they stay in lazy_counts_dev())
+    void gpu_collate_keypoints_for_octave_dev(int num_pixels, hipStream_t stream);
+    nm::pinned_ring _ring;
 
 private:
     void generate_kernels(const SiftParams &params);

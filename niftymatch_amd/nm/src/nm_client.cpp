@@ -4,6 +4,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <condition_variable>
@@ -77,7 +78,7 @@ extern "C" int nm_client_copy_semantics(const float *gray, int width, int height
         SiftParams params(width, height);
         const size_t npix = (size_t)width * height;
         nm::device_vector<float> d_gray(std::vector<float>(gray, gray + npix));
-        auto run = [&](PyramidData &py, std::vector<float> &desc) {
+        auto run = [&](PyramidData &py, std::vector<float> &desc) -> int {
             SiftData out(capacity);
             client_frame(params, py, d_gray.data(), out, 0);
             SiftData copy(out), assigned;                  // deep copies: own vectors, own raw pointers
@@ -113,6 +114,81 @@ extern "C" int nm_client_copy_semantics(const float *gray, int width, int height
         return n;
     } catch (const std::exception &e) {
         std::cerr << e.what() << std::endl;
+        return -1;
+    }
+}
+
+// Lazy counts (nm/lazy_count.h) against the reference's observable state. The frame is run three ways with the same per-octave
+// loop: (a) never looking at a count until the end -- no host synchronisation inside the frame; (b) LOOKING after every call, as
+// a curious client may (pydata._orientations[l].size() after compute_orientations, data._num_items after compute_descriptors):
+// every look resolves a pending count; (c) NM_EAGER_COUNTS behaviour (one synchronisation per octave, the counts on the host
+// before compute_orientations returns). watch (host, 4 ints per octave: the three sizes and the running item count) must be
+// identical for (b) and (c), the descriptors / coordinates identical for all three, `pending_seen` reports how many of (b)'s
+// looks found a pending value (> 0: the lazy path was really taken). A capacity below the frame's keypoint count exercises
+// the clipping on the device. Returns the item count, -2 on a mismatch, -1 on an exception.
+extern "C" void nm_set_eager_counts(int on);
+extern "C" int nm_client_lazy_counts(const float *gray, int width, int height, int capacity, int *watch, int max_octaves,
+                                     int *pending_seen)
+{
+    try {
+        SiftParams params(width, height);
+        const size_t npix = (size_t)width * height;
+        nm::device_vector<float> d_gray(std::vector<float>(gray, gray + npix));
+        hipStream_t st = nullptr;
+        nm_check((int)hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "stream");
+        struct Out { int n; std::vector<float> desc, x, y; std::vector<int> watch; int pending; };
+        auto run = [&](int look, bool eager) -> Out {
+            nm_set_eager_counts(eager ? 1 : 0);
+            PyramidData py(params);
+            SiftData out(capacity);
+            Out r{0, {}, {}, {}, std::vector<int>(4 * (size_t)max_octaves, -1), 0};
+            out._num_items = 0;
+            convolve<float>(py._octave[0].data(), d_gray.data(), py._buffer.data(), width, height, py._base_kernel.data(),
+                            py._base_radius, st);
+            for (int o = 0; o < params._num_octaves; ++o) {
+                const int ow = width >> o, oh = height >> o;
+                if (o > 0)
+                    downsample_by_2<float>(py._octave[0].data(), ow, oh, py._octave[3].data(), width >> (o - 1), height >> (o - 1), st);
+                for (int i = 1; i < py._num_octaves; ++i)
+                    convolve<float>(py._octave[i].data(), py._octave[i - 1].data(), py._buffer.data(), ow, oh,
+                                    py._kernels[i - 1].data(), py._kernel_radii[i - 1], st);
+                compute_dog(py, ow, oh, st);
+                compute_gradients(py, params, ow, oh, st);
+                compute_keypoints(py, params, o, ow, oh, st);
+                compute_orientations(py, params, o, ow, oh, st);
+                if (look == 1 && o < max_octaves)
+                    for (int l = 0; l < 3; ++l) {
+                        r.pending += py._orientations[l].size_pending() ? 1 : 0;
+                        r.watch[4 * o + l] = (int)py._orientations[l].size();
+                    }
+                compute_descriptors(py, params, o, ow, oh, out, st);
+                if (look && o < max_octaves) {
+                    r.pending += out._num_items.pending() ? 1 : 0;
+                    r.watch[4 * o + 3] = out._num_items;
+                }
+            }
+            r.n = out._num_items;                              // (a): the one and only look
+            nm_check((int)hipStreamSynchronize(st), "sync");
+            r.desc = out._desc.to_host(); r.x = out._x.to_host(); r.y = out._y.to_host();
+            r.desc.resize((size_t)r.n * 128); r.x.resize(r.n); r.y.resize(r.n);
+            return r;
+        };
+        // d: looks at the item count only -- compute_descriptors then takes the device-sized path in every octave and the look
+        // resolves ITS pending word
+        const Out a = run(0, false), b = run(1, false), c = run(1, true), d = run(2, false);
+        nm_set_eager_counts(0);
+        (void)hipStreamDestroy(st);
+        if (pending_seen) *pending_seen = b.pending + d.pending;
+        for (int o = 0; o < max_octaves; ++o)
+            if (d.watch[4 * o + 3] != c.watch[4 * o + 3]) return -2;
+        if (d.n != a.n || d.desc != a.desc || d.x != a.x || d.y != a.y) return -2;
+        for (int i = 0; watch && i < 4 * max_octaves; ++i) watch[i] = b.watch[i];
+        if (a.n != b.n || a.n != c.n || a.desc != b.desc || a.desc != c.desc || a.x != c.x || a.y != c.y || b.x != c.x) return -2;
+        if (b.watch != c.watch || c.pending != 0) return -2;
+        return a.n;
+    } catch (const std::exception &e) {
+        std::cerr << e.what() << std::endl;
+        nm_set_eager_counts(0);
         return -1;
     }
 }
@@ -168,7 +244,9 @@ extern "C" double nm_client_pair_loop_ex(const float *gray0, const float *gray1,
                 }
             });
         }
+        double trace_us[2] = {0, 0};                        // host time inside the frames' calls / inside compute_sift_matches
         auto pair = [&]() {
+            const auto t0 = std::chrono::steady_clock::now();
             if (streams >= 2) {
                 { std::lock_guard<std::mutex> lk(mu); ++posted; }
                 cv.notify_all();
@@ -179,7 +257,11 @@ extern "C" double nm_client_pair_loop_ex(const float *gray0, const float *gray1,
                 client_frame(params, py, gray0, a, st);
                 client_frame(params, py, gray1, b, st);
             }
+            const auto t1 = std::chrono::steady_clock::now();
             compute_sift_matches(&a, &b, with_distance ? dist.data() : nullptr, 0.8f, st);
+            const auto t2 = std::chrono::steady_clock::now();
+            trace_us[0] += std::chrono::duration<double, std::micro>(t1 - t0).count();
+            trace_us[1] += std::chrono::duration<double, std::micro>(t2 - t1).count();
         };
         // Runs on EVERY way out of this scope, an exception thrown by pair() included: a joinable std::thread that is
         // destroyed calls std::terminate, and the streams would leak.
@@ -198,6 +280,7 @@ extern "C" double nm_client_pair_loop_ex(const float *gray0, const float *gray1,
         } cleanup{worker, mu, cv, quit, st, st1};
         double us = -1.0;
         pair();                                                       // warm-up (workspace growth, code loading)
+        trace_us[0] = trace_us[1] = 0;
         if (hipDeviceSynchronize() == hipSuccess) {
             const auto t0 = std::chrono::steady_clock::now();
             for (int r = 0; r < reps; ++r) pair();
@@ -205,6 +288,9 @@ extern "C" double nm_client_pair_loop_ex(const float *gray0, const float *gray1,
                 us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
         }
         { std::lock_guard<std::mutex> lk(mu); if (failed) return -1.0; }
+        if (getenv("NM_CLIENT_TRACE") && reps > 0)
+            std::cerr << "client loop: host inside the two frames' calls " << trace_us[0] / reps << " us, inside compute_sift_matches "
+                      << trace_us[1] / reps << " us per pair" << std::endl;
         if (n_out && us >= 0) {
             n_out[0] = a._num_items; n_out[1] = b._num_items;
             std::vector<int> m = a._match_indexes.to_host();

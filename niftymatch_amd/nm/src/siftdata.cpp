@@ -4,7 +4,7 @@
 #include <stdexcept>
 
 SiftData::SiftData(int capacity)
-    : _x_ptr(nullptr), _y_ptr(nullptr), _match_indexes_ptr(nullptr), _num_items(0), _capacity(0)
+    : _x_ptr(nullptr), _y_ptr(nullptr), _match_indexes_ptr(nullptr), _num_items(0), _capacity(0), _items_cur(0)
 {
     if (capacity <= 0) throw std::runtime_error("Invalid initialization of SIFT data");
     initialize_data(capacity);
@@ -22,7 +22,9 @@ void SiftData::copy_from(const SiftData &in)
     _y_ptr = _y.data();
     _match_indexes_ptr = _match_indexes.data();
     _capacity = in._capacity;
-    _num_items = in._num_items;
+    _num_items = in._num_items;                   // (reads a pending count back: the copy starts from a host value)
+    _items_dev = in._items_dev.size() ? nm::device_vector<int>(2) : nm::device_vector<int>();    // (empty containers own nothing)
+    _items_cur = 0;
 }
 
 void SiftData::initialize_data(int capacity)
@@ -37,6 +39,8 @@ void SiftData::initialize_data(int capacity)
     _match_indexes_ptr = _match_indexes.data();
     _capacity = capacity;
     _num_items = 0;
+    _items_dev = nm::device_vector<int>(2);
+    _items_cur = 0;
 }
 
 void SiftData::clear_data()
@@ -47,5 +51,8 @@ void SiftData::clear_data()
     _y.clear();
     _x_ptr = _y_ptr = nullptr;
     _match_indexes_ptr = nullptr;
-    _num_items = _capacity = 0;
+    _num_items = 0;
+    _capacity = 0;
+    _items_dev.clear();
+    _items_cur = 0;
 }

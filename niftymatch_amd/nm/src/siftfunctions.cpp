@@ -4,6 +4,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <memory>
 
 #include "../../../include/nm_abi.h"
 #include "../cudamath.h"
@@ -37,6 +38,10 @@ static bool async_matches()
     }
     return v == 1;
 }
+// (the legacy NULL stream synchronises with every blocking stream: nothing special to do for it -- the name keeps the call
+// site honest about what it checks)
+static bool stream_is_capturing(hipStream_t stream);
+static bool stream_is_capturing_or_null_legacy(hipStream_t stream) { return stream_is_capturing(stream); }
 static bool stream_is_capturing(hipStream_t stream)
 {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
@@ -44,8 +49,53 @@ static bool stream_is_capturing(hipStream_t stream)
     return st != hipStreamCaptureStatusNone;
 }
 
+// Lazy counts (nm/lazy_count.h): NM_EAGER_COUNTS=1 (or nm_set_eager_counts(1)) restores one host synchronisation per octave.
+static std::atomic<int> g_eager_counts{-1};
+extern "C" __attribute__((visibility("default"))) void nm_set_eager_counts(int on) { g_eager_counts.store(on ? 1 : 0); }
+static bool eager_counts()
+{
+    int v = g_eager_counts.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("NM_EAGER_COUNTS");
+        int expected = -1;
+        g_eager_counts.compare_exchange_strong(expected, (e && e[0] == '1') ? 1 : 0);
+        v = g_eager_counts.load(std::memory_order_relaxed);
+    }
+    return v == 1;
+}
+
+// The device word that holds a container's item count for a device-sized launch: the pending count's own word, or -- when
+// the host value is the authority -- that value written into the container's spare word on `stream`.
+static const int *items_on_device(SiftData *S, hipStream_t stream)
+{
+    if (S->_items_dev.size() < 2) S->_items_dev = nm::device_vector<int>(2);
+    if (S->_num_items.pending()) return S->_items_dev.data() + S->_items_cur;
+    int *w = S->_items_dev.data() + (S->_items_cur ^ 1);
+    nm_check(nm_fill_u32(w, 1, (unsigned)S->_num_items.host_value(), stream), "item count upload");
+    return w;
+}
+
 void compute_sift_matches(SiftData *A, SiftData *B, float *distance, float ambiguity, hipStream_t stream)
 {
+    if (!distance && (A->_num_items.pending() || B->_num_items.pending()) && A->_capacity > 0 && B->_capacity > 0) {
+        // Neither count has been read back (lazy_count.h) and no matrix is asked for: the matcher reads both sizes on the
+        // device (nm_sift_match_batch_dev_f32) -- no host synchronisation between compute_descriptors and the match.
+        const size_t need = nm_sift_match_batch_dev_workspace_bytes(1, A->_capacity, B->_capacity) / sizeof(int) + 1;
+        if (A->_match_workspace.size() < need) {
+            if (stream_is_capturing(stream)) RUNTIME_EXCEPTION("compute_sift_matches: the match workspace cannot grow under stream capture");
+            nm_check((int)hipStreamSynchronize(stream), "SIFT matching failed");
+            A->_match_workspace = nm::device_vector<int>();
+            A->_match_workspace = nm::device_vector<int>(need);
+        }
+        const float *pa = A->_desc.data(), *pb = B->_desc.data();
+        const int *na = items_on_device(A, stream), *nb = items_on_device(B, stream);
+        int *res = A->_match_indexes.data();
+        nm_check(nm_sift_match_batch_dev_f32(1, &pa, &na, &pb, &nb, A->_capacity, B->_capacity, &res, ambiguity,
+                                             A->_match_workspace.data(), stream),
+                 "SIFT matching failed");
+        if (!async_matches() && !stream_is_capturing(stream)) nm_check((int)hipStreamSynchronize(stream), "SIFT matching failed");
+        return;
+    }
     const int A_size = A->_num_items;
     const int B_size = B->_num_items;
     if (A_size <= 0 || B_size <= 0) return;
@@ -160,6 +210,27 @@ void compute_orientations(PyramidData &pydata, const SiftParams &params, const i
 {
     const float xper = std::pow(2.0, octave);
     const int num_pixels_for_octave = octave_width * octave_height;
+    if (params._num_dog_levels == 3 && !eager_counts() && !stream_is_capturing_or_null_legacy(stream)) {
+        // Lazy counts (nm/lazy_count.h): the collation's three counts stay on the device, the orientation kernel reads them
+        // there, and _orientations[l].size() becomes pending -- no host synchronisation in this call.
+        pydata.gpu_collate_keypoints_for_octave_dev(num_pixels_for_octave, stream);
+        int *words = nullptr;
+        std::shared_ptr<nm::pending_counts> rec = pydata._ring.take(stream, &words);
+        const float *kp[3];
+        float *res[3];
+        for (int i = 0; i < 3; ++i) {
+            pydata._orientations[i].reserve_uninitialized(pydata._collated_kpts[i].size());
+            kp[i] = reinterpret_cast<const float *>(pydata._collated_kpts[i].data());
+            res[i] = reinterpret_cast<float *>(pydata._orientations[i].data());
+        }
+        nm_check(nm_detect_orientations_levels_dev(kp, pydata.lazy_counts_dev(), num_pixels_for_octave,
+                                                   reinterpret_cast<const float *>(pydata._grad.data()), octave_width,
+                                                   octave_height, 1.5f, xper, res, words, stream),
+                 "Orientation histogram launch failed");
+        for (int i = 0; i < 3; ++i) pydata._orientations[i].defer_size(rec, i);
+        pydata._lazy_rec = rec; pydata._lazy_octave = octave;
+        return;
+    }
     if (params._num_dog_levels == 3) {
         // one batched collation and ONE host synchronisation for the octave (the reference synchronises per level)
         int counts[3];
@@ -167,6 +238,7 @@ void compute_orientations(PyramidData &pydata, const SiftParams &params, const i
         const float *kp[3];
         float *res[3];
         int n[3], levels = 0;
+        for (int i = 0; i < 3; ++i) pydata._orientations[i].resize_uninitialized(0);   // levels behind an empty one count as empty (Q9)
         for (int i = 0; i < 3; ++i) {
             pydata._orientations[i].resize_uninitialized((size_t)counts[i]);
             if (counts[i] == 0) break;                     // an empty level ends the octave (siftfunctions.cu:145)
@@ -195,6 +267,34 @@ void compute_descriptors(PyramidData &pydata, const SiftParams &params, const in
     const float *kp[3], *ori[3];
     float *desc[3], *xs[3], *ys[3];
     int n[3], levels = 0;
+    // Lazy counts: compute_orientations of THIS octave left its counts on the device and nobody has looked at them since --
+    // the descriptor kernel reads them (and the running item count) there; data._num_items becomes pending.
+    const std::shared_ptr<nm::pending_counts> &rec = pydata._lazy_rec;
+    if (params._num_dog_levels == 3 && rec && !rec->resolved && pydata._lazy_octave == octave &&
+        pydata._orientations[0].pending_record() == rec && pydata._orientations[1].pending_record() == rec &&
+        pydata._orientations[2].pending_record() == rec && data._capacity > 0) {
+        if (data._items_dev.size() < 2) data._items_dev = nm::device_vector<int>(2);
+        const int capacity = (int)(data._desc.size() / SIFT_VECTOR_SIZE);
+        const bool dev_base = data._num_items.pending();
+        const int *base_in = dev_base ? data._items_dev.data() + data._items_cur : nullptr;
+        int *items_out = data._items_dev.data() + (data._items_cur ^ 1);
+        int *words = nullptr;
+        std::shared_ptr<nm::pending_counts> items = pydata._ring.take(stream, &words);
+        for (int i = 0; i < 3; ++i) {
+            kp[i] = reinterpret_cast<const float *>(pydata._collated_kpts[i].data());
+            ori[i] = reinterpret_cast<const float *>(pydata._orientations[i].data());
+        }
+        const int bound = octave_width * octave_height;
+        nm_check(nm_compute_sift_descriptors_levels_dev(kp, ori, pydata.lazy_counts_dev(), bound, base_in,
+                                                        dev_base ? 0 : data._num_items.host_value(), capacity, items_out,
+                                                        words + 3, reinterpret_cast<const float *>(pydata._grad.data()),
+                                                        octave_width, octave_height, params._num_dog_levels, xper,
+                                                        data._desc.data(), data._x.data(), data._y.data(), stream),
+                 "SIFT descriptor detection launch failed");
+        data._items_cur ^= 1;
+        data._num_items.defer(items);
+        return;
+    }
     for (int i = 0; i < params._num_dog_levels; ++i) {
         if (pydata._orientations[i].size() == 0) break;       // siftfunctions.cu:160
         int num_pts = (int)pydata._orientations[i].size();

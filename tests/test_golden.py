@@ -53,7 +53,15 @@ def test_hip_path_hits_golden(nm, cuda, path):
     res, D = nm.sift_match(a0.desc, a1.desc, 0.8, want_distance=True, nA=n0, nB=n1)
     torch.cuda.synchronize()
     assert np.array_equal(res.cpu().numpy(), g["match"])
-    assert np.array_equal(D[0].cpu().numpy(), g["dist_row0"])
+    H.assert_distance(nm, D[0], g["dist_row0"], "distance row 0 (default mode: fp32 MFMA, 1e-4 relative)")
+    before = nm.get_distance_mode()
+    try:                                                  # the exact kernel: bit for bit
+        nm.set_distance_mode("exact")
+        res, D = nm.sift_match(a0.desc, a1.desc, 0.8, want_distance=True, nA=n0, nB=n1)
+        torch.cuda.synchronize()
+        assert np.array_equal(res.cpu().numpy(), g["match"]) and np.array_equal(D[0].cpu().numpy(), g["dist_row0"])
+    finally:
+        nm.set_distance_mode(before)
     m1, ix, m2 = nm.sift_match_shard(a0.desc[:n0].contiguous(), a1.desc[:n1].contiguous(), 0)
     assert np.array_equal(ix.cpu().numpy(), g["idx"]) and np.array_equal(m1.cpu().numpy(), g["min1"])
     assert np.array_equal(m2.cpu().numpy(), g["min2"])

@@ -144,3 +144,30 @@ def test_pyramiddata_and_siftdata_value_semantics(nm, oracle, cuda):
     ref = oracle.sift_detect_describe(f, cap)
     n = nm.lib().nm_client_copy_semantics(np.ascontiguousarray(f).ctypes.data, w, h, cap)
     assert n == ref["n"] and n > 100
+
+
+@pytest.mark.parametrize("wh,cap", [((640, 480), 8192), ((320, 240), 300), ((1920, 1080), 16384)])
+def test_lazy_counts_show_the_reference_observable_state(nm, oracle, cuda, wh, cap):
+    """nm/lazy_count.h: the per-octave client loop no longer synchronises per octave -- the keypoint counts stay on the device
+    and _orientations[l].size() / SiftData::_num_items resolve at their first host-visible read (the reference reads them back
+    once per level, sift/pyramidata.cu:84-91, siftfunctions.cu:165-178). A client that looks after every call must see the
+    numbers the eager path (one synchronisation per octave) shows, a client that never looks must end with the same
+    descriptors, and both must equal the oracle; cap = 300 clips in the middle of a level ON THE DEVICE."""
+    w, h = wh
+    f = np.ascontiguousarray(H.blurred_frame(7, w, h))
+    ref = oracle.sift_detect_describe(f, cap)
+    n_oct = ref["counts"].shape[0]
+    watch = (C.c_int * (4 * n_oct))()
+    pending = C.c_int(0)
+    n = nm.lib().nm_client_lazy_counts(f.ctypes.data, w, h, cap, watch, n_oct, C.byref(pending))
+    assert n == ref["n"] and (n == cap or cap > 5000)
+    assert pending.value >= 4 * n_oct, "the lazy path was not taken"      # 3 sizes + 1 item count per octave
+    # what the curious client saw: the level sizes are the oracle's accepted counts per (octave, level) -- an empty level ends
+    # its octave -- and the running item count is their clipped running sum
+    run = 0
+    for o in range(n_oct):
+        cnt = [int(c) for c in ref["counts"][o]]
+        for l in range(3):
+            assert watch[4 * o + l] == cnt[l], (o, l)
+        run = min(cap, run + sum(cnt))
+        assert watch[4 * o + 3] == run, o

@@ -100,12 +100,21 @@ def test_match_batch_16_pairs_on_real_descriptors(nm, oracle, cuda, bench16):
         assert np.array_equal(t[1].cpu().numpy(), ix)
         _eq(t[2], m2, "min2 pair %d" % k)
         if k == 0:
-            res, D = nm.sift_match(arenas[a].desc, arenas[b].desc, 0.8, want_distance=True, workspace=ws1,
-                                   nA=cnt[a], nB=cnt[b])
-            torch.cuda.synchronize()
-            assert np.array_equal(res[:cnt[a]].cpu().numpy(), ref)
-            _eq(D, Dref, "materialised 12k x 12k distance matrix")
-            del D
+            before = nm.get_distance_mode()
+            try:
+                for mode in ("mfma", "exact"):            # fp32 MFMA pass: every entry within 1e-4 relative; exact kernel: bit for bit
+                    nm.set_distance_mode(mode)
+                    res, D = nm.sift_match(arenas[a].desc, arenas[b].desc, 0.8, want_distance=True, workspace=ws1,
+                                           nA=cnt[a], nB=cnt[b])
+                    torch.cuda.synchronize()
+                    assert np.array_equal(res[:cnt[a]].cpu().numpy(), ref)
+                    H.assert_distance(nm, D, Dref, "materialised 12k x 12k distance matrix (%s)" % mode)
+                    if mode == "mfma":                    # real SIFT descriptors: the listed blocks fit the list by a wide margin
+                        listed, cap = nm.match_distance_listed(ws1, cnt[a], cnt[b])
+                        assert 0 <= listed < cap // 4, (listed, cap)
+                    del D
+            finally:
+                nm.set_distance_mode(before)
     # the last call on ws1 was the shard call of pair 9: real SIFT descriptors rarely need the exact fallback
     assert 0 <= nm.match_fallback_count(ws1, cnt[pairs[9][0]], cnt[pairs[9][1]]) < 200
 
