@@ -801,6 +801,54 @@ def main():
         except Exception as exc:
             dropin = {"error": repr(exc)}
 
+    # the materialised N x M distance matrix of compute_sift_matches on pair 0's real descriptors (nm_sift_match_f32 with
+    # `distance`): the fp32 MFMA pass (distance_mfma_kernel, library profile site) and the whole call, beside the exact VALU
+    # kernel's call; its own roofline entry -- MFMA fp32 by the 2 N M 128 flops, and the N x M x 4 bytes it writes
+    dist_roof = None
+    if rank == 0 and not args.no_dropin:
+        try:
+            nm.detect_describe_batch(arenas[:2], frames[:2])
+            torch.cuda.synchronize()
+            dA, dB = int(arenas[0].num_items.item()), int(arenas[1].num_items.item())
+            wsd = nm.MatchWorkspace(dA, dB, dev)
+            Dm = torch.empty((dA, dB), dtype=torch.float32, device=dev)
+            rd = torch.full((dA,), -1, dtype=torch.int32, device=dev)
+            before = nm.get_distance_mode()
+            times = {}
+            for mode in ("mfma", "exact"):
+                nm.set_distance_mode(mode)
+                ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(12)]
+                for q in ev:
+                    for e in q:
+                        e.record()
+                for q in ev:
+                    nm.profile_events(nm.PROF_DISTANCE, q[2], q[3])
+                    q[0].record()
+                    nm._check(nm.lib().nm_sift_match_f32(arenas[0].desc.data_ptr(), dA, arenas[1].desc.data_ptr(), dB, Dm.data_ptr(),
+                                                         rd.data_ptr(), 0.8, wsd.buf.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                              "nm_sift_match_f32")
+                    q[1].record()
+                    nm.profile_events(nm.PROF_DISTANCE, None, None)
+                torch.cuda.synchronize()
+                call = sorted(q[0].elapsed_time(q[1]) for q in ev[2:])
+                kern = sorted(q[2].elapsed_time(q[3]) for q in ev[2:])
+                times[mode] = (call[len(call) // 2], kern[len(kern) // 2])
+            nm.set_distance_mode(before)
+            listed, cap = nm.match_distance_listed(wsd, dA, dB)
+            fl, k_ms = 256.0 * dA * dB, times["mfma"][1]
+            dist_roof = {"kernel": "distance_mfma_kernel", "bound": "mfma", "achieved": round(fl / (k_ms * 1e-3) / 1e12, 3),
+                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / (k_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                         "avg_ms": round(k_ms, 4), "shape": [dA, dB, 128], "bytes_written": 4.0 * dA * dB,
+                         "write_GBps": round(4.0 * dA * dB / (k_ms * 1e-3) / 1e9, 1),
+                         "call_us_mfma": round(1e3 * times["mfma"][0], 1), "call_us_exact_kernel": round(1e3 * times["exact"][0], 1),
+                         "blocks_listed_for_exact_recompute": listed, "blocks_total": ((dA + 31) // 32) * ((dB + 31) // 32),
+                         "note": "median of 10 nm_sift_match_f32 calls with `distance` on pair 0's descriptors; kernel = the library's "
+                                 "profile site around distance_mfma_kernel; call = centring + MFMA pass + fix-up + the fused match. Every "
+                                 "entry within 1e-4 relative of the reference's chain (tests/test_gpu_match.py)"}
+            del Dm, wsd
+        except Exception as exc:
+            dist_roof = {"error": repr(exc)}
+
     detect256 = None
     if not args.no_detect256:
         try:
@@ -921,6 +969,10 @@ def main():
             out["latency"] = latency
         if dropin is not None:
             out["dropin_api"] = dropin
+        if dist_roof is not None:
+            out["roofline_distance"] = dist_roof
+            head["roofline_distance_frac"] = dist_roof.get("frac")
+            head["distance_12k_us"] = (round(1e3 * dist_roof["avg_ms"], 1) if dist_roof.get("avg_ms") else None)
         if detect256 is not None:
             out["detect_256"] = detect256
         if extra is not None:

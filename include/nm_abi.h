@@ -95,6 +95,17 @@ NM_API int nm_selftest_expw(unsigned long long *d_out, void *stream);
  *   [10] chain launches of 1024 chains each                            [11] same-half truncation probe, ulp above 1 */
 #define NM_SELFTEST_MFMA_OUTPUTS 16
 NM_API int nm_selftest_mfma_model(int instruction, int n_random, int n_chains, float *d_out, void *stream);
+/* The same for the fp32 instruction v_mfma_f32_32x32x2_f32 (the matcher's fp32 screen; the materialised distance pass of
+ * nm_sift_match_f32): about n_random single results and n_chains x 1024 accumulator chains against binary64. d_out: 8 floats:
+ *   [0] max |D - exact| / (2^-24 (|C| + |a0 b0| + |a1 b1|)) (<= 2 = two roundings: the premise of both bounds)
+ *   [1] results equal to fma(a1, b1, fma(a0, b0, C))    [2] results equal to the correctly rounded exact sum    [5] results tested
+ *   [3] the distance pass's form (two chains of 64 k-steps + one add): max |v - exact| / (sqrt na + sqrt nb)^2, to be held
+ *       against nm_sift_match_distance_budget()    [4] the fp32 screen's form (one 130-step chain), against
+ *       nm_sift_match_accum_budget(0) */
+NM_API int nm_selftest_mfma_f32(int n_random, int n_chains, float *d_out, void *stream);
+/* DIST_C of the MFMA distance pass (HOST function): |value - exact distance of the centred rows| <= DIST_C (sqrt nx + sqrt ny)^2
+ * is what its acceptance test assumes; 67 + 8 roundings' worth with 15 % of slack. */
+NM_API float nm_sift_match_distance_budget(void);
 /* What the finalize pass budgets for the accumulation error of a screen's MFMA chain, as a multiple of
  * (sqrt na + sqrt nb)^2 (HOST function; screen: 0 = fp32, 1 = bf16x3, 2 = two-stage coarse pass): the share of
  * screen_err_coeff that is a hardware premise rather than arithmetic. The self-test's [8] must stay below half of it. */

@@ -87,6 +87,8 @@ _SIGNATURES = {
     "nm_selftest_expw": (_I, [_P, _P]),
     "nm_selftest_mfma_model": (_I, [_I, _I, _I, _P, _P]),
     "nm_sift_match_accum_budget": (_F, [_I]),
+    "nm_selftest_mfma_f32": (_I, [_I, _I, _P, _P]),
+    "nm_sift_match_distance_budget": (_F, []),
     "nm_undistort_map_f32": (_I, [_P, _P, _SZ, _SZ, _P, _P, _P, _P, _P]),
     "nm_resample_undistort_f32": (_I, [_P, _I, _I, _I, _P, _P, _SZ, _SZ, _P, _P]),
     "nm_resample_mask_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P]),
@@ -589,6 +591,21 @@ def selftest_mfma_model(instruction, n_random=1 << 20, n_chains=4096):
             "one_plus_15_small_ulp": v[3], "c2p24_plus_16": v[4], "rel_u": v[5], "model_ratio": v[6],
             "instructions": v[7], "chain_coeff": v[8], "chain_coeff_subnormal": v[9], "chain_launches": v[10],
             "same_half_truncation_ulp": v[11]}
+
+
+def selftest_mfma_f32(n_random=1 << 22, n_chains=2048):
+    """nm_selftest_mfma_f32: rounding of v_mfma_f32_32x32x2_f32 on this device (single instructions and the two accumulation
+    forms the library issues), against binary64."""
+    torch = _torch()
+    out = torch.zeros(8, dtype=torch.float32, device="cuda")
+    _check(lib().nm_selftest_mfma_f32(int(n_random), int(n_chains), _dev(out), _stream()), "nm_selftest_mfma_f32")
+    v = [float(x) for x in out.cpu()]
+    return {"rel_u": v[0], "frac_fma_chain": v[1] / max(v[5], 1.0), "frac_correctly_rounded": v[2] / max(v[5], 1.0),
+            "two_chain_coeff": v[3], "one_chain_coeff": v[4], "results": v[5]}
+
+
+def match_distance_budget():
+    return float(lib().nm_sift_match_distance_budget())
 
 
 def match_accum_budget(screen):

@@ -2472,6 +2472,8 @@ int nm_sift_match_set_screen(int screen)
 }
 int nm_sift_match_get_screen(void) { return match_screen(); }
 
+float nm_sift_match_distance_budget(void) { return DIST_C; }
+
 int nm_sift_match_set_distance_mode(int mode)
 {
     if (mode < 0 || mode > 1) return (int)hipErrorInvalidValue;

@@ -341,7 +341,140 @@ __global__ __launch_bounds__(64) void selftest_chain_kernel(float *__restrict__ 
     }
 }
 
+// ---- the fp32 instruction: v_mfma_f32_32x32x2_f32 (the matcher's fp32 screen and the materialised distance pass) ----
+// Premise of both bounds: one instruction D = C + a0 b0 + a1 b1 behaves like two fused steps -- exact
+// products, at most two roundings -- so that a chain of n instructions is a 2n-step fma chain.
+//   out[0] = max |D - exact| / (u (|C| + |a0 b0| + |a1 b1|)) over random instructions (<= 2: two roundings; <= 1: one)
+//   out[1] / out[2] = instructions whose result equals fma(a1, b1, fma(a0, b0, C)) / the correctly rounded exact sum
+//   out[3] = the distance pass's form -- two chains (k = 0..63 behind the norm pair, k = 64..127 from 0) and one add -- on
+//            row families (uniform, constant, near-duplicates, mixed binades): max |v - exact of the same operands| /
+//            (sqrt na + sqrt nb)^2, to be held against DIST_C (nm_match.hip; 5.15e-6 incl. the norms' own 8 roundings)
+//   out[4] = the fp32 screen's form (one 130-step chain), same ratio, against nm_sift_match_accum_budget(0)
+//   out[5] = random instructions run
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(64) void selftest_f32_kernel(float *__restrict__ out, int iters)
+{
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    unsigned long long s = 0xD1B54A32D192ED03ull * ((unsigned long long)blockIdx.x * 64 + lane + 1);
+    const double U = 5.9604644775390625e-08;
+    __shared__ float sA[32][2], sB[32][2];
+    auto rnd_f = [&](int binades) {
+        const unsigned a = rng(s), e = rng(s) % (unsigned)binades;
+        return __uint_as_float((a & 0x807FFFFFu) | ((120u + e) << 23));
+    };
+    float worst = 0.f;
+    unsigned n_chain = 0, n_rn = 0, n_all = 0;
+    for (int it = 0; it < iters; ++it) {
+        const float av = rnd_f(12), bv = rnd_f(12);           // this lane's A operand (row r, k = h) and B operand (column r, k = h)
+        sA[r][h] = av; sB[r][h] = bv;
+        f32x16s c, d;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c[e] = (rng(s) & 3u) ? rnd_f(14) : 0.0f;
+        __syncthreads();
+        d = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, c, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = acc_row(e, h);
+            const double p0 = (double)sA[m][0] * (double)sB[r][0], p1 = (double)sA[m][1] * (double)sB[r][1];
+            const double ex = ((double)c[e] + p0) + p1;       // (three binary64 terms: good to 2^-52 of their magnitude)
+            const double mag = fabs((double)c[e]) + fabs(p0) + fabs(p1);
+            const float rel = (float)(fabs((double)d[e] - ex) / (U * mag));
+            worst = fmaxf(worst, rel);
+            const float chain = __builtin_fmaf(sA[m][1], sB[r][1], __builtin_fmaf(sA[m][0], sB[r][0], c[e]));
+            n_chain += (__float_as_uint(chain) == __float_as_uint(d[e])) ? 1u : 0u;
+            n_rn += (__float_as_uint((float)ex) == __float_as_uint(d[e])) ? 1u : 0u;
+            ++n_all;
+        }
+        __syncthreads();
+    }
+    for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+        worst = fmaxf(worst, __shfl_xor(worst, dlt));
+        n_chain += __shfl_xor(n_chain, dlt); n_rn += __shfl_xor(n_rn, dlt); n_all += __shfl_xor(n_all, dlt);
+    }
+    if (lane == 0) {
+        atomic_max_pos(out + 0, worst);
+        atomicAdd(out + 1, (float)n_chain); atomicAdd(out + 2, (float)n_rn); atomicAdd(out + 5, (float)n_all);
+    }
+}
+
+// 32 x 32 pairs of 128-element rows per block: the two accumulation forms against binary64 on the same operands
+__global__ __launch_bounds__(64) void selftest_f32_chain_kernel(float *__restrict__ out, int iters)
+{
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    unsigned long long s = 0x9E3779B97F4A7C15ull * ((unsigned long long)blockIdx.x * 64 + lane + 7);
+    __shared__ float sX[32][129], sY[32][129];
+    __shared__ float nX[32], nY[32];
+    float worst2 = 0.f, worst1 = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        const int fam = (blockIdx.x + it) % 5;
+        const float scale = __uint_as_float((unsigned)(127 - 20 + (int)(rng(s) % 40u)) << 23);      // 2^-20 .. 2^19
+        for (int k = h; k < 128; k += 2) {                    // lane (r, h) fills half of row r of both sets
+            const float u01 = (float)(rng(s) & 0xFFFFFF) * (1.0f / 16777216.0f), v01 = (float)(rng(s) & 0xFFFFFF) * (1.0f / 16777216.0f);
+            float x, y;
+            if (fam == 0) { x = u01; y = v01; }                                      // uniform, all-positive
+            else if (fam == 1) { x = 0.75f; y = 0.75f + 0x1p-20f * (float)(r & 3); } // constant rows: every product rounds alike
+            else if (fam == 2) { x = u01 - 0.5f; y = x * (1.0f + 0x1p-12f * (v01 - 0.5f)); }   // near-duplicates: massive cancellation
+            else if (fam == 3) { x = (u01 - 0.5f) * __uint_as_float((unsigned)(127 - 12 + (k % 24)) << 23); y = (v01 - 0.5f) * __uint_as_float((unsigned)(127 - 12 + ((k * 7) % 24)) << 23); }
+            else { x = u01 - 0.5f; y = v01 - 0.5f; }                                 // centred
+            sX[r][k] = x * scale; sY[r][k] = y * scale;
+        }
+        __syncthreads();
+        if (h == 0) {
+            float a = 0.f, b = 0.f;
+            for (int k = 0; k < 128; ++k) { a = __builtin_fmaf(sX[r][k], sX[r][k], a); b = __builtin_fmaf(sY[r][k], sY[r][k], b); }
+            nX[r] = a; nY[r] = b;
+        }
+        __syncthreads();
+        // rows of the result = X (A operand), columns = Y (B operand, scaled by -2), as distance_mfma_kernel issues it
+        f32x16s a0, b0, c1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { a0[e] = 0.f; b0[e] = 0.f; c1[e] = 0.f; }
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? 1.0f : nX[r], h ? nY[r] : 1.0f, a0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? 1.0f : nX[r], h ? nY[r] : 1.0f, c1, 0, 0, 0);
+        for (int k = 0; k < 64; k += 2) {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(sX[r][k + h], -2.0f * sY[r][k + h], a0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sX[r][k + h], -2.0f * sY[r][k + h], c1, 0, 0, 0);
+        }
+        for (int k = 64; k < 128; k += 2) {
+            b0 = __builtin_amdgcn_mfma_f32_32x32x2f32(sX[r][k + h], -2.0f * sY[r][k + h], b0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sX[r][k + h], -2.0f * sY[r][k + h], c1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = acc_row(e, h);
+            double ex = (double)nX[m] + (double)nY[r], comp = 0.0;
+            for (int k = 0; k < 128; ++k) {                   // Kahan in binary64: exact to far below a binary32 ulp
+                const double t = -2.0 * (double)sX[m][k] * (double)sY[r][k] - comp, nsum = ex + t;
+                comp = (nsum - ex) - t; ex = nsum;
+            }
+            const double sq = sqrt((double)nX[m]) + sqrt((double)nY[r]);
+            const double den = sq * sq;
+            if (den > 0.0) {
+                worst2 = fmaxf(worst2, (float)(fabs((double)(a0[e] + b0[e]) - ex) / den));
+                worst1 = fmaxf(worst1, (float)(fabs((double)c1[e] - ex) / den));
+            }
+        }
+        __syncthreads();
+    }
+    for (int dlt = 32; dlt >= 1; dlt >>= 1) { worst2 = fmaxf(worst2, __shfl_xor(worst2, dlt)); worst1 = fmaxf(worst1, __shfl_xor(worst1, dlt)); }
+    if (lane == 0) { atomic_max_pos(out + 3, worst2); atomic_max_pos(out + 4, worst1); }
+}
+
 }  // namespace
+
+extern "C" int nm_selftest_mfma_f32(int n_random, int n_chains, float *d_out, void *stream)
+{
+    if (!d_out || n_random < 0 || n_chains < 0) return (int)hipErrorInvalidValue;
+    hipStream_t st = nm_stream(stream);
+    NM_RETURN_IF(hipMemsetAsync(d_out, 0, 8 * sizeof(float), st));
+    const int blocks1 = 1024, it1 = (n_random / 1024 + blocks1 - 1) / blocks1;      // 1024 results per wave-instruction
+    if (it1) hipLaunchKernelGGL(selftest_f32_kernel, dim3(blocks1), dim3(64), 0, st, d_out, it1);
+    NM_LAUNCH_CHECK();
+    const int blocks2 = 512, it2 = (n_chains + blocks2 - 1) / blocks2;
+    if (it2) hipLaunchKernelGGL(selftest_f32_chain_kernel, dim3(blocks2), dim3(64), 0, st, d_out, it2);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int nm_selftest_mfma_model(int instruction, int n_random, int n_chains, float *d_out, void *stream)
 {

@@ -169,7 +169,15 @@ def test_cpp_api_match_with_and_without_distance(nm, oracle, cuda):
     D = np.zeros((700, 450), np.float32)
     assert nm.lib().nm_client_match(A.ctypes.data, 700, B.ctypes.data, 450, D.ctypes.data, res.ctypes.data, 0.8) == 0
     assert np.array_equal(res, ref)
-    _eq(D, Dref, "distance matrix via the C++ API")
+    H.assert_distance(nm, D, Dref, "distance matrix via the C++ API (default: fp32 MFMA pass, 1e-4 relative)")
+    before = nm.get_distance_mode()
+    try:                                                  # the exact kernel behind the switch: bit for bit
+        nm.set_distance_mode("exact")
+        assert nm.lib().nm_client_match(A.ctypes.data, 700, B.ctypes.data, 450, D.ctypes.data, res.ctypes.data, 0.8) == 0
+        assert np.array_equal(res, ref)
+        _eq(D, Dref, "distance matrix via the C++ API, exact kernel")
+    finally:
+        nm.set_distance_mode(before)
     res2 = np.full(700, -1, np.int32)
     assert nm.lib().nm_client_match(A.ctypes.data, 700, B.ctypes.data, 450, None, res2.ctypes.data, 0.8) == 0
     assert np.array_equal(res2, ref)

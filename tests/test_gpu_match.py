@@ -718,3 +718,18 @@ def test_distance_on_the_mfma_every_entry_within_1e_4(nm, oracle, cuda, screen):
     A, B = H.synth.descriptors(8, 300), H.synth.descriptors(9, 300)
     B[17, 5] = np.nan; A[3, 100] = np.inf
     run(A, B, "NaN / inf rows")
+
+
+def test_fp32_mfma_rounding_is_inside_what_the_fp32_bounds_assume(nm, cuda, screen):
+    """The hardware premise under the fp32 screen's bound (since round 1) and under the materialised distance pass's acceptance
+    test (round 5): v_mfma_f32_32x32x2_f32 forms C + a0 b0 + a1 b1 with exact products and at most two roundings, so a chain of
+    n instructions errs like a 2n-step fma chain. Measured on the device against binary64: single instructions, and both
+    accumulation forms exactly as the kernels issue them on row families incl. near-duplicates and mixed binades."""
+    if screen != "f32":
+        pytest.skip("one run is enough")
+    m = nm.selftest_mfma_f32(1 << 22, 2048)
+    assert m["results"] >= 1 << 22
+    assert m["rel_u"] <= 2.0 + 1e-3, m                      # two roundings at most
+    assert m["two_chain_coeff"] <= 0.5 * nm.match_distance_budget(), m
+    assert m["one_chain_coeff"] <= 0.5 * nm.match_accum_budget(0), m
+    assert m["two_chain_coeff"] > 0 and m["one_chain_coeff"] > 0
