@@ -165,6 +165,13 @@ NM_API int nm_compact_keypoints(const float *dense, int num_pixels, float *out, 
 NM_API int nm_find_keypoints3_f32(const float *const dog[5], const float *mask, int mask_width, int mask_height,
                                   int width, int height, float peak_threshold, float edge_threshold, float xper,
                                   float sigma_0, int num_dogs, float *const result[3], void *stream);
+/* The same launch, which also resets entries [width * height, reset_end[l]) of result[l] to -1 (reset_end NULL: nothing):
+ * compute_keypoints' per-octave reset of the dense maps (thrust::fill, sift/siftfunctions.cu:120-121) without launches of its
+ * own -- the detection writes every entry of the octave's region, only what a larger octave left behind it needs the reset. */
+NM_API int nm_find_keypoints3_reset_f32(const float *const dog[5], const float *mask, int mask_width, int mask_height,
+                                        int width, int height, float peak_threshold, float edge_threshold, float xper,
+                                        float sigma_0, int num_dogs, float *const result[3], const size_t reset_end[3],
+                                        void *stream);
 /* The frame driver's detection of one octave on caller-provided DoG planes: fused 3-level detection straight into ordered
  * lists, no dense maps (what nm_sift_detect_describe does per octave). The orchestration rules of compute_orientations /
  * compute_descriptors are applied: an empty level ends the octave (siftfunctions.cu:145,160), at most `capacity`

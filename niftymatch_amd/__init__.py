@@ -39,6 +39,7 @@ _SIGNATURES = {
     "nm_subtract_batch_f32": (_I, [_I, _P, _P, _P, _I, _I, _P]),
     "nm_gradient_batch_f32": (_I, [_I, _P, _P, _I, _I, _P]),
     "nm_find_keypoints3_f32": (_I, [_P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _I, _P, _P]),
+    "nm_find_keypoints3_reset_f32": (_I, [_P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _I, _P, _P, _P]),
     "nm_find_keypoints3_compact_workspace_bytes": (_SZ, [_I, _I]),
     "nm_find_keypoints3_compact_f32": (_I, [_P, _I, _I, _F, _F, _F, _F, _I, _I, _P, _P, _P, _P]),
     "nm_compact3_workspace_bytes": (_SZ, [_I]),

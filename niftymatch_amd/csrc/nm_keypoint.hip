@@ -1,6 +1,7 @@
 // nm_keypoint.hip -- DoG extrema, one-shot sub-pixel refinement, ordered (raster) stream compaction for gfx950.
 // Replaces kernels/keypoint.cu:19-251 and the thrust::copy_if of sift/pyramidata.cu:84-91. The reference's texture
 // fetches at (x+0.5,y+0.5) are exact texel loads (utils/cudatex2D.cu:15-19), so planes are read as plain arrays.
+#include <algorithm>
 #include "nm_common.hpp"
 #include "nm_fpspec.hpp"
 #include "nm_keypoint.hpp"
@@ -124,6 +125,10 @@ __global__ __launch_bounds__(256) void count_valid3_kernel(NmCompact3 c)
     if (threadIdx.x == 0) c.counts[l * c.nb + blockIdx.x] = total;
 }
 
+// (Round 5, measured and removed: count_valid3_kernel + scan_counts3_kernel as ONE launch -- every workgroup publishes its count
+// write-through, the last one to finish, found by an agent-scope ticket, scans. 24 000 tickets on one address cost 300 us per
+// launch; with 16 units per workgroup the ticket is free, but the last workgroup's acquire + scan is a 15 us tail on every
+// launch, however small -- 56 us at 1080p octave 0 against 15 + 8 for the two launches. profiles/r05_l_dropin_kernel_summary.txt)
 __global__ __launch_bounds__(256) void scatter_valid3_kernel(NmCompact3 c)
 {
     __shared__ int s_wave[4];
@@ -227,6 +232,19 @@ template <bool DENSE, bool LEV = false, bool MASKED = DENSE>
 __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
 {
     __shared__ DetectSmem sm;
+    if (DENSE && a.fill_blocks > 0 && (int)blockIdx.x >= a.det_blocks) {
+        // the launch's reset part: -1 into what lies behind this octave's region in the three dense maps
+        const size_t first = (size_t)a.ow * a.oh;
+        const float4 inv = make_float4(-1.f, -1.f, -1.f, -1.f);
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            float4 *m = reinterpret_cast<float4 *>(a.dense[l]);
+            for (size_t i = first + (size_t)(blockIdx.x - a.det_blocks) * 256 + threadIdx.x; i < a.reset_end[l];
+                 i += (size_t)a.fill_blocks * 256)
+                m[i] = inv;
+        }
+        return;
+    }
     const int frame = blockIdx.y;
     DetectView v;
 #pragma unroll
@@ -385,6 +403,18 @@ int nm_find_keypoints3_f32(const float *const dog[5], const float *mask, int mas
                            int height, float peak_threshold, float edge_threshold, float xper, float sigma_0, int num_dogs,
                            float *const result[3], void *stream)
 {
+    return nm_find_keypoints3_reset_f32(dog, mask, mask_width, mask_height, width, height, peak_threshold, edge_threshold, xper,
+                                        sigma_0, num_dogs, result, nullptr, stream);
+}
+
+// The same launch, which ALSO resets entries [width * height, reset_end[l]) of result[l] to -1 (reset_end NULL or <= width *
+// height: nothing): compute_keypoints' per-octave reset of the dense maps (thrust::fill, sift/siftfunctions.cu:120-121) without
+// launches of its own -- the detection part writes every entry of the region, so only what an earlier, larger octave left
+// behind it needs the reset.
+int nm_find_keypoints3_reset_f32(const float *const dog[5], const float *mask, int mask_width, int mask_height, int width,
+                                 int height, float peak_threshold, float edge_threshold, float xper, float sigma_0, int num_dogs,
+                                 float *const result[3], const size_t reset_end[3], void *stream)
+{
     if (width <= 0 || height <= 0) return 0;
     if (!dog || !result) return (int)hipErrorInvalidValue;
     NmDetectArgs d{};
@@ -394,8 +424,15 @@ int nm_find_keypoints3_f32(const float *const dog[5], const float *mask, int mas
     for (int i = 0; i < 5; ++i) { if (!dog[i]) return (int)hipErrorInvalidValue; d.api_planes[i] = dog[i]; }
     for (int l = 0; l < 3; ++l) { if (!result[l]) return (int)hipErrorInvalidValue; d.dense[l] = result[l]; }
     d.mask = mask; d.mask_w = mask_width; d.mask_h = mask_height;
-    hipLaunchKernelGGL(detect_stage_kernel<true>, dim3(d.nseg * nm_divup(height, DET_ROWS), 1), dim3(256), 0,
-                       nm_stream(stream), d);
+    d.det_blocks = d.nseg * nm_divup(height, DET_ROWS);
+    size_t most = 0;
+    const size_t region = (size_t)width * height;
+    for (int l = 0; l < 3; ++l) {
+        d.reset_end[l] = reset_end ? reset_end[l] : 0;
+        if (d.reset_end[l] > region) most = std::max(most, d.reset_end[l] - region);
+    }
+    d.fill_blocks = (int)std::min<size_t>((most + 2047) / 2048, 2048);          // >= 8 entries per thread, at most 2048 workgroups
+    hipLaunchKernelGGL(detect_stage_kernel<true>, dim3(d.det_blocks + d.fill_blocks, 1), dim3(256), 0, nm_stream(stream), d);
     NM_LAUNCH_CHECK();
     return 0;
 }

@@ -30,6 +30,11 @@ struct NmDetectArgs {
     // frame driver (nm_sift_arena_set_mask): optional full-resolution mask per frame, mask_w x mask_h as above
     const float *masks[NM_MAX_BATCH];
     int any_mask;
+    // API path (nm_find_keypoints3_reset_f32): the launch also resets entries [ow * oh, reset_end[l]) of dense[l] to -1 -- what an
+    // earlier, larger octave left behind the region this octave writes -- with fill_blocks extra workgroups behind the
+    // det_blocks that detect (the reference resets the whole maps with thrust::fill per octave, siftfunctions.cu:120-121)
+    size_t reset_end[3];
+    int det_blocks, fill_blocks;
 };
 
 struct NmScanArgs {

@@ -154,18 +154,18 @@ static void keypoints_impl(PyramidData &pydata, const SiftParams &params, const 
         // The reference resets the whole full-resolution maps and lets the kernel write the keypoints (siftfunctions.cu:
         // 120-125). Here the fused kernel writes EVERY pixel of the octave's region (keypoint or -1), so only what an
         // earlier, larger octave may have left beyond the region is reset: same final contents, ~6x fewer bytes.
+        // (round 5: the reset rides in the detection launch -- three launches per octave fewer)
+        size_t reset_end[3];
         for (int l = 0; l < 3; ++l) {
-            if (pydata._dirty[l] > region)
-                nm_check(nm_fill_u32(pydata._key_pts[l].data() + region, (pydata._dirty[l] - region) * 4, 0xBF800000u, stream),
-                         "Keypoint map reset failed");
+            reset_end[l] = pydata._dirty[l] > region ? pydata._dirty[l] : 0;
             pydata._dirty[l] = region < pydata._key_pts[l].size() ? region : pydata._key_pts[l].size();
         }
         const float *dog[5];
         float *res[3];
         for (int i = 0; i < 5; ++i) dog[i] = pydata._dog[i].data();
         for (int l = 0; l < 3; ++l) res[l] = reinterpret_cast<float *>(pydata._key_pts[l].data());
-        nm_check(nm_find_keypoints3_f32(dog, mask, mask_w, mask_h, ow, oh, params._peak_threshold, params._edge_threshold,
-                                        xper, params._sigma_0, params._num_dog_levels, res, stream),
+        nm_check(nm_find_keypoints3_reset_f32(dog, mask, mask_w, mask_h, ow, oh, params._peak_threshold, params._edge_threshold,
+                                              xper, params._sigma_0, params._num_dog_levels, res, reset_end, stream),
                  "Keypoint detection launch failed");
         return;
     }

@@ -58,6 +58,20 @@ def test_find_keypoints3_and_compact3(nm, oracle, cuda, wh):
             want = oracle.compact_keypoints(ref[l])
             assert int(cnt[l]) == len(want)
             _eq(out[l][: len(want)], want, "collated level %d" % l)
+        # the detection launch that also resets what lies behind the region (compute_keypoints' per-octave reset): entries
+        # [w h, reset_end) become -1, everything behind reset_end stays
+        dense2 = [torch.full((h + 40, w, 4), 7.0, dtype=torch.float32, device=cuda) for _ in range(3)]
+        ends = (C.c_size_t * 3)(w * h + 5, 0, (h + 33) * w + 1)
+        rc = nm.lib().nm_find_keypoints3_reset_f32(_ptrs(tdog), tm.data_ptr() if tm is not None else None,
+                                                   m.shape[1] if m is not None else 0, m.shape[0] if m is not None else 0, w, h,
+                                                   p.peak_threshold, p.edge_threshold, xper, p.sigma_0, 3, _ptrs(dense2), ends, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        for l in range(3):
+            _eq(dense2[l][:h], ref[l], "dense map level %d with reset" % l)
+            flat = dense2[l].reshape(-1, 4)
+            end = max(int(ends[l]), w * h)
+            assert bool((flat[w * h:end] == -1.0).all()) and bool((flat[end:] == 7.0).all()), l
 
 
 def test_dog_and_gradient_batches(nm, oracle, cuda):
