@@ -727,9 +727,14 @@ def test_fp32_mfma_rounding_is_inside_what_the_fp32_bounds_assume(nm, cuda, scre
     accumulation forms exactly as the kernels issue them on row families incl. near-duplicates and mixed binades."""
     if screen != "f32":
         pytest.skip("one run is enough")
-    m = nm.selftest_mfma_f32(1 << 22, 2048)
+    m = nm.selftest_mfma_f32(1 << 22, 8192)
+    u = 2.0 ** -24
     assert m["results"] >= 1 << 22
     assert m["rel_u"] <= 2.0 + 1e-3, m                      # two roundings at most
-    assert m["two_chain_coeff"] <= 0.5 * nm.match_distance_budget(), m
-    assert m["one_chain_coeff"] <= 0.5 * nm.match_accum_budget(0), m
-    assert m["two_chain_coeff"] > 0 and m["one_chain_coeff"] > 0
+    # On MI355X EVERY result equals fma(a1, b1, fma(a0, b0, C)) (profiles/r05_n_mfma_f32_model.txt): the instruction IS the
+    # two-step chain, so the bounds below are arithmetic. A device where that stops being true must still stay inside them.
+    assert m["frac_fma_chain"] > 0.999 or m["rel_u"] <= 1.0 + 1e-3, m
+    # the chains as issued, on adversarial rows (constant rows round every product alike and come close to the worst case):
+    # inside the fma-chain worst cases gamma_67 / gamma_130, hence inside the budgets, which add the norms' share and slack
+    assert 0 < m["two_chain_coeff"] <= 67 * u * 1.001 < nm.match_distance_budget(), m
+    assert 0 < m["one_chain_coeff"] <= 130 * u * 1.001 <= 0.5 * nm.match_accum_budget(0) * 1.001, m

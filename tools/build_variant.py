@@ -1,5 +1,5 @@
 """Scratch builds for A/B timing: recompile ONE kernel source with extra preprocessor flags and link it with the objects of
-the regular build into niftymatch_amd/lib/variants/libnm_hip_<name>.so (selected at run time with NM_HIP_LIB=<path>).
+the regular build into tools/_variants/libnm_hip_<name>.so (git-ignored; selected at run time with NM_HIP_LIB=<path> NM_DIAGNOSTIC=1).
     python tools/build_variant.py <name> <source.hip>[,<source2.hip>] -DFLAG=1 ...
 Results of such variants may be wrong by design (pieces compiled out); only their times are read."""
 import os, subprocess, sys
@@ -9,7 +9,7 @@ from niftymatch_amd import build as B
 name, srcs = sys.argv[1], sys.argv[2].split(",")
 flags = sys.argv[3:]
 B.build()
-out_dir = os.path.join(B.LIBDIR, "variants")
+out_dir = os.path.join(root, "tools", "_variants")        # NOT under the product's lib/: a diagnostic build must never sit beside libnm_hip.so
 os.makedirs(out_dir, exist_ok=True)
 vobjs = []
 for src in srcs:
