@@ -81,6 +81,17 @@ for it in range(n_match):
     tri = nm.sift_match_shard(t(A), t(B), 3)
     ok = (np.array_equal(got.cpu().numpy(), ref) and np.array_equal(tri[1].cpu().numpy(), ix)
           and np.array_equal(tri[0].cpu().numpy(), m1) and np.array_equal(tri[2].cpu().numpy(), m2))
+    if ok and it % 4 == 0:
+        # round 5: the materialised distance on the fp32 MFMA -- EVERY entry within 1e-4 relative of the reference's chain
+        # (exact copies exactly 0), on the same random families; and the indexes do not depend on the mode
+        _, Dref, _ = O.sift_matches(A, B, amb, want_distance=True)
+        got2, D = nm.sift_match(t(A), t(B), amb, want_distance=True)
+        try:
+            H.assert_distance(nm, D, Dref, "soak distance")
+            ok = np.array_equal(got2.cpu().numpy(), ref)
+        except AssertionError as e:
+            print("   ", str(e)[:200], flush=True)
+            ok = False
     if not ok:
         bad += 1
         print("MATCH MISMATCH", it, na, nb, kind, amb, flush=True)
@@ -117,6 +128,34 @@ for it in range(n_groups):
             bad += 1
             print("BATCH MATCH MISMATCH", it, len(a), len(b), amb, flush=True)
 print("batched matches done: %d groups, total mismatches %d, %.1fs" % (n_groups, bad, time.time() - t0), flush=True)
+
+# ---- round 5: the drop-in C++ API's per-octave client loop with lazy counts (nm/lazy_count.h) on random geometries: never
+#      looking / looking after every call / eager counts must agree on every count, descriptor and coordinate, and with the oracle
+import ctypes as C  # noqa: E402
+t0 = time.time()
+n_lazy = max(5, n_frames // 20)
+for it in range(n_lazy):
+    w = int(rng.integers(40, 700)); h = int(rng.integers(40, 500))
+    if rng.random() < 0.7:
+        w = (w // 4) * 4
+    cap = int(rng.choice([64, 500, 8192]))
+    f = np.ascontiguousarray(H.blurred_frame(int(rng.integers(1, 1 << 30)), w, h, sigma=float(rng.uniform(1.0, 4.0))))
+    ref = O.sift_detect_describe(f, cap)
+    n_oct = ref["counts"].shape[0]
+    watch = (C.c_int * (4 * n_oct))()
+    pend = C.c_int(0)
+    n = nm.lib().nm_client_lazy_counts(f.ctypes.data, w, h, cap, watch, n_oct, C.byref(pend))
+    ok = n == ref["n"]
+    run = 0
+    for o in range(n_oct):
+        cnt = [int(c) for c in ref["counts"][o]]
+        ok = ok and [watch[4 * o + l] for l in range(3)] == cnt
+        run = min(cap, run + sum(cnt))
+        ok = ok and watch[4 * o + 3] == run
+    if not ok:
+        bad += 1
+        print("LAZY COUNT MISMATCH", it, w, h, cap, n, ref["n"], flush=True)
+print("lazy-count client loops done: %d cases, total mismatches %d, %.1fs" % (n_lazy, bad, time.time() - t0), flush=True)
 
 # ---- side stages: front end, warps, blend, RANSAC ----
 t0 = time.time()
