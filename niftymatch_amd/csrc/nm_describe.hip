@@ -433,21 +433,38 @@ __device__ __forceinline__ void level_extent_dev(const NmLevelLists &a, int l, b
     run_out = run;
 }
 
+// Both kernels walk the three level lists as ONE list (index = level-major): a grid row per level left the workgroups of the
+// short lists idle while those of the longest ran ~3 rounds (octave 0 of a 1080p frame: 4.5k / 2.2k / 0.8k keypoints).
+__device__ __forceinline__ void level_counts(const NmLevelLists &a, bool clip, int (&n)[3], int (&base)[3], int &run)
+{
+    if (a.d_counts) {
+        level_extent_dev(a, 0, clip, n[0], base[0], run);
+        level_extent_dev(a, 1, clip, n[1], base[1], run);
+        level_extent_dev(a, 2, clip, n[2], base[2], run);
+    } else {
+#pragma unroll
+        for (int l = 0; l < 3; ++l) { n[l] = l < a.n_levels ? max(a.num_pts[l], 0) : 0; base[l] = 0; }
+        run = 0;
+    }
+}
+
 __global__ __launch_bounds__(256) void orientations_levels_kernel(NmLevelLists a, const float2 *__restrict__ grad, int ow,
                                                                  int oh, float gauss_factor, float xper)
 {
     __shared__ __attribute__((aligned(16))) float s_part[4][ORI_LDS];
-    const int wave = threadIdx.x >> 6, l = blockIdx.y;
-    int n = a.num_pts[l];
-    if (a.d_counts) {
-        int base, run;
-        level_extent_dev(a, l, false, n, base, run);
-        if (a.h_counts && blockIdx.x == 0 && l == 0 && threadIdx.x < 3) a.h_counts[threadIdx.x] = a.d_counts[threadIdx.x];
-    }
-    for (int pt = blockIdx.x * 4 + wave; pt < n; pt += gridDim.x * 4) {
+    const int wave = threadIdx.x >> 6;
+    int n[3], base[3], run;
+    level_counts(a, false, n, base, run);
+    if (a.d_counts && a.h_counts && blockIdx.x == 0 && threadIdx.x < 3) a.h_counts[threadIdx.x] = a.d_counts[threadIdx.x];
+    const int total = n[0] + n[1] + n[2];
+    for (int idx = blockIdx.x * 4 + wave; idx < total; idx += gridDim.x * 4) {
+        const int l = idx < n[0] ? 0 : (idx < n[0] + n[1] ? 1 : 2);
+        const int pt = idx - (l > 0 ? n[0] : 0) - (l > 1 ? n[1] : 0);
+        const float4 *kp = l == 0 ? a.key_pts[0] : (l == 1 ? a.key_pts[1] : a.key_pts[2]);
+        float2 *out = l == 0 ? a.orients[0] : (l == 1 ? a.orients[1] : a.orients[2]);
         float th0, th1;                           // unset components are -1, as the pre-fill of pyramidata.cu:90 leaves them
-        orient_wave(a.key_pts[l][pt], grad, ow, oh, gauss_factor, xper, th0, th1, s_part[wave]);
-        if ((threadIdx.x & 63) == 0) a.orients[l][pt] = make_float2(th0, th1);
+        orient_wave(kp[pt], grad, ow, oh, gauss_factor, xper, th0, th1, s_part[wave]);
+        if ((threadIdx.x & 63) == 0) out[pt] = make_float2(th0, th1);
     }
 }
 
@@ -455,21 +472,29 @@ __global__ __launch_bounds__(64) void descriptors_levels_kernel(NmLevelLists a, 
                                                                int oh, int num_dogs, float xper)
 {
     __shared__ __attribute__((aligned(16))) float part[DESC_LDS];
-    const int l = blockIdx.y;
-    int n = a.num_pts[l];
-    float *desc = a.desc[l], *xs = a.x[l], *ys = a.y[l];
-    if (a.d_counts) {
-        int base, run;
-        level_extent_dev(a, l, true, n, base, run);
-        desc = a.desc[0] + (size_t)base * 128; xs = a.x[0] + base; ys = a.y[0] + base;
-        if (blockIdx.x == 0 && l == 0 && threadIdx.x == 0) {
-            if (a.d_items_out) *a.d_items_out = run;
-            if (a.h_items) *a.h_items = run;
-        }
+    int n[3], base[3], run;
+    level_counts(a, true, n, base, run);
+    if (a.d_counts && blockIdx.x == 0 && threadIdx.x == 0) {
+        if (a.d_items_out) *a.d_items_out = run;
+        if (a.h_items) *a.h_items = run;
     }
-    for (int pt = blockIdx.x; pt < n; pt += gridDim.x)
-        describe_wave(a.key_pts[l][pt], a.orients[l][pt].x, grad, ow, oh, num_dogs, xper, desc + (size_t)pt * 128, xs + pt,
-                      ys + pt, part);
+    const int total = n[0] + n[1] + n[2];
+    for (int idx = blockIdx.x; idx < total; idx += gridDim.x) {
+        const int l = idx < n[0] ? 0 : (idx < n[0] + n[1] ? 1 : 2);
+        const int pt = idx - (l > 0 ? n[0] : 0) - (l > 1 ? n[1] : 0);
+        const float4 *kp = l == 0 ? a.key_pts[0] : (l == 1 ? a.key_pts[1] : a.key_pts[2]);
+        const float2 *ori = l == 0 ? a.orients[0] : (l == 1 ? a.orients[1] : a.orients[2]);
+        float *desc, *xs, *ys;
+        if (a.d_counts) {                         // the container's arrays from slot 0
+            const int slot = (l == 0 ? base[0] : (l == 1 ? base[1] : base[2])) + pt;
+            desc = a.desc[0] + (size_t)slot * 128; xs = a.x[0] + slot; ys = a.y[0] + slot;
+        } else {
+            desc = (l == 0 ? a.desc[0] : (l == 1 ? a.desc[1] : a.desc[2])) + (size_t)pt * 128;
+            xs = (l == 0 ? a.x[0] : (l == 1 ? a.x[1] : a.x[2])) + pt;
+            ys = (l == 0 ? a.y[0] : (l == 1 ? a.y[1] : a.y[2])) + pt;
+        }
+        describe_wave(kp[pt], ori[pt].x, grad, ow, oh, num_dogs, xper, desc, xs, ys, part);
+    }
 }
 
 // ---- frame-driver kernels: all octaves of a frame in one launch, counts read from the device-side book ----
@@ -616,7 +641,9 @@ int nm_detect_orientations_levels(int n_levels, const float *const *key_pts, con
         most = max(most, num_pts[l]);
     }
     if (most <= 0) return 0;
-    hipLaunchKernelGGL(orientations_levels_kernel, dim3(min(nm_divup(most, 4), 4096), n_levels), dim3(256), 0,
+    int sum = 0;
+    for (int l = 0; l < n_levels; ++l) sum += num_pts[l] > 0 ? num_pts[l] : 0;
+    hipLaunchKernelGGL(orientations_levels_kernel, dim3(min(nm_divup(sum, 4), 4096)), dim3(256), 0,
                        nm_stream(stream), a, reinterpret_cast<const float2 *>(grad), octave_width, octave_height,
                        gauss_factor, xper);
     NM_LAUNCH_CHECK();
@@ -638,7 +665,7 @@ int nm_detect_orientations_levels_dev(const float *const *key_pts, const int *d_
         a.orients[l] = reinterpret_cast<float2 *>(result[l]);
     }
     a.d_counts = d_counts; a.h_counts = h_counts;
-    hipLaunchKernelGGL(orientations_levels_kernel, dim3(min(nm_divup(max_pts, 4), 1024), 3), dim3(256), 0, nm_stream(stream), a,
+    hipLaunchKernelGGL(orientations_levels_kernel, dim3(min(nm_divup(max_pts, 4), 1024)), dim3(256), 0, nm_stream(stream), a,
                        reinterpret_cast<const float2 *>(grad), octave_width, octave_height, gauss_factor, xper);
     NM_LAUNCH_CHECK();
     return 0;
@@ -661,7 +688,7 @@ int nm_compute_sift_descriptors_levels_dev(const float *const *key_pts, const fl
     a.desc[0] = desc; a.x[0] = x; a.y[0] = y;
     a.d_counts = d_counts; a.d_base_in = d_base_in; a.host_base = host_base; a.capacity = capacity;
     a.d_items_out = d_items_out; a.h_items = h_items;
-    hipLaunchKernelGGL(descriptors_levels_kernel, dim3(min(min(max_pts, capacity), 2048), 3), dim3(64), 0, nm_stream(stream), a,
+    hipLaunchKernelGGL(descriptors_levels_kernel, dim3(min(min(max_pts, capacity), 4096)), dim3(64), 0, nm_stream(stream), a,
                        reinterpret_cast<const float2 *>(grad), octave_width, octave_height, num_dogs, xper);
     NM_LAUNCH_CHECK();
     return 0;
@@ -686,7 +713,9 @@ int nm_compute_sift_descriptors_levels(int n_levels, const float *const *key_pts
         most = max(most, num_pts[l]);
     }
     if (most <= 0) return 0;
-    hipLaunchKernelGGL(descriptors_levels_kernel, dim3(min(most, 4096), n_levels), dim3(64), 0, nm_stream(stream), a,
+    int sum = 0;
+    for (int l = 0; l < n_levels; ++l) sum += num_pts[l] > 0 ? num_pts[l] : 0;
+    hipLaunchKernelGGL(descriptors_levels_kernel, dim3(min(sum, 4096)), dim3(64), 0, nm_stream(stream), a,
                        reinterpret_cast<const float2 *>(grad), octave_width, octave_height, num_dogs, xper);
     NM_LAUNCH_CHECK();
     return 0;
