@@ -72,6 +72,13 @@ __global__ __launch_bounds__(1024) void rate_kernel(float *out, int iters, float
                 if (KIND == 41) asm volatile("v_cmp_lt_i32 vcc, %0, %1" : : "v"(n[i]), "v"(lane) : "vcc");
                 if (KIND == 42) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
                 if (KIND == 43) asm volatile("v_subrev_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+                if (KIND == 44) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+                if (KIND == 45) asm volatile("v_rsq_f32 %0, %0" : "+v"(a[i]));
+                if (KIND == 46) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[i]));
+                if (KIND == 47) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+                if (KIND == 48) asm volatile("v_rcp_f64 %0, %0" : "+v"(d[i]));
+                if (KIND == 49) asm volatile("v_ldexp_f64 %0, %0, %1" : "+v"(d[i]) : "v"(lane));
+                if (KIND == 50) asm volatile("v_cvt_i32_f64 %0, %1" : "+v"(n[i]) : "v"(d[i]));
             }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -125,5 +132,8 @@ int main()
     run<31>("v_sub_u32", out, clk); run<32>("v_lshlrev_b32", out, clk); run<33>("v_mov_b32", out, clk); run<34>("v_min_u32", out, clk);
     run<35>("v_xor_b32", out, clk); run<36>("v_fma_f32 acc", out, clk); run<38>("v_add_f32 |abs|", out, clk); run<39>("v_mul_f32 |abs|", out, clk);
     run<41>("v_cmp_lt_i32", out, clk); run<42>("v_sub_f32", out, clk);
+    // round 5: the transcendental unit (the gradient's rsq + rcp per pixel, the descriptor weight's ldexp / conversions)
+    run<44>("v_rcp_f32", out, clk); run<45>("v_rsq_f32", out, clk); run<46>("v_sqrt_f32", out, clk); run<47>("v_exp_f32", out, clk);
+    run<48>("v_rcp_f64", out, clk); run<49>("v_ldexp_f64", out, clk); run<50>("v_cvt_i32_f64", out, clk);
     return 0;
 }
