@@ -1942,8 +1942,9 @@ __device__ __forceinline__ void dist_emit(const f32x16 &acc, const DistArgs &a, 
                                           int rb, int h, unsigned long long jmask, float tyj, unsigned vo, unsigned ld4,
                                           int i_blk, int j_blk, int rows_here)
 {
-    // vo: this lane's byte offset inside the tile's rows of D, 0x80000000 for a lane whose column does not exist -- the
-    // descriptor's range check (voffset IS part of it; soffset is not) drops that lane's stores. jmask = lanes with a column.
+    // vo: this lane's byte offset inside the tile's rows of D, 0x80000000 for a lane whose column does not exist -- beyond any
+    // tile's byte range (< 2^31), so the descriptor's range check drops that lane's stores whatever soffset adds (the probe
+    // tools/micro/buffer_range.hip shows voffset + soffset checked on this device). jmask = lanes with a column.
     unsigned long long listed = 0;
 #pragma unroll
     for (int e4 = 0; e4 < 4; ++e4) {
@@ -1992,8 +1993,9 @@ __global__ __launch_bounds__(512, 1) void distance_mfma_kernel(DistArgs a)
     float stn = 0.f, stt = 0.f;
     auto stage_load = [&](int rt) {                         // rows rt * 128 .. + 127 of X -> registers (rows >= nX read as zeros)
         const int ib = rt * TILE_C;
+        // (the row offset rides in voffset, which every reading of the ISA includes in the descriptor's range check; on this
+        // device soffset is included too -- tools/micro/buffer_range.hip, profiles/r05_b_buffer_range_probe.txt)
 #pragma unroll
-        // (the row offset rides in voffset: soffset is excluded from the descriptor's range check)
         for (int it = 0; it < 8; ++it) st[it] = __builtin_amdgcn_raw_buffer_load_b128(rsX, voff + (ib + 16 * it) * (DIM * 4), 0, 0);
         if (tid < TILE_C) {
             const bool ok = ib + tid < nX;
