@@ -1859,8 +1859,8 @@ __global__ __launch_bounds__(256) void exact_distance_kernel(const float *__rest
 // ---- the materialised distance matrix on the fp32 MFMA (round 5; reference: kernels/match.cu:14-80, siftfunctions.cu:28-34) ----
 // D[i][j] = |x_i - y_j|^2 as |x'_i|^2 + |y'_j|^2 - 2 x'_i . y'_j on v_mfma_f32_32x32x2_f32 with the store fused into the
 // kernel, where x' = x - mu, y' = y - mu are the rows CENTRED on the mean row of Y: distances are translation-invariant, and
-// the contraction's rounding error scales with the norms of what is multiplied, not with the distance (uniform all-positive
-// rows: without the centring every entry would fail the test below; SIFT descriptors: 5 x fewer do).
+// the contraction's rounding error scales with the norms of what is multiplied, not with the distance (rows that share a large
+// common component -- an offset, a dominant mean descriptor -- would otherwise all fail the test below).
 // Every entry is within 1e-4 relative of the reference's chain (acc = fma(t, t, acc), t = x_k - y_k, match.cu:36-42):
 //   * the value v is the sum of TWO accumulator chains (k = 0..63 with the norm pair, k = 64..127): no term passes through more
 //     than 67 roundings (2 + 64 steps of a chain, the final add), and the tabulated norms carry 8 (distance_center_kernel), so
