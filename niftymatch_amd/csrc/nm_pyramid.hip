@@ -532,6 +532,13 @@ __global__ __launch_bounds__(256) void conv_pk_kernel(NmConvBatch batch, int wid
     pk_cols_epilogue<R, WRITE_DOG, WRITE_GRAD, WRITE_BUF>(s_in, s_mid, w, tid, x0, y0, width, height, result, dog, grad, down);
 }
 
+// (Round 5, measured and removed: 64-ROW tiles with 512 threads -- the share of halo rows the row pass filters and the loads
+// fetch drops from 1.81 to 1.41 at R = 13 and from 1.44 to 1.22 at R = 7, the row tasks mapped densely (row pair fastest) so
+// that whole waves skip the pass; bit-identical (60 GPU tests). 64-frame chain: 57.83 -> 57.91 us per frame with the DoG
+// planes, 51.9 -> 53.3 without, 42.1 -> 42.6 without the gradients. Per launch (octave 0, 64 frames): R = 10 with gradient
+// 589 -> 546 us (3 workgroups of 8 waves fit a CU where 5 of 4 did), R = 13 438 -> 467, R = 5 222 -> 240, the others +-1 %:
+// the launches follow the waves in flight and the workgroup granularity, not the FMA or load count -- like round 4's 48-row
+// tiles. profiles/r05_x_kpyr_tall.txt, r05_y_kpyr_tall{0,1}.txt)
 // (Round 3, measured and removed: a STREAMING form of this kernel -- a workgroup owns a 64-column strip segment and marches
 // down it in 32-row bands, fetching and row-filtering only the 32 new input rows per band, moving the last 2R rows of both LDS
 // tiles to their head, with the next band's rows prefetched into registers -- is bit-identical and does 38 % less staging
