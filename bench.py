@@ -970,6 +970,9 @@ def main():
         if dropin is not None:
             out["dropin_api"] = dropin
         if dist_roof is not None:
+            if "error" not in dist_roof:
+                dist_roof["traffic"] = traffic.get("distance_mfma_kernel", {}).get("hbm_bytes_per_launch")
+                dist_roof["traffic_note"] = "HBM bytes per launch from the rocprofv3 PMC passes in profiles/ (stored, not live)"
             out["roofline_distance"] = dist_roof
             head["roofline_distance_frac"] = dist_roof.get("frac")
             head["distance_12k_us"] = (round(1e3 * dist_roof["avg_ms"], 1) if dist_roof.get("avg_ms") else None)
