@@ -1028,6 +1028,9 @@ __device__ __forceinline__ void match_top2_body(const float *__restrict__ A, int
 // ONE launch per call: the workgroups are persistent over the PAIRS of the call too (every pair's plan is in device memory,
 // nbmax_kernel), so the launch, the kernel-argument and plan loads and the drain of the slowest workgroup are paid once
 // per call instead of once per pair (~9 us of fixed cost per pair beside ~40 us of tiles when each pair was a launch).
+#ifndef NM_COARSE_CROSS
+#define NM_COARSE_CROSS 1
+#endif
 __global__ __launch_bounds__(512, 1) void match_coarse_kernel(MatchBatch bt)
 {
     constexpr int ROWB = DIM * 2, IMG = TILE_C * ROWB, SLOT0 = 2 * IMG, SLOTB = TILE_C * 16, QREG = SLOT0 + 2 * SLOTB;
@@ -1047,53 +1050,90 @@ __global__ __launch_bounds__(512, 1) void match_coarse_kernel(MatchBatch bt)
     for (int t = 0; t < 4; ++t) dvoff[t] = (unsigned)((lane >> 4) * ROWB + (((lane & 15) ^ ((4 * t + (lane >> 4)) & 15)) << 4));
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     typedef __attribute__((address_space(3))) void lds_void;
-    bool worked = false;
-    for (int pq = 0; pq < bt.n; ++pq) {
-    const MatchPair &c = bt.p[pq];
-    const int nA = pair_nA(c), nB = pair_nB(c);
-    if (nA <= 0 || nB <= 0) continue;                     // an empty set is a no-op for the pair, as in the reference
-    const MatchPlan plan = *c.d_plan;                     // uniform: scalar loads
-    if (wg >= plan.G) continue;
-    const unsigned *__restrict__ Ah = c.Ah, *__restrict__ Bh = c.Bh;
-    const float *__restrict__ na = c.na;
-    const uint4 *__restrict__ nbslot = c.nbslot;
-    float4 *__restrict__ partial = c.partial;
-    float *__restrict__ partial3 = c.partial3;
-    const int S = plan.S;
-    const int xg = wg % plan.X, vg = wg / plan.X;
-    const PlanGroup grp = plan_group(plan, xg);
-    const unit_t u_begin = group_begin(grp, vg), u_end = group_begin(grp, vg + 1);
-    SegIter it;
-    it.init(u_begin, u_end);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(Bh), 0, nB * ROWB, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(Ah), 0, nA * ROWB, 0x00020000);
-    auto dma_tile = [&](int tile, int b) {
+    // Pair directory: sizes and plan of every pair of the call, read once by sixteen lanes (the device-memory latency of
+    // the plan used to be exposed to all eight waves at every pair change) and kept in 1 KiB of LDS behind the query region.
+    constexpr int DIR = QREG + QB * ROWB, DIR_STRIDE = 16;
+    static_assert(sizeof(MatchPlan) == 10 * sizeof(int) && DIR_STRIDE >= 12, "directory entry: nA, nB, the plan");
+    int *const dir = reinterpret_cast<int *>(ldsb + DIR);
+    if (tid < bt.n) {
+        const MatchPair &c = bt.p[tid];
+        const int *pl = reinterpret_cast<const int *>(c.d_plan);
+        int *d = dir + tid * DIR_STRIDE;
+        d[0] = pair_nA(c); d[1] = pair_nB(c);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void *)(ldsb + b * IMG + (wave_u * 4 + t) * 1024), 16, (int)dvoff[t],
-                                                     (tile * TILE_C + 4 * (wave_u * 4 + t)) * ROWB, 0, 0);
-    };
-    auto dma_queries = [&](int i0) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void *)(ldsb + QREG + (wave_u * 8 + t) * 1024), 16, (int)dvoff[t & 3],
-                                                     (i0 + 4 * (wave_u * 8 + t)) * ROWB, 0, 0);
+        for (int k = 0; k < 10; ++k) d[2 + k] = pl[k];
+    }
+    __syncthreads();
+
+    // What a workgroup needs of the pair a segment belongs to. The segments of ALL pairs of the call form one stream: the
+    // segment after a pair's last one is the first of the next pair in which this workgroup has work, requested ahead like any
+    // other (until round 5 every pair began with the slow path below: plan load, request, wait, barrier -- ~2 us of 41).
+    struct PairCtx {
+        int pq, nA, vg;
+        MatchPlan plan;
+        PlanGroup grp;
+        unit_t u_end;
+        SegIter it;
+        __amdgpu_buffer_rsrc_t rsA, rsB;
+        const float *na;
+        const uint4 *nbslot;
+        float4 *partial;
+        float *partial3;
     };
     struct Seg { int pc, qbl, tt, Lc, qb, t0, ntiles; };
-    auto locate = [&](unit_t u) {
+    // the first pair >= from in which this workgroup has a segment; u: the local unit where that segment starts
+    auto open_pair = [&](int from, PairCtx &cx, unit_t &u) -> bool {
+        for (int pq = from; pq < bt.n; ++pq) {
+            const int *d = dir + pq * DIR_STRIDE;
+            const int nA = __builtin_amdgcn_readfirstlane(d[0]), nB = __builtin_amdgcn_readfirstlane(d[1]);
+            if (nA <= 0 || nB <= 0) continue;             // an empty set is a no-op for the pair, as in the reference
+            MatchPlan plan;
+            plan.qblocks = __builtin_amdgcn_readfirstlane(d[2]); plan.T = __builtin_amdgcn_readfirstlane(d[3]);
+            plan.G = __builtin_amdgcn_readfirstlane(d[4]); plan.S = __builtin_amdgcn_readfirstlane(d[5]);
+            plan.X = __builtin_amdgcn_readfirstlane(d[6]); plan.Gx = __builtin_amdgcn_readfirstlane(d[7]);
+            plan.Tc = __builtin_amdgcn_readfirstlane(d[8]); plan.C = __builtin_amdgcn_readfirstlane(d[9]);
+            plan.q_base = __builtin_amdgcn_readfirstlane(d[10]); plan.q_rem = __builtin_amdgcn_readfirstlane(d[11]);
+            if (wg >= plan.G) continue;
+            const MatchPair &c = bt.p[pq];
+            cx.pq = pq; cx.nA = nA; cx.plan = plan;
+            const int xg = wg % plan.X;
+            cx.vg = wg / plan.X;
+            cx.grp = plan_group(plan, xg);
+            cx.u_end = group_begin(cx.grp, cx.vg + 1);
+            cx.it.init(group_begin(cx.grp, cx.vg), cx.u_end);
+            cx.rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(c.Bh), 0, nB * ROWB, 0x00020000);
+            cx.rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(c.Ah), 0, nA * ROWB, 0x00020000);
+            cx.na = c.na; cx.nbslot = c.nbslot; cx.partial = c.partial; cx.partial3 = c.partial3;
+            if (cx.it.next(cx.plan, cx.grp, u)) return true;
+        }
+        return false;
+    };
+    auto dma_tile = [&](const PairCtx &cx, int tile, int b) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(cx.rsB, (lds_void *)(ldsb + b * IMG + (wave_u * 4 + t) * 1024), 16, (int)dvoff[t],
+                                                     (tile * TILE_C + 4 * (wave_u * 4 + t)) * ROWB, 0, 0);
+    };
+    auto dma_queries = [&](const PairCtx &cx, int i0) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(cx.rsA, (lds_void *)(ldsb + QREG + (wave_u * 8 + t) * 1024), 16, (int)dvoff[t & 3],
+                                                     (i0 + 4 * (wave_u * 8 + t)) * ROWB, 0, 0);
+    };
+    auto locate = [&](const PairCtx &cx, unit_t u) {
         Seg sg;
-        plan_locate(plan, grp, u, sg.pc, sg.qbl, sg.tt, sg.Lc);
-        sg.qb = grp.q0 + sg.qbl; sg.t0 = sg.pc * plan.Tc + sg.tt;
-        sg.ntiles = min(sg.Lc - sg.tt, (int)(u_end - u));
+        plan_locate(cx.plan, cx.grp, u, sg.pc, sg.qbl, sg.tt, sg.Lc);
+        sg.qb = cx.grp.q0 + sg.qbl; sg.t0 = sg.pc * cx.plan.Tc + sg.tt;
+        sg.ntiles = min(sg.Lc - sg.tt, (int)(cx.u_end - u));
         return sg;
     };
-    auto norm_of = [&](int qb) { const int qi = qb * QB + wave * 32 + r; return (qi < nA) ? na[qi] : 0.f; };
+    auto norm_of = [&](const PairCtx &cx, int qb) { const int qi = qb * QB + wave * 32 + r; return (qi < cx.nA) ? cx.na[qi] : 0.f; };
 
+    PairCtx pc_cur, pc_nxt;
     unit_t u;
-    if (!it.next(plan, grp, u)) continue;
-    if (worked) __syncthreads();                          // slower waves may still read the previous pair's last tile
-    worked = true;
-    Seg cur = locate(u);
+    if (!open_pair(0, pc_cur, u)) return;
+    pc_nxt = pc_cur;
+    Seg cur = locate(pc_cur, u);
     bool ahead = false;                                   // the current segment's queries and first tile(s) were requested ahead
     int g = 0;                                            // stream tile index of the current segment's first tile (its parity picks the buffer)
     float nav = 0.f, nav_next = 0.f;
@@ -1101,20 +1141,26 @@ __global__ __launch_bounds__(512, 1) void match_coarse_kernel(MatchBatch bt)
     u32x4 frA[8], frB[8];
     for (;;) {
         unit_t u_next = 0;
-        const bool have_next = it.next(plan, grp, u_next);
+        bool have_next = pc_cur.it.next(pc_cur.plan, pc_cur.grp, u_next);
+        bool cross = false, restart = false;              // the next segment is the first of another pair (restart: A/B builds only)
+        if (!have_next && open_pair(pc_cur.pq + 1, pc_nxt, u_next)) {
+            if (NM_COARSE_CROSS) have_next = cross = true;
+            else restart = true;
+        }
+        const PairCtx &pn = cross ? pc_nxt : pc_cur;      // (uniform: the compiler selects the fields it needs)
         Seg nxt = cur;
-        if (have_next) nxt = locate(u_next);
+        if (have_next) nxt = locate(pn, u_next);
         const int ntiles = cur.ntiles, t0 = cur.t0;
         if (!ahead) {
             // slow path. Every wave is past the barrier of the previous stream tile (or this is the start): both tile buffers,
             // the slots and the query region are free
-            dma_queries(cur.qb * QB);
-            nav = norm_of(cur.qb);
-            dma_tile(t0, g & 1);
-            if (tid < TILE_C) *reinterpret_cast<uint4 *>(ldsb + SLOT0 + (g & 1) * SLOTB + tid * 16) = nbslot[t0 * TILE_C + tid];
+            dma_queries(pc_cur, cur.qb * QB);
+            nav = norm_of(pc_cur, cur.qb);
+            dma_tile(pc_cur, t0, g & 1);
+            if (tid < TILE_C) *reinterpret_cast<uint4 *>(ldsb + SLOT0 + (g & 1) * SLOTB + tid * 16) = pc_cur.nbslot[t0 * TILE_C + tid];
             if (ntiles > 1) {                             // stream tile g + 1
-                if (tid < TILE_C) sts = nbslot[(t0 + 1) * TILE_C + tid];
-                dma_tile(t0 + 1, (g + 1) & 1);
+                if (tid < TILE_C) sts = pc_cur.nbslot[(t0 + 1) * TILE_C + tid];
+                dma_tile(pc_cur, t0 + 1, (g + 1) & 1);
             }
             // (LDS-DMA is tracked per wave: every wave drains ITS transfers before the barrier -- see match_top2_body)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1173,13 +1219,17 @@ __global__ __launch_bounds__(512, 1) void match_coarse_kernel(MatchBatch bt)
                 const int k2 = n + 2 - ntiles;                        // index in the next segment when tile g + n + 2 lies there
                 const bool ex2 = in2 || (have_next && ntiles >= 2 && k2 < nxt.ntiles);
                 if (ex2) {
-                    const int tile2 = in2 ? t0 + n + 2 : nxt.t0 + k2;
-                    if (tid < TILE_C) sts = nbslot[tile2 * TILE_C + tid];
-                    dma_tile(tile2, b);
+                    if (in2) {
+                        if (tid < TILE_C) sts = pc_cur.nbslot[(t0 + n + 2) * TILE_C + tid];
+                        dma_tile(pc_cur, t0 + n + 2, b);
+                    } else {
+                        if (tid < TILE_C) sts = pn.nbslot[(nxt.t0 + k2) * TILE_C + tid];
+                        dma_tile(pn, nxt.t0 + k2, b);
+                    }
                 }
                 if (n == 0 && have_next && ntiles >= 2) {             // every wave holds its fragments: the query region is free
-                    dma_queries(nxt.qb * QB);
-                    nav_next = norm_of(nxt.qb);
+                    dma_queries(pn, nxt.qb * QB);
+                    nav_next = norm_of(pn, nxt.qb);
                     next_ahead = true;
                 }
                 if (in1 || next_ahead) f16_fetch<0>(frA, ldsb + (b ^ 1) * IMG + r * ROWB, foff);
@@ -1189,13 +1239,18 @@ __global__ __launch_bounds__(512, 1) void match_coarse_kernel(MatchBatch bt)
         }
         asm volatile("s_nop 15\n\ts_nop 3" : "+v"(b0), "+v"(b1));
         select_half<COARSE_SLOT_BITS>(b0, b1, best, ntiles);       // group 2 ntiles - 1: slots 0..31 of "iteration" ntiles
-        segment_publish<COARSE_SLOT_BITS>(best, plan, grp, cur.pc, cur.qbl, vg, cur.tt + ntiles == cur.Lc, t0 * TILE_C, h, cur.qb * QB + wave * 32 + r,
-                        nA, S, partial, partial3);
-        if (!have_next) break;
+        segment_publish<COARSE_SLOT_BITS>(best, pc_cur.plan, pc_cur.grp, cur.pc, cur.qbl, pc_cur.vg, cur.tt + ntiles == cur.Lc, t0 * TILE_C, h,
+                        cur.qb * QB + wave * 32 + r, pc_cur.nA, pc_cur.plan.S, pc_cur.partial, pc_cur.partial3);
+        if (!have_next) {
+            if (!restart) break;
+            __syncthreads();                              // NM_COARSE_CROSS=0: every pair starts with the slow path, as until round 5
+            pc_cur = pc_nxt; cur = locate(pc_cur, u_next); ahead = false; g = 0;
+            continue;
+        }
         g += ntiles;
         ahead = next_ahead;
         cur = nxt;
-    }
+        if (cross) pc_cur = pc_nxt;
     }
 }
 
@@ -2359,7 +2414,7 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
     }
     const size_t lds_full = (size_t)2 * TILE_C * KP * sizeof(float);
     // coarse pass: two 32 KiB images + the norm slots; the staged query block (256 rows at a 272-byte pitch) is as large
-    const size_t lds_bytes = lds_full;
+    const size_t lds_bytes = screen == 2 ? lds_full + 1024 : lds_full;      // + the coarse pass's pair directory
     static_assert(2 * TILE_C * (DIM * 2) + 2 * TILE_C * 16 + QB * (DIM * 2) == 2 * TILE_C * KP * sizeof(float),
                   "coarse pass: two tile images, the norm slots and the query region take what the other screens' tiles take");
     // per call: the attribute is per device, and a process may drive several (cheap host-side call, not a stream op)

@@ -108,6 +108,8 @@ for it in range(n_groups):
     for _ in range(k):
         na = int(rng.integers(0, 1500)) if rng.random() < 0.9 else 0
         nb = int(rng.integers(1, 1500))
+        if rng.random() < 0.12:                                        # round 5: pairs of several multi-tile segments per workgroup
+            na, nb = int(rng.integers(2500, 7000)), int(rng.integers(2500, 7000))   # (segments requested ahead ACROSS pairs)
         A = (rng.uniform(0, 1, (max(na, 1), 128)).astype(np.float32) * np.float32(rng.choice([1, 50, 400])))[:na]
         B = rng.uniform(0, 1, (nb, 128)).astype(np.float32) * np.float32(rng.choice([1, 50, 400]))
         if na and rng.random() < 0.5:
