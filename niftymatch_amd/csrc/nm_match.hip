@@ -1031,6 +1031,22 @@ __device__ __forceinline__ void match_top2_body(const float *__restrict__ A, int
 #ifndef NM_COARSE_CROSS
 #define NM_COARSE_CROSS 1
 #endif
+#ifndef NM_COARSE_PRIO
+#define NM_COARSE_PRIO 1
+#endif
+// Diagnostic builds only (tools/build_variant.py ... -DNM_COARSE_STAMPS=1, read by tools/kcoarse_stamps.py): s_memtime at eight
+// points of a tile iteration, every wave of workgroup 0, the first 64 iterations. No stamp executes in the product.
+#ifdef NM_COARSE_STAMPS
+__device__ unsigned long long nm_coarse_stamps[8 * 64 * 8];
+#define NM_STAMP(K)                                                                                                      \
+    do {                                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t[K]) :: "memory");                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+    } while (0)
+#else
+#define NM_STAMP(K) do { } while (0)
+#endif
 __global__ __launch_bounds__(512, 1) void match_coarse_kernel(MatchBatch bt)
 {
     constexpr int ROWB = DIM * 2, IMG = TILE_C * ROWB, SLOT0 = 2 * IMG, SLOTB = TILE_C * 16, QREG = SLOT0 + 2 * SLOTB;
@@ -1052,7 +1068,7 @@ __global__ __launch_bounds__(512, 1) void match_coarse_kernel(MatchBatch bt)
     typedef __attribute__((address_space(3))) void lds_void;
     // Pair directory: sizes and plan of every pair of the call, read once by sixteen lanes (the device-memory latency of
     // the plan used to be exposed to all eight waves at every pair change) and kept in 1 KiB of LDS behind the query region.
-    constexpr int DIR = QREG + QB * ROWB, DIR_STRIDE = 16;
+    constexpr int DIR = QREG + QB * ROWB, DIR_STRIDE = 16, NAV = DIR + 1024;     // + 8 x 256 B of query norms
     static_assert(sizeof(MatchPlan) == 10 * sizeof(int) && DIR_STRIDE >= 12, "directory entry: nA, nB, the plan");
     int *const dir = reinterpret_cast<int *>(ldsb + DIR);
     if (tid < bt.n) {
@@ -1074,10 +1090,8 @@ __global__ __launch_bounds__(512, 1) void match_coarse_kernel(MatchBatch bt)
         PlanGroup grp;
         unit_t u_end;
         SegIter it;
-        __amdgpu_buffer_rsrc_t rsA, rsB;
-        const float *na;
-        const uint4 *nbslot;
-        float4 *partial;
+        __amdgpu_buffer_rsrc_t rsA, rsB, rsS, rsN;        // fp16 images of the queries / candidates, the candidates' norm k-slots,
+        float4 *partial;                                  // the queries' norms
         float *partial3;
     };
     struct Seg { int pc, qbl, tt, Lc, qb, t0, ntiles; };
@@ -1103,21 +1117,38 @@ __global__ __launch_bounds__(512, 1) void match_coarse_kernel(MatchBatch bt)
             cx.it.init(group_begin(cx.grp, cx.vg), cx.u_end);
             cx.rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(c.Bh), 0, nB * ROWB, 0x00020000);
             cx.rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(c.Ah), 0, nA * ROWB, 0x00020000);
-            cx.na = c.na; cx.nbslot = c.nbslot; cx.partial = c.partial; cx.partial3 = c.partial3;
+            // (prep_kernel pads the slots to whole tiles)
+            cx.rsS = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(c.nbslot), 0, plan.T * SLOTB, 0x00020000);
+            cx.rsN = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(c.na), 0, nA * 4, 0x00020000);
+            cx.partial = c.partial; cx.partial3 = c.partial3;
             if (cx.it.next(cx.plan, cx.grp, u)) return true;
         }
         return false;
     };
-    auto dma_tile = [&](const PairCtx &cx, int tile, int b) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(cx.rsB, (lds_void *)(ldsb + b * IMG + (wave_u * 4 + t) * 1024), 16, (int)dvoff[t],
-                                                     (tile * TILE_C + 4 * (wave_u * 4 + t)) * ROWB, 0, 0);
+    // A tile = its 32 KiB image (four 1 KiB pieces per wave) and its 2 KiB of norm k-slots (one piece each from waves 0 and 1),
+    // all by LDS-DMA. (Until round 5 the slots went through registers -- loaded when the tile was requested, written to LDS an
+    // iteration later: the compiler carried them around the loop in a phi, and its copy on the back edge waited with vmcnt(0),
+    // i.e. for the tile image requested a few hundred cycles earlier. Every iteration exposed a whole request latency:
+    // ~900 of ~5 500 cycles, `tools/kcoarse_stamps.py`.)
+    typedef __amdgpu_buffer_rsrc_t rsrc_t;
+    auto dma_piece = [&](rsrc_t rsB, int tile, int b, int t) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void *)(ldsb + b * IMG + (wave_u * 4 + t) * 1024), 16, (int)dvoff[t],
+                                                 (tile * TILE_C + 4 * (wave_u * 4 + t)) * ROWB, 0, 0);
     };
-    auto dma_queries = [&](const PairCtx &cx, int i0) {
+    auto dma_slots = [&](rsrc_t rsS, int tile, int b) {
+        if (wave_u < 2)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (lds_void *)(ldsb + SLOT0 + b * SLOTB + wave_u * 1024), 16, lane * 16,
+                                                     tile * SLOTB + wave_u * 1024, 0, 0);
+    };
+    auto dma_tile = [&](rsrc_t rsB, rsrc_t rsS, int tile, int b) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dma_piece(rsB, tile, b, t);
+        dma_slots(rsS, tile, b);
+    };
+    auto dma_queries = [&](rsrc_t rsA, int i0) {
 #pragma unroll
         for (int t = 0; t < 8; ++t)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(cx.rsA, (lds_void *)(ldsb + QREG + (wave_u * 8 + t) * 1024), 16, (int)dvoff[t & 3],
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void *)(ldsb + QREG + (wave_u * 8 + t) * 1024), 16, (int)dvoff[t & 3],
                                                      (i0 + 4 * (wave_u * 8 + t)) * ROWB, 0, 0);
     };
     auto locate = [&](const PairCtx &cx, unit_t u) {
@@ -1127,17 +1158,24 @@ __global__ __launch_bounds__(512, 1) void match_coarse_kernel(MatchBatch bt)
         sg.ntiles = min(sg.Lc - sg.tt, (int)(cx.u_end - u));
         return sg;
     };
-    auto norm_of = [&](const PairCtx &cx, int qb) { const int qi = qb * QB + wave * 32 + r; return (qi < cx.nA) ? cx.na[qi] : 0.f; };
+    // the norms of a wave's 32 queries: 128 B of the wave's own 256-byte LDS slot, by LDS-DMA as well (rows >= nA read as 0) -- no
+    // load of the tile loop returns into registers, so no wait of the compiler's can stand in it
+    auto dma_norms = [&](rsrc_t rsN, int qb) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsN, (lds_void *)(ldsb + NAV + wave_u * 256), 4, r * 4, (qb * QB + wave_u * 32) * 4, 0, 0);
+    };
+    auto norm_read = [&]() { return *reinterpret_cast<const float *>(ldsb + NAV + wave * 256 + r * 4); };
 
     PairCtx pc_cur, pc_nxt;
     unit_t u;
+#ifdef NM_COARSE_STAMPS
+    int stamp_it = 0;
+    unsigned long long stamp_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     if (!open_pair(0, pc_cur, u)) return;
     pc_nxt = pc_cur;
     Seg cur = locate(pc_cur, u);
     bool ahead = false;                                   // the current segment's queries and first tile(s) were requested ahead
     int g = 0;                                            // stream tile index of the current segment's first tile (its parity picks the buffer)
-    float nav = 0.f, nav_next = 0.f;
-    uint4 sts = make_uint4(0u, 0u, 0u, 0u);
     u32x4 frA[8], frB[8];
     for (;;) {
         unit_t u_next = 0;
@@ -1147,28 +1185,26 @@ __global__ __launch_bounds__(512, 1) void match_coarse_kernel(MatchBatch bt)
             if (NM_COARSE_CROSS) have_next = cross = true;
             else restart = true;
         }
-        const PairCtx &pn = cross ? pc_nxt : pc_cur;      // (uniform: the compiler selects the fields it needs)
+        // the descriptors the NEXT segment's requests go through, by value (a reference picked at run time sent the
+        // contexts to scratch memory and every request through a waterfall loop)
+        const rsrc_t nA_rs = cross ? pc_nxt.rsA : pc_cur.rsA, nB_rs = cross ? pc_nxt.rsB : pc_cur.rsB;
+        const rsrc_t nS_rs = cross ? pc_nxt.rsS : pc_cur.rsS, nN_rs = cross ? pc_nxt.rsN : pc_cur.rsN;
         Seg nxt = cur;
-        if (have_next) nxt = locate(pn, u_next);
+        if (have_next) nxt = cross ? locate(pc_nxt, u_next) : locate(pc_cur, u_next);
         const int ntiles = cur.ntiles, t0 = cur.t0;
         if (!ahead) {
             // slow path. Every wave is past the barrier of the previous stream tile (or this is the start): both tile buffers,
             // the slots and the query region are free
-            dma_queries(pc_cur, cur.qb * QB);
-            nav = norm_of(pc_cur, cur.qb);
-            dma_tile(pc_cur, t0, g & 1);
-            if (tid < TILE_C) *reinterpret_cast<uint4 *>(ldsb + SLOT0 + (g & 1) * SLOTB + tid * 16) = pc_cur.nbslot[t0 * TILE_C + tid];
-            if (ntiles > 1) {                             // stream tile g + 1
-                if (tid < TILE_C) sts = pc_cur.nbslot[(t0 + 1) * TILE_C + tid];
-                dma_tile(pc_cur, t0 + 1, (g + 1) & 1);
-            }
+            dma_queries(pc_cur.rsA, cur.qb * QB);
+            dma_norms(pc_cur.rsN, cur.qb);
+            dma_tile(pc_cur.rsB, pc_cur.rsS, t0, g & 1);
+            if (ntiles > 1) dma_tile(pc_cur.rsB, pc_cur.rsS, t0 + 1, (g + 1) & 1);    // stream tile g + 1
             // (LDS-DMA is tracked per wave: every wave drains ITS transfers before the barrier -- see match_top2_body)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             f16_fetch<0>(frA, ldsb + (g & 1) * IMG + r * ROWB, foff);
-        } else {
-            nav = nav_next;
         }
+        const float nav = norm_read();                    // (requested ahead: landed before the previous segment's second barrier)
         // per-lane MFMA fragments of the wave's 32 queries (k-steps 0..7; prep_kernel applied the -2) and the norm k-slot
         u32x4 qw[16];
 #pragma unroll
@@ -1195,47 +1231,66 @@ __global__ __launch_bounds__(512, 1) void match_coarse_kernel(MatchBatch bt)
             const char *tb = ldsb + b * IMG + r * ROWB;
             const char *sp = ldsb + SLOT0 + b * SLOTB + r * 16;
             int g1 = KEY_INF, g2 = KEY_INF;               // of groups 2 n - 1 (slots 0..31) and 2 n (slots 32..63) together
+            // Issue priority: the two waves of a SIMD do not share it evenly -- one of them runs almost at its solo speed and
+            // then idles ~1 200 cycles at the tile's barrier, the other (the critical path) takes ~30 % longer through the same
+            // instructions (tools/kcoarse_stamps.py). A wave is raised from the barrier to the end of the iteration (the
+            // request of the next tile and the last half group) and lowered for the first three half groups: -1.0 to -1.4 % per
+            // launch, same box (static priorities for half the waves: no change; alternating by tile parity: -0.7 %).
+            if (NM_COARSE_PRIO) __builtin_amdgcn_s_setprio(0);
+            NM_STAMP(0);
             f16_fetch<4>(frB, tb, foff);
             f16_slots(a0, a1, sp, qslot);
             if (n == 0) {
                 f16_half<false, 0>(a0, a1, b0, frA, qw, g1, g2);
+                NM_STAMP(1);
                 f16_fetch<0>(frA, tb + 64 * ROWB, foff);
                 f16_half<false, 4>(a0, a1, b1, frB, qw, g1, g2);
             } else {
                 f16_half<true, 0>(a0, a1, b0, frA, qw, g1, g2);
+                NM_STAMP(1);
                 f16_fetch<0>(frA, tb + 64 * ROWB, foff);
                 f16_half<true, 4>(a0, a1, b1, frB, qw, g1, g2);
             }
+            NM_STAMP(2);
             f16_fetch<4>(frB, tb + 64 * ROWB, foff);
             f16_slots(b0, b1, sp + 64 * 16, qslot);
             f16_half<true, 0, 32>(b0, b1, a0, frA, qw, g1, g2);
-            // stream tiles g + n + 1 (landed by now; its slots are still in registers) and g + n + 2 (to be requested)
+            NM_STAMP(3);
+            // stream tiles g + n + 1 (requested an iteration ago: landed by now) and g + n + 2 (to be requested)
             const bool in1 = n + 1 < ntiles, in2 = n + 2 < ntiles;
             const bool ex1 = in1 || have_next;
+            bool ex2 = false;                                         // stream tile g + n + 2 exists and is requested in this iteration
+            int tile2 = 0;
             if (ex1) {
-                if (tid < TILE_C) *reinterpret_cast<uint4 *>(ldsb + SLOT0 + (b ^ 1) * SLOTB + tid * 16) = sts;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                NM_STAMP(4);
                 __syncthreads();
+                if (NM_COARSE_PRIO) __builtin_amdgcn_s_setprio(2);
+                NM_STAMP(5);
                 const int k2 = n + 2 - ntiles;                        // index in the next segment when tile g + n + 2 lies there
-                const bool ex2 = in2 || (have_next && ntiles >= 2 && k2 < nxt.ntiles);
-                if (ex2) {
-                    if (in2) {
-                        if (tid < TILE_C) sts = pc_cur.nbslot[(t0 + n + 2) * TILE_C + tid];
-                        dma_tile(pc_cur, t0 + n + 2, b);
-                    } else {
-                        if (tid < TILE_C) sts = pn.nbslot[(nxt.t0 + k2) * TILE_C + tid];
-                        dma_tile(pn, nxt.t0 + k2, b);
-                    }
-                }
+                ex2 = in2 || (have_next && ntiles >= 2 && k2 < nxt.ntiles);
+                tile2 = in2 ? t0 + n + 2 : nxt.t0 + k2;
                 if (n == 0 && have_next && ntiles >= 2) {             // every wave holds its fragments: the query region is free
-                    dma_queries(pn, nxt.qb * QB);
-                    nav_next = norm_of(pn, nxt.qb);
+                    dma_queries(nA_rs, nxt.qb * QB);
+                    dma_norms(nN_rs, nxt.qb);
                     next_ahead = true;
                 }
                 if (in1 || next_ahead) f16_fetch<0>(frA, ldsb + (b ^ 1) * IMG + r * ROWB, foff);
             }
+            NM_STAMP(6);
+            // (The request spread over the last half group, one piece behind each k-step, measured 1.5 % SLOWER than five
+            // instructions back to back here: 651 against 642 us per 16-pair launch, same box.)
+            if (ex2) dma_tile(in2 ? pc_cur.rsB : nB_rs, in2 ? pc_cur.rsS : nS_rs, tile2, b);
             f16_half<true, 4, 32>(b0, b1, a1, frB, qw, g1, g2);
             fold(g1, g2, g2, n);
+            NM_STAMP(7);
+#ifdef NM_COARSE_STAMPS
+            if (wg == 0 && stamp_it < 64 && lane == 0) {              // (the stores' cost falls into segment 7 -> 0')
+#pragma unroll
+                for (int k = 0; k < 8; ++k) nm_coarse_stamps[(wave * 64 + stamp_it) * 8 + k] = stamp_t[k];
+            }
+            ++stamp_it;
+#endif
         }
         asm volatile("s_nop 15\n\ts_nop 3" : "+v"(b0), "+v"(b1));
         select_half<COARSE_SLOT_BITS>(b0, b1, best, ntiles);       // group 2 ntiles - 1: slots 0..31 of "iteration" ntiles
@@ -2414,7 +2469,7 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
     }
     const size_t lds_full = (size_t)2 * TILE_C * KP * sizeof(float);
     // coarse pass: two 32 KiB images + the norm slots; the staged query block (256 rows at a 272-byte pitch) is as large
-    const size_t lds_bytes = screen == 2 ? lds_full + 1024 : lds_full;      // + the coarse pass's pair directory
+    const size_t lds_bytes = screen == 2 ? lds_full + 1024 + 2048 : lds_full;      // + the coarse pass's pair directory and query norms
     static_assert(2 * TILE_C * (DIM * 2) + 2 * TILE_C * 16 + QB * (DIM * 2) == 2 * TILE_C * KP * sizeof(float),
                   "coarse pass: two tile images, the norm slots and the query region take what the other screens' tiles take");
     // per call: the attribute is per device, and a process may drive several (cheap host-side call, not a stream op)
@@ -2758,3 +2813,10 @@ int nm_sift_match_merge_f32(const float *min1, const int *idx1, const float *min
 }
 
 }  // extern "C"
+
+#ifdef NM_COARSE_STAMPS
+extern "C" __attribute__((visibility("default"))) int nm_debug_coarse_stamps(unsigned long long *host_dst)
+{
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(nm_coarse_stamps), sizeof(nm_coarse_stamps));
+}
+#endif
