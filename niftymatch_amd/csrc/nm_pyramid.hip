@@ -532,6 +532,8 @@ __global__ __launch_bounds__(256) void conv_pk_kernel(NmConvBatch batch, int wid
     pk_cols_epilogue<R, WRITE_DOG, WRITE_GRAD, WRITE_BUF>(s_in, s_mid, w, tid, x0, y0, width, height, result, dog, grad, down);
 }
 
+// (Round 5, measured and removed: issue priorities (s_setprio 3 while the tile's loads are issued / 2 or 1 in the epilogue / both):
+// 54.2-54.9 us per frame against 54.4-54.5, 64-frame chain, same box -- nothing beyond the run-to-run spread.)
 // (Round 5, measured and removed: 64-ROW tiles with 512 threads -- the share of halo rows the row pass filters and the loads
 // fetch drops from 1.81 to 1.41 at R = 13 and from 1.44 to 1.22 at R = 7, the row tasks mapped densely (row pair fastest) so
 // that whole waves skip the pass; bit-identical (60 GPU tests). 64-frame chain: 57.83 -> 57.91 us per frame with the DoG
