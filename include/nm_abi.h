@@ -181,6 +181,11 @@ NM_API size_t nm_find_keypoints3_compact_workspace_bytes(int width, int height);
 NM_API int nm_find_keypoints3_compact_f32(const float *const dog[5], int width, int height, float peak_threshold,
                                           float edge_threshold, float xper, float sigma_0, int num_dogs, int capacity,
                                           float *out, int *d_counts, void *workspace, void *stream);
+/* Tuning (extension, no counterpart in the reference): the batched detection launches of the frame driver take unit groups of 20
+ * image rows instead of 5 when the launch still has at least `min_groups` of them (default 2048; results are identical
+ * either way, tests/test_gpu_frame.py). min_groups < 0 restores the default; INT_MAX disables the tall form. Returns the
+ * previous value. */
+NM_API int nm_sift_set_detect_tall_min(int min_groups);
 /* nm_compact_keypoints for three dense maps at once (three launches instead of nine); d_counts: 3 device ints. */
 NM_API size_t nm_compact3_workspace_bytes(int num_pixels);
 NM_API int nm_compact_keypoints3(const float *const dense[3], int num_pixels, float *const out[3], int *d_counts,

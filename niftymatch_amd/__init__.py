@@ -67,6 +67,7 @@ _SIGNATURES = {
     "nm_sift_match_set_screen": (_I, [_I]),
     "nm_sift_match_get_screen": (_I, []),
     "nm_sift_match_set_distance_mode": (_I, [_I]),
+    "nm_sift_set_detect_tall_min": (_I, [_I]),
     "nm_sift_match_get_distance_mode": (_I, []),
     "nm_sift_match_distance_listed": (_I, [_P, _I, _I, _P, _P, _P]),
     "nm_sift_match_f32": (_I, [_P, _I, _P, _I, _P, _P, _F, _P, _P]),
@@ -432,6 +433,12 @@ def set_match_screen(name):
 def get_match_screen():
     v = lib().nm_sift_match_get_screen()
     return [k for k, x in MATCH_SCREENS.items() if x == v][0]
+
+
+def set_detect_tall_min(min_groups=-1):
+    """Batched detection launches with at least `min_groups` 20-row unit groups take the tall form (default 2048; -1 restores
+    it, 2**31 - 1 disables it). Returns the previous value. Results do not depend on it."""
+    return lib().nm_sift_set_detect_tall_min(int(min_groups))
 
 
 DISTANCE_MODES = {"exact": 0, "mfma": 1}

@@ -130,15 +130,24 @@ __device__ __forceinline__ float dpp_from_upper(float own, float edge)   // lane
 __device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 __device__ __forceinline__ float min3f(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
 
-constexpr int DET_ROWS = 5;      // image rows per workgroup: 7 rows are loaded for 5 tested. 4 was best while the kernel read
-                                 // 5 DoG planes; reading 6 level planes, 5 rows are 0.6-0.7 % of the headline better (same box,
-                                 // three alternating runs); the 12 sub-lists per row must fit the 64-lane scan: <= 5
+// Image rows per unit group (one workgroup, or one quarter of a tail workgroup): ROWS + 2 rows are loaded and absorbed into the
+// sliding window for ROWS rows tested, so the halo share falls with ROWS (1.4 at 5, 1.1 at 20) -- and so does the number of
+// workgroups. Round 5: launches with thousands of unit groups (the 64-frame calls of the frame driver) take DET_ROWS_TALL:
+// octave 0 of 64 frames 1 060 -> 990 us alone, +2.5-3 % on the headline (three alternations, same box:
+// 2 936/2 959/2 994 against 3 034/3 033/2 943 at 20 rows and 3 038/3 044/3 027 at 27); a single frame keeps DET_ROWS (with 20
+// rows its 432 workgroups no longer fill the chip: 279 -> 582 us per frame). The octave-tail kernel keeps DET_ROWS too.
+// (Until round 5 the sub-list scan below took one entry per lane, which capped the rows at 5; 7 rows alone measured 24 %
+// SLOWER than 5, 12 rows 8 % slower, 16 equal, 20 7 % faster: profiles/r05_af_detect_rows.txt.)
+constexpr int DET_ROWS = 5;
+constexpr int DET_ROWS_TALL = 20;
 
-struct DetectSmem {
-    unsigned char s_x[DET_ROWS][3][4][64];    // candidate lanes per (row, level, wave), in lane order
-    int s_cnt[DET_ROWS * 12 + 1];              // sub-list lengths, then their exclusive scan (+ total)
-    int s_acc[DET_ROWS * 3], s_last[DET_ROWS * 3], s_wtot[4], s_pref[257];
+template <int ROWS>
+struct DetectSmemT {
+    unsigned char s_x[ROWS][3][4][64];    // candidate lanes per (row, level, wave), in lane order
+    int s_cnt[ROWS * 12 + 1];              // sub-list lengths, then their exclusive scan (+ total)
+    int s_acc[ROWS * 3], s_last[ROWS * 3], s_wtot[4], s_pref[257];
 };
+typedef DetectSmemT<DET_ROWS> DetectSmem;
 
 // What one unit group needs of one frame's octave (filled from NmDetectArgs by the launch wrapper, or from the tail
 // kernel's per-frame tables).
@@ -164,11 +173,12 @@ struct DetectView {
 // threadIdx.x / 256 works on sm_all[q]); the workgroup barriers inside are shared, so the refinement loop runs for the
 // LONGEST candidate list of the NQ groups. !active: the quarter has no unit group (the last item of a segment): it computes on
 // a clamped one and stores nothing.
-template <bool DENSE, bool LEV, bool MASKED, bool SC1 = false, int NQ = 1>
-__device__ __forceinline__ void detect_stage_body(const DetectView &a, int blk, DetectSmem *sm_all, bool active = true)
+template <bool DENSE, bool LEV, bool MASKED, bool SC1 = false, int NQ = 1, int ROWS = DET_ROWS>
+__device__ __forceinline__ void detect_stage_body(const DetectView &a, int blk, DetectSmemT<ROWS> *sm_all, bool active = true)
 {
+    constexpr int DET_ROWS = ROWS;                          // (shadows the namespace constant inside this function)
     const int tid = (NQ > 1) ? (int)(threadIdx.x & 255) : (int)threadIdx.x;
-    DetectSmem &sm = sm_all[(NQ > 1) ? (threadIdx.x >> 8) : 0];
+    DetectSmemT<ROWS> &sm = sm_all[(NQ > 1) ? (threadIdx.x >> 8) : 0];
     auto &s_x = sm.s_x; auto &s_cnt = sm.s_cnt; auto &s_acc = sm.s_acc; auto &s_last = sm.s_last; auto &s_wtot = sm.s_wtot;
     auto &s_pref = sm.s_pref;
     const float *pl[6];                                    // LEV: the six Gaussian levels, else the five DoG planes
@@ -274,19 +284,25 @@ __device__ __forceinline__ void detect_stage_body(const DetectView &a, int blk, 
         }
     }
     __syncthreads();
-    // exclusive scan of the 48 sub-list lengths -> flattened candidate order (row, level, column): s_cnt[q] = first index
+    // exclusive scan of the DET_ROWS x 12 sub-list lengths -> flattened candidate order (row, level, column): s_cnt[q] = first
+    // index. A lane of wave 0 takes EPL consecutive entries (serial prefix inside, wave scan of the lane totals).
     if (wave == 0) {
-        const int c = lane < DET_ROWS * 12 ? s_cnt[lane] : 0;
-        int incl = c;
+        constexpr int NSUB = DET_ROWS * 12, EPL = (NSUB + 63) / 64;
+        int c[EPL], sum = 0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { const int q = lane * EPL + e; c[e] = q < NSUB ? s_cnt[q] : 0; sum += c[e]; }
+        int incl = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int o = __shfl_up(incl, d);
             if (lane >= d) incl += o;
         }
-        if (lane < DET_ROWS * 12) s_cnt[lane] = incl - c;
-        if (lane == DET_ROWS * 12 - 1) s_cnt[DET_ROWS * 12] = incl;
-        if (lane < DET_ROWS * 3) s_acc[lane] = 0;
+        int run = incl - sum;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { const int q = lane * EPL + e; if (q < NSUB) s_cnt[q] = run; run += c[e]; }
+        if (lane == 63) s_cnt[NSUB] = incl;
     }
+    if (tid < DET_ROWS * 3) s_acc[tid] = 0;
     __syncthreads();
     const int total = s_cnt[DET_ROWS * 12];
     int total_all = total;                                  // barriers inside the loop: every quarter runs the longest list

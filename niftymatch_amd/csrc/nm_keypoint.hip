@@ -2,6 +2,7 @@
 // Replaces kernels/keypoint.cu:19-251 and the thrust::copy_if of sift/pyramidata.cu:84-91. The reference's texture
 // fetches at (x+0.5,y+0.5) are exact texel loads (utils/cudatex2D.cu:15-19), so planes are read as plain arrays.
 #include <algorithm>
+#include <atomic>
 #include "nm_common.hpp"
 #include "nm_fpspec.hpp"
 #include "nm_keypoint.hpp"
@@ -228,10 +229,10 @@ __global__ __launch_bounds__(1024) void scan_counts3_kernel(NmCompact3 c)
 // their halo explicitly. The 26-neighbour strict extremum test is branch-free: per plane, max3/min3 of each row, then
 //   is_max(level l) = c > max(M9[l], M9[l+2], M8[l+1]),  M9 = max of a plane's 3x3, M8 = the 3x3 without its centre.
 // Only accepted candidates (rare) run the divergent sub-pixel refinement from global memory.
-template <bool DENSE, bool LEV = false, bool MASKED = DENSE>
+template <bool DENSE, bool LEV = false, bool MASKED = DENSE, int ROWS = DET_ROWS>
 __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
 {
-    __shared__ DetectSmem sm;
+    __shared__ DetectSmemT<ROWS> sm;
     if (DENSE && a.fill_blocks > 0 && (int)blockIdx.x >= a.det_blocks) {
         // the launch's reset part: -1 into what lies behind this octave's region in the three dense maps
         const size_t first = (size_t)a.ow * a.oh;
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
     v.mask = MASKED ? (DENSE ? a.mask : a.masks[frame]) : nullptr; v.mask_w = a.mask_w; v.mask_h = a.mask_h;
     v.ow = a.ow; v.oh = a.oh; v.peak = a.peak; v.edge = a.edge; v.xper = a.xper; v.sigma0 = a.sigma0;
     v.num_dogs = a.num_dogs; v.n_blocks = a.n_blocks; v.nseg = a.nseg;
-    detect_stage_body<DENSE, LEV, MASKED>(v, blockIdx.x, &sm);
+    detect_stage_body<DENSE, LEV, MASKED, false, 1, ROWS>(v, blockIdx.x, &sm);
 }
 
 __global__ __launch_bounds__(1024) void scan_book_kernel(NmScanArgs a)
@@ -310,13 +311,26 @@ __global__ __launch_bounds__(256) void gather_stage_kernel(NmGatherArgs a)
 
 }  // namespace
 
+#ifndef NM_DET_TALL_MIN_DEFAULT
+#define NM_DET_TALL_MIN_DEFAULT 2048             // eight workgroups per CU
+#endif
+constexpr int DET_TALL_MIN_DEFAULT = NM_DET_TALL_MIN_DEFAULT;
+static std::atomic<int> g_tall_min{DET_TALL_MIN_DEFAULT};
+
 int nm_launch_detect_octave(const NmDetectArgs &d, const NmScanArgs &s, const NmGatherArgs &g, hipStream_t stream)
 {
     if (d.n_blocks <= 0 || d.n <= 0) return 0;
     const dim3 grid(d.nseg * nm_divup(d.oh, DET_ROWS), d.n);
     const bool prof = s.octave == 0;
     if (prof) nm_prof_begin(NM_PROF_DETECT_O0, stream);
-    if (d.from_levels && d.any_mask) hipLaunchKernelGGL((detect_stage_kernel<false, true, true>), grid, dim3(256), 0, stream, d);
+    // tall unit groups when there are thousands of them even so (see DET_ROWS_TALL)
+    const dim3 tall(d.nseg * nm_divup(d.oh, DET_ROWS_TALL), d.n);
+    const bool use_tall = d.from_levels && (long)tall.x * tall.y >= g_tall_min.load(std::memory_order_relaxed);
+    if (use_tall && d.any_mask)
+        hipLaunchKernelGGL((detect_stage_kernel<false, true, true, DET_ROWS_TALL>), tall, dim3(256), 0, stream, d);
+    else if (use_tall)
+        hipLaunchKernelGGL((detect_stage_kernel<false, true, false, DET_ROWS_TALL>), tall, dim3(256), 0, stream, d);
+    else if (d.from_levels && d.any_mask) hipLaunchKernelGGL((detect_stage_kernel<false, true, true>), grid, dim3(256), 0, stream, d);
     else if (d.from_levels) hipLaunchKernelGGL((detect_stage_kernel<false, true, false>), grid, dim3(256), 0, stream, d);
     else if (d.any_mask) hipLaunchKernelGGL((detect_stage_kernel<false, false, true>), grid, dim3(256), 0, stream, d);
     else hipLaunchKernelGGL((detect_stage_kernel<false, false, false>), grid, dim3(256), 0, stream, d);
@@ -340,6 +354,11 @@ extern "C" {
 // lists (no dense maps), with the orchestration rules of compute_orientations / compute_descriptors applied (an empty
 // level ends the octave, sift/siftfunctions.cu:145,160; at most `capacity` keypoints in total, :165-169). out: capacity
 // float4, the levels' raster-ordered lists back to back; d_counts: 3 device ints = keypoints kept per level.
+int nm_sift_set_detect_tall_min(int min_groups)
+{
+    return g_tall_min.exchange(min_groups < 0 ? DET_TALL_MIN_DEFAULT : min_groups);
+}
+
 size_t nm_find_keypoints3_compact_workspace_bytes(int width, int height)
 {
     const size_t nb = (size_t)(height > 0 ? height : 1) * nm_divup(width > 0 ? width : 1, 256);

@@ -96,6 +96,42 @@ def test_frame_batch_equals_single_frames(nm, oracle, cuda, wh, n):
         a.close()
 
 
+@pytest.mark.parametrize("wh,n", [((250, 187), 3), ((320, 240), 4), ((37, 41), 2), ((1920, 1080), 2), ((523, 21), 2)])
+def test_tall_detection_groups_give_the_same_frames(nm, oracle, cuda, wh, n):
+    """Round 5: batched detection launches with thousands of unit groups take 20-row groups instead of 5-row ones
+    (nm_sift_set_detect_tall_min). Forced on here for every launch: heights that 20 does not divide, planes lower than one
+    group, widths that 256 does not divide -- the same keypoints, orientations and descriptors as the oracle's, and as the
+    5-row form's bit for bit."""
+    import torch
+    w, h = wh
+    frames = [H.blurred_frame(40 + i, w, h) for i in range(n)]
+    outs = {}
+    for tall_min in (1, 2 ** 31 - 1):
+        prev = nm.set_detect_tall_min(tall_min)
+        try:
+            arenas = [nm.SiftArena(w, h, 16384) for _ in range(n)]
+            nm.detect_describe_batch(arenas, [_t(f, cuda) for f in frames])
+            torch.cuda.synchronize()
+            outs[tall_min] = [(int(a.num_items.item()), a.kpts[:int(a.num_items.item())].cpu().numpy(),
+                               a.orients[:int(a.num_items.item())].cpu().numpy(), a.desc[:int(a.num_items.item())].cpu().numpy())
+                              for a in arenas]
+            for a in arenas:
+                a.close()
+        finally:
+            nm.set_detect_tall_min(prev)
+    nm.set_detect_tall_min(-1)                             # the default, whatever an earlier failure left
+    for i in range(n):
+        t, f = outs[1][i], outs[2 ** 31 - 1][i]
+        assert t[0] == f[0]
+        for k, what in ((1, "keypoints"), (2, "orientations"), (3, "descriptors")):
+            _eq(t[k], f[k], "%s, frame %d, 20-row against 5-row groups" % (what, i))
+        if w * h <= 320 * 240 or i == 0:
+            ref = oracle.sift_detect_describe(frames[i], 16384)
+            assert t[0] == ref["n"]
+            _eq(t[1], ref["kpts"], "keypoints frame %d, 20-row groups" % i)
+            _eq(t[3], ref["desc"], "descriptors frame %d, 20-row groups" % i)
+
+
 def test_frame_batch_rejects_bad_arguments(nm, cuda):
     import torch
     a, b = nm.SiftArena(64, 48, 256), nm.SiftArena(128, 96, 256)
