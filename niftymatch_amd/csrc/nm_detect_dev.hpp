@@ -244,6 +244,9 @@ __device__ __forceinline__ void detect_stage_body(const DetectView &a, int blk, 
         }
     };
     // rows y0-1, y0 absorbed, y0+1 in flight before the loop; iteration j absorbs y+1 and fetches y+2
+    // (Round 5, measured: TWO rows in flight -- a ring of three raw buffers -- is 19 % slower alone, 20-row groups: 1 166 against
+    // 977 us per 64-frame launch, and within the noise on the headline. Like loading both neighbour columns, more loads in
+    // flight cost more than they hide.)
     fetch_row(y0 - 1, 0);
     fetch_row(y0, 1);
     absorb_row(0, 0, 0);
