@@ -31,6 +31,9 @@ static inline hipStream_t nm_stream(void *s) { return reinterpret_cast<hipStream
 // Either one (start, stop) pair, re-recorded by every launch of the site, or a caller-owned list of pairs consumed in
 // launch order (a batched call launches the site several times).
 struct NmProfSite { hipEvent_t start, stop; void *const *list; int n, next; };
+// Detection units (nm_detect_dev.hpp): a unit is one image row of a segment of NM_DET_SEG_W pixels (four waves of NM_DET_WAVE_W tested
+// columns + two halo lanes each); units per row = nm_divup(width, NM_DET_SEG_W); a unit's staging slots stay 256.
+constexpr int NM_DET_WAVE_W = 62, NM_DET_SEG_W = 4 * NM_DET_WAVE_W;
 extern thread_local NmProfSite nm_prof_sites[6];   // NM_PROF_SITES (include/nm_abi.h)
 static inline void nm_prof_begin(int site, hipStream_t st)
 {

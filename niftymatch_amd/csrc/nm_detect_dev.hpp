@@ -140,6 +140,13 @@ __device__ __forceinline__ float min3f(float a, float b, float c) { return __bui
 // SLOWER than 5, 12 rows 8 % slower, 16 equal, 20 7 % faster: profiles/r05_af_detect_rows.txt.)
 constexpr int DET_ROWS = 5;
 constexpr int DET_ROWS_TALL = 20;
+// A wave tests 62 columns: its lanes 0 and 63 hold the halo columns of the 3 x 3 neighbourhoods and test nothing, so every lane
+// loads ONE value per plane and row and the horizontal neighbours come from the adjacent lanes alone. (Until round 5 a wave
+// tested 64 columns and every lane loaded a second value -- the left neighbour on lane 0, the right one elsewhere -- of which
+// two lanes used theirs: half the load instructions of a kernel that is bound by their number. The launch without those loads,
+// results wrong at the wave edges, ran 733 against 972 us; profiles/r05_af_detect_rows.txt.) A unit = one image row of a
+// segment = DET_SEG_W pixels; its staging slots stay 256.
+constexpr int DET_WAVE_W = NM_DET_WAVE_W, DET_SEG_W = NM_DET_SEG_W;
 
 template <int ROWS>
 struct DetectSmemT {
@@ -166,7 +173,7 @@ struct DetectView {
     int num_dogs, n_blocks, nseg;
 };
 
-// One unit group (DET_ROWS rows of one 256-pixel segment) of one frame's octave: `blk` = seg + nseg * row group. 256 threads.
+// One unit group (DET_ROWS rows of one DET_SEG_W-pixel segment) of one frame's octave: `blk` = seg + nseg * row group. 256 threads.
 // SC1: the survivors and the per-unit counts are consumed by ANOTHER workgroup of the SAME launch (the octave-tail kernel's
 // scan + gather item): they are stored write-through (agent-scope atomic stores = global_store ... sc1), see nm_tail.hip.
 // NQ > 1 (the tail kernel's 1024-thread workgroups): NQ unit groups run side by side, 256 threads each (quarter q =
@@ -186,12 +193,11 @@ __device__ __forceinline__ void detect_stage_body(const DetectView &a, int blk, 
     for (int p = 0; p < 6; ++p) pl[p] = a.pl[p];
     const int seg = blk % a.nseg, yg = blk / a.nseg;
     const int y0 = yg * DET_ROWS;
-    const int x = seg * 256 + tid;
     const int lane = tid & 63, wave = tid >> 6;
+    const int x = seg * DET_SEG_W + wave * DET_WAVE_W + lane - 1;      // lanes 0 and 63: halo columns
     const int ow = a.ow, oh = a.oh;
-    const bool xin = x < ow;
-    const int xc = xin ? x : ow - 1;                       // clamped column for safe addressing
-    const int xe = (lane == 0) ? max(xc - 1, 0) : min(xc + 1, ow - 1);
+    const bool xin = lane >= 1 && lane <= DET_WAVE_W && x < ow;        // the lane tests a pixel of the plane
+    const int xc = min(max(x, 0), ow - 1);                             // clamped column for safe addressing
     const float thr = 0.8f * a.peak;
     const float *const mask = MASKED ? a.mask : nullptr;
 
@@ -199,43 +205,31 @@ __device__ __forceinline__ void detect_stage_body(const DetectView &a, int blk, 
     // Rows are FETCHED one iteration ahead of being absorbed into the window (raw values wait in registers), so the
     // global-load latency of row y+2 hides behind the tests of row y instead of stalling every iteration.
     float rmax[5][3], rmin[5][3], cmid[5][2], clr_max[5][2], clr_min[5][2];
-    float raw_mid[2][5], raw_ev[2][5];
-    // Every lane loads its own column and ONE neighbour column (the left neighbour on lane 0, the right one elsewhere): only the
-    // two edge lanes of a wave use the second value (the DPP shifts below take it where they run off the wave), but a load under
-    // `if (edge_lane)` costs the same instruction slot plus an EXEC save / branch / restore and a zeroing move per load -- 42 of
-    // each per workgroup. The addresses are a uniform row base + a 32-bit lane offset (one scalar-base load form each; the
-    // 64-bit per-lane pointer arithmetic of `row[xc]` was 84 VALU instructions per workgroup).
-    const unsigned xb = 4u * (unsigned)xc, eb = 4u * (unsigned)xe;
-    // (Measured and not kept: raw buffer loads -- plane descriptor, row as the scalar offset -- remove the last 36 address
-    // instructions too and ran 270 against 263 us; loading BOTH neighbour columns instead of shifting by DPP removes 70 DPP
-    // moves and their 52 set-up moves per workgroup and ran 371 us: the kernel has no room for 50 % more load instructions.)
+    float raw_mid[2][5];
+    // The addresses are a uniform row base + a 32-bit lane offset (one scalar-base load form each; the 64-bit per-lane pointer
+    // arithmetic of `row[xc]` was 84 VALU instructions per workgroup).
+    const unsigned xb = 4u * (unsigned)xc;
+    // (Measured and not kept: raw buffer loads -- plane descriptor, row as the scalar offset -- remove the last address
+    // instructions too and ran 270 against 263 us; loading BOTH neighbour columns instead of shifting by DPP ran 371 us.)
     auto fetch_row = [&](int yy, int buf) {
         const int yr = min(max(yy, 0), oh - 1);
         const size_t rofs = (size_t)yr * (size_t)ow * 4;      // uniform
         if (LEV) {                              // DoG p = level p + 1 - level p, formed here instead of read
-            float lm[6], le[6];
+            float lm[6];
 #pragma unroll
-            for (int p = 0; p < 6; ++p) {
-                const char *row = reinterpret_cast<const char *>(pl[p]) + rofs;
-                lm[p] = *reinterpret_cast<const float *>(row + xb);
-                le[p] = *reinterpret_cast<const float *>(row + eb);
-            }
+            for (int p = 0; p < 6; ++p) lm[p] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(pl[p]) + rofs + xb);
 #pragma unroll
-            for (int p = 0; p < 5; ++p) { raw_mid[buf][p] = lm[p + 1] - lm[p]; raw_ev[buf][p] = le[p + 1] - le[p]; }
+            for (int p = 0; p < 5; ++p) raw_mid[buf][p] = lm[p + 1] - lm[p];
             return;
         }
 #pragma unroll
-        for (int p = 0; p < 5; ++p) {
-            const char *row = reinterpret_cast<const char *>(pl[p]) + rofs;
-            raw_mid[buf][p] = *reinterpret_cast<const float *>(row + xb);
-            raw_ev[buf][p] = *reinterpret_cast<const float *>(row + eb);
-        }
+        for (int p = 0; p < 5; ++p) raw_mid[buf][p] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(pl[p]) + rofs + xb);
     };
     auto absorb_row = [&](int buf, int slot, int cslot) {
 #pragma unroll
         for (int p = 0; p < 5; ++p) {
-            const float mid = raw_mid[buf][p], ev = raw_ev[buf][p];
-            const float lf = dpp_from_lower(mid, ev), rt = dpp_from_upper(mid, ev);
+            const float mid = raw_mid[buf][p];
+            const float lf = dpp_from_lower(mid, mid), rt = dpp_from_upper(mid, mid);      // (lanes 0 / 63: unused)
             rmax[p][slot] = max3f(lf, mid, rt);
             rmin[p][slot] = min3f(lf, mid, rt);
             cmid[p][cslot] = mid;
@@ -327,7 +321,7 @@ __device__ __forceinline__ void detect_stage_body(const DetectView &a, int blk, 
             g = lo >> 2;                                  // (row, level) group
             const int jr = g / 3, w = lo & 3;
             lvl = g - 3 * jr;
-            px = seg * 256 + w * 64 + s_x[jr][lvl][w][c - s_cnt[lo]];
+            px = seg * DET_SEG_W + w * DET_WAVE_W + s_x[jr][lvl][w][c - s_cnt[lo]] - 1;
             py = y0 + jr;
             // the candidate's planes: selected from the copies above (lvl is 0, 1 or 2) -- a table lookup with a run-time
             // index would be one more dependent memory access at the head of the refinement's chain

@@ -197,7 +197,7 @@ int nm_sift_arena_create(int width, int height, int capacity, nm_sift_arena **ou
     // them is raised (headline 2 934-3 058 against 2 953-3 047) and cost 17 % when both are (2 479-2 498).)
     if (!rc) rc = (int)hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking);
     if (!rc) rc = (int)hipStreamCreateWithFlags(&a->desc, hipStreamNonBlocking);
-    a->max_blocks = height * nm_divup(width, 256);
+    a->max_blocks = height * nm_divup(width, NM_DET_SEG_W);
     a->stage_stride = (size_t)a->max_blocks * 256;
     if (!rc) rc = a->alloc(&a->staging, 3 * a->stage_stride * 4);
     if (!rc) rc = a->alloc(&a->counts, (size_t)3 * a->max_blocks);
@@ -222,7 +222,7 @@ int nm_sift_arena_create(int width, int height, int capacity, nm_sift_arena **ou
                 const int j = o - T;
                 for (int i = 0; i < 6; ++i) h.lev[j][i] = a->lev[o][i];
                 h.grad[j] = a->grad[o];
-                const size_t units = (size_t)(height >> o) * nm_divup(width >> o, 256);
+                const size_t units = (size_t)(height >> o) * nm_divup(width >> o, NM_DET_SEG_W);
                 a->stg_stride[o] = units * 256;
                 rc = a->alloc(&a->stg[o], 3 * a->stg_stride[o] * 4);
                 if (!rc) rc = a->alloc(&a->cnt[o], 3 * units);
@@ -525,7 +525,7 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
             NM_RETURN_IF(hipStreamWaitEvent(side, as[0]->ev_pyr[o], 0));
             forked = true;
 
-            const int nseg = nm_divup(ow, 256);
+            const int nseg = nm_divup(ow, NM_DET_SEG_W);
             const int n_blocks = oh * nseg;
             NmDetectArgs d{};
             NmScanArgs s{};

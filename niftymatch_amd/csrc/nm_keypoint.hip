@@ -361,7 +361,7 @@ int nm_sift_set_detect_tall_min(int min_groups)
 
 size_t nm_find_keypoints3_compact_workspace_bytes(int width, int height)
 {
-    const size_t nb = (size_t)(height > 0 ? height : 1) * nm_divup(width > 0 ? width : 1, 256);
+    const size_t nb = (size_t)(height > 0 ? height : 1) * nm_divup(width > 0 ? width : 1, NM_DET_SEG_W);
     return 3 * nb * 256 * 16 + 2 * 3 * nb * sizeof(int) + 1024;
 }
 
@@ -372,7 +372,7 @@ int nm_find_keypoints3_compact_f32(const float *const dog[5], int width, int hei
     if (width <= 0 || height <= 0 || capacity <= 0) return 0;
     if (!dog || !out || !d_counts || !workspace) return (int)hipErrorInvalidValue;
     hipStream_t st = nm_stream(stream);
-    const int nseg = nm_divup(width, 256), n_blocks = height * nseg;
+    const int nseg = nm_divup(width, NM_DET_SEG_W), n_blocks = height * nseg;
     char *base = static_cast<char *>(workspace);
     NmFrameBook *book = reinterpret_cast<NmFrameBook *>(base);        // 1 KB reserved
     float *staging = reinterpret_cast<float *>(base + 1024);
@@ -443,7 +443,7 @@ int nm_find_keypoints3_reset_f32(const float *const dog[5], const float *mask, i
     NmDetectArgs d{};
     d.n = 1; d.ow = width; d.oh = height; d.peak = peak_threshold; d.edge = edge_threshold; d.xper = xper;
     d.sigma0 = sigma_0; d.num_dogs = num_dogs;
-    d.nseg = nm_divup(width, 256); d.n_blocks = height * d.nseg;
+    d.nseg = nm_divup(width, NM_DET_SEG_W); d.n_blocks = height * d.nseg;
     for (int i = 0; i < 5; ++i) { if (!dog[i]) return (int)hipErrorInvalidValue; d.api_planes[i] = dog[i]; }
     for (int l = 0; l < 3; ++l) { if (!result[l]) return (int)hipErrorInvalidValue; d.dense[l] = result[l]; }
     d.mask = mask; d.mask_w = mask_width; d.mask_h = mask_height;

@@ -562,7 +562,7 @@ bool nm_tail_plan(NmTailArgs &a, int width, int height, int num_octaves, int T, 
         oc.n_a = oc.whole ? 1 : oc.tiles_x * oc.tiles_y;
         oc.n_b = oc.whole ? 0 : oc.n_a;
         oc.b_target = oc.whole ? 1 : oc.n_b;
-        oc.nseg = nm_divup(oc.ow, 256);
+        oc.nseg = nm_divup(oc.ow, NM_DET_SEG_W);
         oc.n_det = nm_divup(oc.nseg * nm_divup(oc.oh, nmdet::DET_ROWS), NQ);
         oc.n_blocks = oc.oh * oc.nseg;
         oc.n_grad = oc.whole ? 3 * nm_divup(oc.oh, GRAD_BAND) : 0;
