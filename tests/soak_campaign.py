@@ -40,8 +40,10 @@ for it in range(n_frames):
             f = np.round(f).astype(np.float32)                         # quantised image: many exact ties / zeros
         frames.append(np.ascontiguousarray(f, dtype=np.float32))
     arenas = [nm.SiftArena(w, h, cap) for _ in range(nb)]
+    nm.set_detect_tall_min(1 if rng.random() < 0.5 else -1)            # round 5: 20-row detection groups forced on half the batches
     nm.detect_describe_batch(arenas, [t(f) for f in frames])
     torch.cuda.synchronize()
+    nm.set_detect_tall_min(-1)
     for a, f in zip(arenas, frames):
         ref = O.sift_detect_describe(f, cap)
         n = int(a.num_items.item())
