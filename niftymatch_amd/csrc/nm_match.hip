@@ -1031,6 +1031,12 @@ __device__ __forceinline__ void match_top2_body(const float *__restrict__ A, int
 #ifndef NM_COARSE_CROSS
 #define NM_COARSE_CROSS 1
 #endif
+#ifndef NM_COARSE_PRIO_LO
+#define NM_COARSE_PRIO_LO 0
+#endif
+#ifndef NM_COARSE_PRIO_HI
+#define NM_COARSE_PRIO_HI 2
+#endif
 #ifndef NM_COARSE_PRIO
 #define NM_COARSE_PRIO 1
 #endif
@@ -1236,7 +1242,7 @@ __global__ __launch_bounds__(512, 1) void match_coarse_kernel(MatchBatch bt)
             // instructions (tools/kcoarse_stamps.py). A wave is raised from the barrier to the end of the iteration (the
             // request of the next tile and the last half group) and lowered for the first three half groups: -1.0 to -1.4 % per
             // launch, same box (static priorities for half the waves: no change; alternating by tile parity: -0.7 %).
-            if (NM_COARSE_PRIO) __builtin_amdgcn_s_setprio(0);
+            if (NM_COARSE_PRIO) __builtin_amdgcn_s_setprio(NM_COARSE_PRIO_LO);
             NM_STAMP(0);
             f16_fetch<4>(frB, tb, foff);
             f16_slots(a0, a1, sp, qslot);
@@ -1265,7 +1271,7 @@ __global__ __launch_bounds__(512, 1) void match_coarse_kernel(MatchBatch bt)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 NM_STAMP(4);
                 __syncthreads();
-                if (NM_COARSE_PRIO) __builtin_amdgcn_s_setprio(2);
+                if (NM_COARSE_PRIO) __builtin_amdgcn_s_setprio(NM_COARSE_PRIO_HI);
                 NM_STAMP(5);
                 const int k2 = n + 2 - ntiles;                        // index in the next segment when tile g + n + 2 lies there
                 ex2 = in2 || (have_next && ntiles >= 2 && k2 < nxt.ntiles);

@@ -485,6 +485,10 @@ __device__ __forceinline__ void pk_cols_epilogue(const float *s_in, const float 
     }
 }
 
+#ifdef NM_CONV_STAMPS        // diagnostic builds only (tools/kconv_stamps.py): where a tile's waves spend their cycles
+__device__ unsigned long long nm_conv_stamps[4096 * 8];
+__device__ unsigned nm_conv_stamp_n;
+#endif
 template <int R, bool WRITE_DOG, bool WRITE_GRAD, bool WRITE_BUF = false>
 __global__ __launch_bounds__(256) void conv_pk_kernel(NmConvBatch batch, int width, int height,
                                                      const float *__restrict__ taps, int tiles_x, int ntiles,
@@ -515,21 +519,45 @@ __global__ __launch_bounds__(256) void conv_pk_kernel(NmConvBatch batch, int wid
 #pragma unroll
     for (int i = 0; i <= 2 * R; ++i) w[i] = (unsigned long long)__float_as_uint(taps[i]);
 
+#ifdef NM_CONV_STAMPS
+    unsigned long long st_[6];
+#define NM_CSTAMP(K) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_[K]) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define NM_CSTAMP(K) do { } while (0)
+#endif
+    NM_CSTAMP(0);
     // phase 1: global -> LDS, two rows per thread, interleaved
     {
         float4 a[NLOAD], b[NLOAD];
         pk_load_pairs<R, NLOAD>(a, b, image, RP, y0 - R, x0, width, height, tid);
         pk_store_pairs<R, NLOAD>(a, b, s_in, RP, 0, tid);
     }
+    NM_CSTAMP(1);
     __syncthreads();
+    NM_CSTAMP(2);
     // phase 2: rows
     {
         const int p = tid & 31, cg = tid >> 5;
         if (p < RP) pk_row_task<R, WRITE_BUF>(s_in, s_mid, w, p, cg, down, x0, y0, width, height);
     }
+    NM_CSTAMP(3);
     __syncthreads();
+    NM_CSTAMP(4);
     // phase 3: columns + epilogue
     pk_cols_epilogue<R, WRITE_DOG, WRITE_GRAD, WRITE_BUF>(s_in, s_mid, w, tid, x0, y0, width, height, result, dog, grad, down);
+#ifdef NM_CONV_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the epilogue's stores acknowledged
+    NM_CSTAMP(5);
+    // one in 61 workgroups of frame 0 records (R, WRITE_GRAD) and its five segment lengths, wave by wave
+    if (frame == 0 && (blk % 61) == 0 && (tid & 63) == 0) {
+        const unsigned slot = atomicAdd(&nm_conv_stamp_n, 1u);
+        if (slot < 4096) {
+            unsigned long long *d = nm_conv_stamps + slot * 8;
+            d[0] = (unsigned long long)(R * 2 + (WRITE_GRAD ? 1 : 0)) | ((unsigned long long)width << 32);
+            for (int k = 0; k < 5; ++k) d[1 + k] = st_[k + 1] - st_[k];
+        }
+    }
+#endif
 }
 
 // (Round 5, measured and removed: issue priorities (s_setprio 3 while the tile's loads are issued / 2 or 1 in the epilogue / both):
@@ -932,3 +960,13 @@ int nm_gradient_f32(const float *source, float *result, int width, int height, v
 }
 
 }  // extern "C"
+
+#ifdef NM_CONV_STAMPS
+extern "C" __attribute__((visibility("default"))) int nm_debug_conv_stamps(unsigned long long *host_dst, unsigned *n, int reset)
+{
+    int rc = (int)hipMemcpyFromSymbol(n, HIP_SYMBOL(nm_conv_stamp_n), sizeof(unsigned));
+    if (!rc) rc = (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(nm_conv_stamps), sizeof(nm_conv_stamps));
+    if (!rc && reset) { const unsigned z = 0; rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(nm_conv_stamp_n), &z, sizeof(z)); }
+    return rc;
+}
+#endif
