@@ -307,7 +307,7 @@ __device__ __forceinline__ void detect_stage_body(const DetectView &a, int blk, 
 #pragma unroll
         for (int q = 0; q < NQ; ++q) total_all = max(total_all, sm_all[q].s_cnt[DET_ROWS * 12]);
     }
-    for (int b0 = 0; b0 < total_all; b0 += 256) {           // 256 candidates per pass (a 4 x 256 pixel unit usually holds < 100)
+    for (int b0 = 0; b0 < total_all; b0 += 256) {           // 256 candidates per pass (a 5 x 248 pixel group usually holds < 100)
         const int c = b0 + tid;
         bool acc = false;
         float4 kp = make_float4(-1.f, -1.f, -1.f, -1.f);

@@ -223,10 +223,10 @@ __global__ __launch_bounds__(1024) void scan_counts3_kernel(NmCompact3 c)
 
 // ---- frame-driver kernels: detect 3 levels of one octave straight into per-unit staging, then scan + book-keeping,
 //      then gather into the output-ordered keypoint list ----
-// A unit is a 256-pixel segment of one image row (units in raster order: u = y * nseg + seg). One workgroup per unit,
-// one pixel per thread. Every lane loads its own column of the 3 rows x 5 DoG planes (15 coalesced 256-B row segments
-// per wave); horizontal neighbours come from the adjacent lanes by DPP wave shifts, the two segment-edge lanes fetch
-// their halo explicitly. The 26-neighbour strict extremum test is branch-free: per plane, max3/min3 of each row, then
+// A unit is one image row of a segment of NM_DET_SEG_W = 248 pixels (units in raster order: u = y * nseg + seg). One workgroup
+// per unit GROUP (DET_ROWS or DET_ROWS_TALL rows of a segment), four waves of 62 tested columns with their edge lanes as halo
+// (nm_detect_dev.hpp). Every lane loads its own column of the window's rows x planes; horizontal neighbours come from the
+// adjacent lanes by DPP wave shifts. The 26-neighbour strict extremum test is branch-free: per plane, max3/min3 of each row, then
 //   is_max(level l) = c > max(M9[l], M9[l+2], M8[l+1]),  M9 = max of a plane's 3x3, M8 = the 3x3 without its centre.
 // Only accepted candidates (rare) run the divergent sub-pixel refinement from global memory.
 template <bool DENSE, bool LEV = false, bool MASKED = DENSE, int ROWS = DET_ROWS>

@@ -17,7 +17,7 @@ struct NmTailOct {
     int n_a;                         // items that produce levels 1..3 (+ the decimated seed): tiles, or 1
     int n_b;                         // items that produce levels 4..5: tiles, or 0 (the whole-plane item continues)
     int b_target;                    // value of the b_done counter when levels 4..5 are complete (n_b, or 1)
-    int nseg, n_det;                 // detection: 256-pixel segments per row, unit groups (DET_ROWS rows x one segment)
+    int nseg, n_det;                 // detection: NM_DET_SEG_W-pixel segments per row, unit groups (DET_ROWS rows x one segment)
     int n_blocks;                    // units = oh * nseg
     int n_grad;                      // whole planes: gradient items (3 levels x row bands); tiles compute it inline
     int decimate;                    // level 3 seeds octave o + 1
