@@ -65,13 +65,12 @@ __device__ __forceinline__ void orient_fetch(const float4 kp, const float2 *__re
     }
 }
 
-// part: ORI_LDS floats private to the wave, [bin][strip]. Returns the number of peaks found (0..2); th0/th1 are valid in
-// every lane.
-__device__ __forceinline__ int orient_finish(const OriSamples &o, float &th0, float &th1, float *part)
+// part: ORI_LDS floats private to the wave, [bin][strip]. First half of a keypoint: zero the partial sums, cast the votes (the
+// only part that reads the gathered samples).
+__device__ __forceinline__ void orient_votes(const OriSamples &o, float *part)
 {
     const int lane = threadIdx.x & 63;
-    th0 = -1.f; th1 = -1.f;
-    if (!o.valid) return 0;
+    if (!o.valid) return;
     const float x = o.x, y = o.y;
     const int xi = o.xi, yi = o.yi, W = o.W;
     const int xmin = o.xmin, xmax = o.xmax, ymin = o.ymin, ymax = o.ymax;
@@ -111,6 +110,14 @@ __device__ __forceinline__ int orient_finish(const OriSamples &o, float &th0, fl
         }
     }
     __builtin_amdgcn_wave_barrier();             // same-wave LDS traffic is in order; this only pins the compiler
+}
+
+// Second half: sums, smoothing, peaks. Returns the number of peaks found (0..2); th0/th1 are valid in every lane.
+__device__ __forceinline__ int orient_peaks(const OriSamples &o, float &th0, float &th1, const float *part)
+{
+    const int lane = threadIdx.x & 63;
+    th0 = -1.f; th1 = -1.f;
+    if (!o.valid) return 0;
 
     float h = 0.f;                                // lane b < 36 owns bin b: partials in strip order
     if (lane < 36) {                              // h = ((row[0] + row[1]) + row[2]) + ... + row[62], reads 9 at a time
@@ -153,7 +160,8 @@ __device__ __forceinline__ int orient_wave(const float4 kp, const float2 *__rest
 {
     OriSamples o;
     orient_fetch(kp, grad, ow, oh, gauss_factor, xper, o);
-    return orient_finish(o, th0, th1, part);
+    orient_votes(o, part);
+    return orient_peaks(o, th0, th1, part);
 }
 
 // LDS of one descriptor wave (floats): [16 cells][9 temporal slots][16 partials] | [9 rows][16] landing words of rejected votes.
@@ -517,19 +525,30 @@ __global__ __launch_bounds__(256) void frame_orient_kernel(NmDescribeArgs a)
     const int stride = gridDim.x * 4;
     int pt = book->oct_base[a.o_begin] + blockIdx.x * 4 + wave;
     OriSamples cur, nxt;
-    auto fetch = [&](int p, OriSamples &o) {
+    auto fetch = [&](int p, const float4 kp, OriSamples &o) {
         const int oc = octave_of(book, a.num_octaves, p);
-        orient_fetch(kpts[p], reinterpret_cast<const float2 *>(a.grad0[frame] + a.grad_off[oc]), a.geom[oc].ow, a.geom[oc].oh, 1.5f,
+        orient_fetch(kp, reinterpret_cast<const float2 *>(a.grad0[frame] + a.grad_off[oc]), a.geom[oc].ow, a.geom[oc].oh, 1.5f,
                      a.geom[oc].xper, o);
     };
-    if (pt < n) fetch(pt, cur);
+    // Two loads deep: the samples of keypoint i + 1 are requested from the keypoint record loaded during keypoint i - 1, behind
+    // the VOTES of keypoint i (the only part that reads samples) and in front of its sums, smoothing and peaks. Round 5 stamps
+    // of the loop as it was (next keypoint's record loaded and its samples requested at the TOP of an iteration): 23 % of a
+    // wave's time per keypoint in that fetch -- the record's latency, exposed, before the dependent gathers could issue --
+    // and a third in the votes, whose first use of the current samples waits with vmcnt(0), i.e. for the gathers issued a
+    // few hundred cycles earlier as well (`profiles/r05_ak_orient_stamps.txt`).
+    const float4 none = make_float4(0.f, 0.f, 0.f, -1.f);           // w < 0: orient_fetch / votes / peaks do nothing
+    float4 kp_next = none, kp_after = none;
+    if (pt < n) fetch(pt, kpts[pt], cur);
+    if (pt + stride < n) kp_next = kpts[pt + stride];
     for (; pt < n; pt += stride) {
         const bool more = pt + stride < n;
-        if (more) fetch(pt + stride, nxt);        // the next keypoint's samples fly while this one is processed
+        orient_votes(cur, s_part[wave]);
+        if (more) fetch(pt + stride, kp_next, nxt);                     // (kp_next landed an iteration ago: nothing newer is in flight)
+        if (pt + 2 * stride < n) kp_after = kpts[pt + 2 * stride];
         float th0, th1;                           // unset components stay -1 (pyramidata.cu:90)
-        orient_finish(cur, th0, th1, s_part[wave]);
+        orient_peaks(cur, th0, th1, s_part[wave]);
         if ((threadIdx.x & 63) == 0) orients[pt] = make_float2(th0, th1);
-        if (more) cur = nxt;
+        if (more) { cur = nxt; kp_next = kp_after; }
     }
 }
 
