@@ -139,7 +139,10 @@ __device__ __forceinline__ float min3f(float a, float b, float c) { return __bui
 // (Until round 5 the sub-list scan below took one entry per lane, which capped the rows at 5; 7 rows alone measured 24 %
 // SLOWER than 5, 12 rows 8 % slower, 16 equal, 20 7 % faster: profiles/r05_af_detect_rows.txt.)
 constexpr int DET_ROWS = 5;
-constexpr int DET_ROWS_TALL = 20;
+#ifndef NM_DET_ROWS_TALL
+#define NM_DET_ROWS_TALL 20
+#endif
+constexpr int DET_ROWS_TALL = NM_DET_ROWS_TALL;
 // A wave tests 62 columns: its lanes 0 and 63 hold the halo columns of the 3 x 3 neighbourhoods and test nothing, so every lane
 // loads ONE value per plane and row and the horizontal neighbours come from the adjacent lanes alone. (Until round 5 a wave
 // tested 64 columns and every lane loaded a second value -- the left neighbour on lane 0, the right one elsewhere -- of which
