@@ -89,6 +89,55 @@ def test_sharded_match_two_ranks_gloo():
     assert out[0][3] == [0, 1, 2, 3] and out[1][3] == [4, 5, 6]
 
 
+def _worker4(rank, world, port, q):
+    """Four ranks: (a) 3 candidates over 4 ranks -- the last shard is EMPTY (neutral triple: +inf, -1, +inf) and candidates 1
+    and 2 (ranks 1 and 2) are equal: the lower global index wins; (b) 1 003 candidates, a tie between shards 0 and 3 and an
+    exact copy of a query in shard 2 (min1 = 0)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib as O
+    O.set_threads(1)
+
+    def shard_fn(Aq, Bs, off):
+        m1, ix, m2 = O.sift_match_shard(Aq.numpy(), Bs.numpy(), off)
+        return torch.from_numpy(m1), torch.from_numpy(ix), torch.from_numpy(m2)
+
+    out = []
+    for nA, nB, dups, copies in ((40, 3, [(1, 2)], []), (200, 1003, [(17, 900)], [(9, 600)])):
+        A = H.synth.descriptors(11, nA)
+        B = H.synth.descriptors(12, nB)
+        for lo, hi in dups:
+            B[lo] = B[hi]
+            A[3] = B[hi] + np.float32(1e-3)
+        for qa, jb in copies:
+            A[qa] = B[jb]
+        b, e = parallel.block_range(nB, world, rank)
+        res = parallel.match_sharded(torch.from_numpy(A), torch.from_numpy(B[b:e].copy()), b, 1.5, shard_fn=shard_fn,
+                                     merge_fn=_cpu_merge)
+        ref, _, _ = O.sift_matches(A, B, 1.5, want_distance=False)
+        out.append((res.numpy().tolist() == ref.tolist(), int(ref[3]), e - b, [int(ref[qa]) for qa, _ in copies]))
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_sharded_match_four_ranks_gloo_empty_shard_and_cross_shard_tie():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker4, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [o[1][0][2] for o in out] == [1, 1, 1, 0]            # case (a): the fourth shard is empty
+    for rank, (a, b) in out:
+        assert a[0] and b[0], rank                              # every rank holds the unsharded answer
+        assert a[1] == 1                                        # tie between shards 1 and 2: the lower global index
+        assert b[1] == 17 and b[3] == [600]                     # tie between shards 0 and 3; the exact copy (min1 = 0) in shard 2
+
+
 def test_single_process_path_without_init():
     import oracle_lib as O
     A = H.synth.descriptors(3, 50); B = H.synth.descriptors(4, 60)
