@@ -21,6 +21,10 @@
 using nmfp::fma32;
 using nmfp::fma64;
 
+#ifndef NM_DESC_ATOMIC
+#define NM_DESC_ATOMIC 0
+#endif
+
 namespace {
 
 constexpr int ORI_MAXW = 10;                    // 22x22 block of the reference -> W <= 10 (orientation.cu:29-30)
@@ -326,6 +330,16 @@ __device__ __forceinline__ void desc_run(const DescSetup &d, float *__restrict__
                 }
             // rounds none of whose 16 samples has a vote inside the grid are skipped (their votes are all +0 into the landing words)
             const unsigned long long voters = __ballot(inwin && (okx[0] || okx[1]) && (oky[0] || oky[1]));
+#if NM_DESC_ATOMIC
+            if (voters) {
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const uint32_t a = (uint32_t)(uintptr_t)loc[c4];
+                    asm volatile("ds_add_f32 %0, %1" : : "v"(a), "v"(wt[2 * c4]) : "memory");
+                    asm volatile("ds_add_f32 %0, %1 offset:%2" : : "v"(a), "v"(wt[2 * c4 + 1]), "n"(DESC_PITCH * 4) : "memory");
+                }
+            }
+#else
 #pragma unroll
             for (int k = 0; k < 4; ++k) {          // rows of this pass in increasing cy: 16 lanes per round, LDS in order
                 if (!((voters >> (16 * k)) & 0xFFFFull)) continue;
@@ -341,10 +355,14 @@ __device__ __forceinline__ void desc_run(const DescSetup &d, float *__restrict__
                 // the rounds pins the program order that the in-order LDS then executes.
                 asm volatile("" ::: "memory");
             }
+#endif
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
     }
+#if NM_DESC_ATOMIC
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     __builtin_amdgcn_wave_barrier();
 
     // lane b owns descriptor elements b and b + 64 (element = 8 cell + t): pairwise tree over the 16 partials (strides 1, 2,
