@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 template <int KIND>
@@ -20,7 +21,8 @@ __global__ __launch_bounds__(1024) void rate_kernel(float *out, int iters, float
     const float m = 1.0001f + seed * 1e-9f, c = seed * 1e-3f;
     const double md = 1.0001 + seed * 1e-12, cd = seed * 1e-3;
     const f2 mp = (f2){m, m}, cp = (f2){c, c};
-    const unsigned long long smask = __ballot(seed * lane > 3.f);
+    const unsigned long long smask = __ballot(seed * lane > 3.f), smask2 = __ballot(seed * lane > 7.f);
+    unsigned long long sm[2] = {smask, smask2};
     asm volatile("v_cmp_gt_f32 vcc, %0, %1" : : "v"(a[0]), "v"(c) : "vcc");
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
@@ -79,11 +81,22 @@ __global__ __launch_bounds__(1024) void rate_kernel(float *out, int iters, float
                 if (KIND == 48) asm volatile("v_rcp_f64 %0, %0" : "+v"(d[i]));
                 if (KIND == 49) asm volatile("v_ldexp_f64 %0, %0, %1" : "+v"(d[i]) : "v"(lane));
                 if (KIND == 50) asm volatile("v_cvt_i32_f64 %0, %1" : "+v"(n[i]) : "v"(d[i]));
+                // round 6: what reading / writing VCC costs (the VOP2 v_cndmask_b32 above issues at 1 / 23 cycles)
+                if (KIND == 51) asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(n[i]) : "v"(lane));
+                if (KIND == 52) asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n\tv_add_f32 %2, %2, %3" : "+v"(n[i]), "+v"(a[i]) : "v"(lane), "v"(c));
+                if (KIND == 53) asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n\tv_add_f32 %2, %2, %3\n\tv_mul_f32 %2, %2, %4\n\tv_sub_f32 %2, %2, %3" : "+v"(n[i]), "+v"(a[i]) : "v"(lane), "v"(c), "v"(m));
+                if (KIND == 54) asm volatile("v_subbrev_co_u32 %0, vcc, 0, %0, vcc" : "+v"(n[i]) : : "vcc");
+                if (KIND == 55) asm volatile("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(sm[i & 1]) : "v"(a[i]), "v"(c));
+                if (KIND == 56) asm volatile("s_and_b64 vcc, %2, %3\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(n[i]) : "v"(lane), "s"(smask), "s"(smask2) : "vcc");
+                if (KIND == 57) asm volatile("s_and_b64 %4, %2, %3\n\tv_cndmask_b32_e64 %0, %0, %1, %4" : "+v"(n[i]) : "v"(lane), "s"(smask), "s"(smask2), "s"(sm[0]));
+                if (KIND == 58) asm volatile("v_cndmask_b32 %0, 0, %1, vcc" : "=v"(n[i]) : "v"(lane));
+                if (KIND == 59) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(n[i]) : "v"(lane), "v"(n[(i + 1) & 7]));
             }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0.f;
     for (int i = 0; i < 8; ++i) s += a[i] + (float)d[i] + (float)n[i] + p[i].x + p[i].y;
+    s += (float)(sm[0] + sm[1]);
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
 }
@@ -115,11 +128,20 @@ static void run(const char *name, float *out, unsigned long long *clk)
     printf("\n");
 }
 
-int main()
+int main(int argc, char **argv)
 {
     float *out; unsigned long long *clk;
+    setvbuf(stdout, nullptr, _IONBF, 0);
     CK(hipMalloc(&out, 2048 * 1024 * 4)); CK(hipMalloc(&clk, 16));
     printf("wave-instructions per cycle per SIMD, by waves per SIMD\n");
+    if (argc > 1 && !strcmp(argv[1], "vcc")) {        // round 6: the VCC group only (52 / 53 / 56 / 57 issue 2 / 4 / 2 / 2 instructions per count)
+        run<4>("v_cndmask_b32 vop2 vcc", out, clk); run<51>("v_cndmask e64 vcc", out, clk); run<13>("v_cndmask e64 sgpr", out, clk);
+        run<58>("v_cndmask vop2 0,v,vcc (new dst)", out, clk); run<59>("v_cndmask vop2 v,v,vcc (new dst)", out, clk);
+        run<52>("vop2 cndmask + v_add (x2)", out, clk); run<53>("vop2 cndmask + 3 f32 (x4)", out, clk);
+        run<54>("v_subbrev_co_u32 vcc", out, clk); run<9>("v_cmp_gt_f32 -> vcc", out, clk); run<55>("v_cmp_gt_f32_e64 -> sgpr", out, clk);
+        run<56>("s_and vcc + vop2 cndmask (x1 valu)", out, clk); run<57>("s_and sgpr + e64 cndmask (x1 valu)", out, clk);
+        return 0;
+    }
     run<0>("v_fma_f32", out, clk); run<5>("v_add_f32", out, clk); run<12>("v_max3_f32", out, clk); run<3>("v_pk_fma_f32", out, clk);
     run<1>("v_fma_f64", out, clk); run<6>("v_mul_f64", out, clk); run<8>("v_cvt_f64_f32", out, clk);
     run<2>("v_add_u32", out, clk); run<7>("v_lshl_add_u32", out, clk); run<10>("v_mad_i32_i24", out, clk); run<11>("v_med3_i32", out, clk);
