@@ -21,10 +21,6 @@
 using nmfp::fma32;
 using nmfp::fma64;
 
-#ifndef NM_DESC_ATOMIC
-#define NM_DESC_ATOMIC 0
-#endif
-
 namespace {
 
 constexpr int ORI_MAXW = 10;                    // 22x22 block of the reference -> W <= 10 (orientation.cu:29-30)
@@ -173,7 +169,10 @@ __device__ __forceinline__ int orient_wave(const float4 kp, const float2 *__rest
 // 10 % fewer VALU instructions, conflict-free banks, the votes' latency hidden behind the next pass's math -> no gain or a
 // loss; no votes at all -> -27 %; LDS float atomics -> 6 x slower), so the layout serves the votes: a sample's two temporal
 // votes go to slots (bint & 7) and (bint & 7) + 1 of the same cell and partial -- 16 floats apart, ONE ds_read2_b32 and ONE
-// ds_write2_b32 -- with slot 8 collecting what wraps round to orientation bin 0 (added to it when the partials are combined:
+// ds_write2_b32 (round 6: ONE ds_add_f32 per vote with all 64 lanes -- the hardware applies the lanes that share a word in
+// ascending lane order with IEEE adds, denormals included, so the order would have been specifiable -- runs at ~770 cycles per
+// wave-instruction: the kernel 301.8 instead of 46.4 us per frame; tools/micro/lds_atomic.hip, profiles/r06_b_*) -- with slot 8
+// collecting what wraps round to orientation bin 0 (added to it when the partials are combined:
 // the fp spec's summation order). With a pitch of 16 floats the 16 lanes of a vote instruction (partials
 // tx = 0..15 of arbitrary rows) hit 16 different banks.
 constexpr int DESC_PITCH = 16;
@@ -264,6 +263,12 @@ __device__ __forceinline__ void desc_run(const DescSetup &d, float *__restrict__
 
     for (int c = 0; c < chunks; ++c) {
         if (c + 1 < chunks) desc_fetch_chunk(d, c + 1, nxt);
+        // Round 6: what depends on the sample's COLUMN only is formed once per chunk. ct0, st0 are floats widened to binary64 and
+        // dx, dy are floats, so the products ct0 dx, st0 dx (and st0 dy, ct0 dy below) are EXACT in binary64 (48 significant
+        // bits): fma64(ct0, dx, st0 dy) = RN64(ct0 dx + st0 dy) is then the plain sum of the two exact products, and
+        // fma64(-st0, dx, ct0 dy) = RN64(ct0 dy - st0 dx) their difference -- the same roundings of the same real numbers.
+        const float dx = (fx0 + (float)(16 * c)) - x;
+        const double pxc = ct0 * (double)dx, pxs = st0 * (double)dx;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const bool inwin = (16 * c <= lx) && (16 * c + 4 * q <= ly);
@@ -277,10 +282,11 @@ __device__ __forceinline__ void desc_run(const DescSetup &d, float *__restrict__
             const float2 gq = cur[q];
             const float mod = inwin ? gq.x : 0.f, ang = gq.y;
             const float theta = nmfp::mod_2pi_f(ang - angle0);
-            const float dx = (fx0 + (float)(16 * c)) - x, dy = (fy0 + (float)(16 * c + 4 * q)) - y;
-            const float nx = nmfp::div_to_f32_wave(fma64(ct0, (double)dx, st0 * (double)dy), dSBP, rSBP);
-            const float ny = nmfp::div_to_f32_wave(fma64(-st0, (double)dx, ct0 * (double)dy), dSBP, rSBP);
-            const float nt = nmfp::div_to_f32_wave((double)(8.0f * theta), nmfp::TWO_PI_D, nmfp::INV_TWO_PI_D);
+            const float dy = (fy0 + (float)(16 * c + 4 * q)) - y;
+            const double ddy = (double)dy;
+            float nx, ny, nt;
+            nmfp::div3_to_f32_wave(pxc + st0 * ddy, ct0 * ddy - pxs, dSBP, rSBP, (double)(8.0f * theta), nmfp::TWO_PI_D,
+                                   nmfp::INV_TWO_PI_D, nx, ny, nt);
             // exp_spec clamps its argument to [-700, 700]: t / 8 > 700 <=> t > 5600 exactly (t = nx^2 + ny^2 >= 0 is a float,
             // the division by 8 is exact), so the clamp is taken on the float (one v_min_f32) and the binary64 compares /
             // selects are dropped
@@ -304,10 +310,10 @@ __device__ __forceinline__ void desc_run(const DescSetup &d, float *__restrict__
             const float wm = win * mod;
             // votes outside the 4x4 grid (or outside the window) become +0 into a landing word behind the histogram, so the 8
             // addresses of a sample never collide and a round can be issued as 4 two-word loads, 8 adds, 4 two-word stores
-            float *const dummy = part + DESC_DUMMY + tx;
-            // word = (9 * cell + slot) * DESC_PITCH + tx, cell = (binx + 2) + 4 (biny + 2), with 24-bit multiplies
-            float *const base = mine + (__mul24(binx, 9 * DESC_PITCH) + __mul24(biny, 36 * DESC_PITCH));
             const int tw = (bint & 7) * DESC_PITCH;                  // bint in [0, 8]; the second vote lies DESC_PITCH further
+            float *const dummy = part + DESC_DUMMY + tx + tw;
+            // word = (9 * cell + slot) * DESC_PITCH + tx, cell = (binx + 2) + 4 (biny + 2), with 24-bit multiplies
+            float *const base = mine + (__mul24(binx, 9 * DESC_PITCH) + __mul24(biny, 36 * DESC_PITCH)) + tw;
             const bool okx[2] = {(unsigned)(binx + 2) < 4u, (unsigned)(binx + 3) < 4u};
             const bool oky[2] = {(unsigned)(biny + 2) < 4u, (unsigned)(biny + 3) < 4u};
             // The in-grid test depends on (dbx, dby) only: it is applied to the partial product (wm * ax) * ay and to the
@@ -324,22 +330,12 @@ __device__ __forceinline__ void desc_run(const DescSetup &d, float *__restrict__
                     const bool ok = inwin && okx[dbx] && oky[dby];
                     const float w2 = wm * __builtin_fabsf((1.f - dbx) - rbinx) * __builtin_fabsf((1.f - dby) - rbiny);
                     const float w2s = ok ? w2 : 0.f;
-                    loc[c4] = (ok ? base + (dbx * 9 + dby * 36) * DESC_PITCH : dummy) + tw;
+                    loc[c4] = ok ? base + (dbx * 9 + dby * 36) * DESC_PITCH : dummy;
                     wt[2 * c4] = w2s * at0;
                     wt[2 * c4 + 1] = w2s * at1;
                 }
             // rounds none of whose 16 samples has a vote inside the grid are skipped (their votes are all +0 into the landing words)
             const unsigned long long voters = __ballot(inwin && (okx[0] || okx[1]) && (oky[0] || oky[1]));
-#if NM_DESC_ATOMIC
-            if (voters) {
-#pragma unroll
-                for (int c4 = 0; c4 < 4; ++c4) {
-                    const uint32_t a = (uint32_t)(uintptr_t)loc[c4];
-                    asm volatile("ds_add_f32 %0, %1" : : "v"(a), "v"(wt[2 * c4]) : "memory");
-                    asm volatile("ds_add_f32 %0, %1 offset:%2" : : "v"(a), "v"(wt[2 * c4 + 1]), "n"(DESC_PITCH * 4) : "memory");
-                }
-            }
-#else
 #pragma unroll
             for (int k = 0; k < 4; ++k) {          // rows of this pass in increasing cy: 16 lanes per round, LDS in order
                 if (!((voters >> (16 * k)) & 0xFFFFull)) continue;
@@ -355,14 +351,10 @@ __device__ __forceinline__ void desc_run(const DescSetup &d, float *__restrict__
                 // the rounds pins the program order that the in-order LDS then executes.
                 asm volatile("" ::: "memory");
             }
-#endif
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
     }
-#if NM_DESC_ATOMIC
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
     __builtin_amdgcn_wave_barrier();
 
     // lane b owns descriptor elements b and b + 64 (element = 8 cell + t): pairwise tree over the 16 partials (strides 1, 2,
@@ -570,6 +562,12 @@ __global__ __launch_bounds__(256) void frame_orient_kernel(NmDescribeArgs a)
     }
 }
 
+// (Round 6, measured and removed: chunk PAIRS. The samples of partial tx in chunks c and c + 1 at the same row of their chunk lie
+// exactly (16, 16) pixels apart = (16 (ct0 + st0), 16 (ct0 - st0)) / SBP cells, more than 2 cells in one component when SBP <= 7.95,
+// so they never vote into the same word and a pass of 2 rows x 2 chunks needs TWO rounds of 32 lanes instead of four of 16: half
+// the vote rounds' LDS instructions and exec-masked adds. 46.8 against 46.9 us per frame (the 2 x 2-row passes are skipped less
+// often than the 4-row passes of one chunk, 128 VGPRs), and NOT the same sums: rows 0.. of chunk c + 1 are then added before rows
+// ..15 of chunk c, which share words with them. profiles/r06_g_desc_pairs_ab.txt)
 // (Setting up keypoint pt + stride -- window and first chunk of samples -- before computing keypoint pt was measured:
 // 983 vs 930 us per 16 frames. This kernel is bound by VALU issue, not by the gather latency, and the second setup costs
 // 12 VGPRs. The straightforward loop stays.)

@@ -55,6 +55,24 @@ __device__ __forceinline__ float div_to_f32_wave(double a, double b, double r)
     if (__builtin_expect(__any(near | tiny), 0)) return (float)(a / b);
     return (float)y;
 }
+// Three quotients of one wave at once (the descriptor's nx, ny, nt): (float)(a1 / b), (float)(a2 / b), (float)(a3 / b3) with
+// r = RN64(1 / b), r3 = RN64(1 / b3). Same `near` test per value as div_to_f32; the three `tiny` tests (0 < |y| < 2^-120, three
+// instructions each on the binary64 bits) become ONE on the narrowed results: |y| < 2^-120 implies |(float)y| <= 2^-120
+// (rounding is monotonic), so  min(|f1|, |f2|, |f3|) <= 2^-120  is a superset of "some y is tiny" -- it also takes exact zeros and
+// the first 2^-25 of the binade above, for which the exact quotients it then computes are equally right. One branch for all three.
+__device__ __forceinline__ void div3_to_f32_wave(double a1, double a2, double b, double r, double a3, double b3, double r3,
+                                                 float &f1, float &f2, float &f3)
+{
+    const double y1 = a1 * r, y2 = a2 * r, y3 = a3 * r3;
+    const uint32_t l1 = (uint32_t)(unsigned long long)__double_as_longlong(y1);
+    const uint32_t l2 = (uint32_t)(unsigned long long)__double_as_longlong(y2);
+    const uint32_t l3 = (uint32_t)(unsigned long long)__double_as_longlong(y3);
+    const bool near = (((l1 << 3) - (0x0FFFFFF0u << 3)) <= (0x20u << 3)) | (((l2 << 3) - (0x0FFFFFF0u << 3)) <= (0x20u << 3)) |
+                      (((l3 << 3) - (0x0FFFFFF0u << 3)) <= (0x20u << 3));
+    f1 = (float)y1; f2 = (float)y2; f3 = (float)y3;
+    const bool tiny = __builtin_fminf(__builtin_fminf(__builtin_fabsf(f1), __builtin_fabsf(f2)), __builtin_fabsf(f3)) <= 0x1p-120f;
+    if (__builtin_expect(__any(near | tiny), 0)) { f1 = (float)(a1 / b); f2 = (float)(a2 / b); f3 = (float)(a3 / b3); }
+}
 constexpr float TWO_PI_F = (float)(2 * 3.14159265358979323846);
 
 // atan(ay/ax), ax > 0, ay >= 0: one IEEE division (range chosen by products, see oracle/nmo_math.h)

@@ -2363,6 +2363,17 @@ static bool distance_scratch(const MatchWs &w, int nA, DistArgs &a, float **part
     return true;
 }
 
+// More than a quarter of the 32 x 32 blocks listed (one NaN or inf in B makes the mean row NaN and lists EVERY block; so do sets of
+// near-duplicates): the per-block fix-up -- one wave per block, the rows from L2 -- is then far slower than exact_distance_kernel,
+// so the list counts as overflowed from there on and the exact kernel behind it fills the whole matrix (ADVICE r5;
+// tests/test_gpu_match.py::test_distance_with_one_nan_takes_the_exact_kernel).
+static int distance_list_cap(int pool_cap, int nA, int nB)
+{
+    const long long blocks = (long long)nm_divup(nA, 32) * nm_divup(nB, 32);
+    const long long quarter = blocks / 4 > 1 ? blocks / 4 : 1;
+    return pool_cap > quarter ? (int)quarter : pool_cap;
+}
+
 static int run_distance(const float *A, int nA, const float *B, int nB, float *distance, const MatchWs &w, hipStream_t st)
 {
     DistArgs a{};
@@ -2375,6 +2386,7 @@ static int run_distance(const float *A, int nA, const float *B, int nB, float *d
     }
     a.ty = a.ny + nB;
     a.D = distance; a.ldd = (size_t)nB; a.nX = nA; a.nY = nB;
+    a.fix_cap = distance_list_cap(a.fix_cap, nA, nB);
     hipLaunchKernelGGL(distance_colsum_kernel, dim3(DIST_P), dim3(128), 0, st, B, nB, part);
     NM_LAUNCH_CHECK();
     hipLaunchKernelGGL(distance_center_kernel, dim3(min(1024, nm_divup(max(nA, nB), 4)), 2), dim3(256), 0, st, A, nA, B, nB, part,
@@ -2609,7 +2621,7 @@ int nm_sift_match_distance_listed(const void *workspace, int nA, int nB, int *li
     *listed = -1;
     if (capacity) *capacity = 0;
     if (!distance_scratch(carve(const_cast<void *>(workspace), nA, nB), nA, a, &part)) return 0;
-    if (capacity) *capacity = a.fix_cap;
+    if (capacity) *capacity = distance_list_cap(a.fix_cap, nA, nB);
     NM_RETURN_IF(hipStreamSynchronize(nm_stream(stream)));
     return (int)hipMemcpy(listed, a.fix_report, sizeof(int), hipMemcpyDeviceToHost);
 }

@@ -560,160 +560,16 @@ __global__ __launch_bounds__(256) void conv_pk_kernel(NmConvBatch batch, int wid
 #endif
 }
 
-// ---- round 6: the same tile pipeline as ONE persistent workgroup per LDS slot with an LDS-DMA ring ----
-// A workgroup walks virtual blocks v = blockIdx.x, blockIdx.x + gridDim.x, ... of the one-tile-per-workgroup grid above (same
-// XCD banding: gridDim.x is a multiple of the XCD count). The NEXT tile's rows are requested by LDS-DMA (buffer_load_dword ...
-// lds: no staging registers, no ds_write pass) into the other of two input images BEFORE the current tile's epilogue issues
-// its stores: vector-memory operations retire in issue order, so at the top of the next iteration `s_waitcnt vmcnt(#stores of
-// the epilogue)` waits for the rows but not for the stores behind them (round 4's persistent form prefetched through VGPRs
-// behind the stores and waited for both). A DMA wave-instruction lands 64 consecutive dwords = 32 columns of one row PAIR in
-// the interleaved layout: lane l reads row (l & 1), column 32 k + (l >> 1); columns / rows outside the image are zero through
-// the descriptor's range check (a poisoned voffset; rows past the bottom lie beyond num_records by themselves).
-// Barriers are raw s_barrier + lgkmcnt(0): __syncthreads() would drain the DMA in flight (vmcnt(0)).
-template <int R, bool WRITE_DOG, bool WRITE_GRAD>
-__global__ __launch_bounds__(256) void conv_pk_ring_kernel(NmConvBatch batch, int width, int height,
-                                                          const float *__restrict__ taps, int tiles_x, int ntiles,
-                                                          int blocks_per_frame, int nxcd, int vblocks)
-{
-    using G = PkGeom<R>;
-    constexpr int TW = G::TW, TH = G::TH, RP = G::RP, RA = G::RA, IN_W = G::IN_W, IN_P2 = G::IN_P2;
-    constexpr int SIN = RP * IN_P2 * 2;                         // floats per input image
-    constexpr int KI = (2 * IN_W + 63) / 64;                    // DMA wave-instructions per row pair
-    constexpr unsigned POISON = 0x80000000u;
-    __shared__ __attribute__((aligned(16))) float s_in[2 * SIN];
-    __shared__ __attribute__((aligned(16))) float s_mid[G::ROWS * G::MID_P];
-    typedef __attribute__((address_space(3))) void lds_void;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned long long w[2 * R + 1];
-#pragma unroll
-    for (int i = 0; i <= 2 * R; ++i) w[i] = (unsigned long long)__float_as_uint(taps[i]);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the taps' loads: nothing ordinary stays in flight beside the DMA
-
-    const int band = (ntiles + nxcd - 1) / nxcd;
-    const unsigned img_bytes = (unsigned)width * (unsigned)height * 4u;
-    struct Tile { int frame, x0, y0; bool ok; };
-    auto locate = [&](int v) {
-        Tile t;
-        t.ok = false; t.frame = 0; t.x0 = 0; t.y0 = 0;
-        if (v >= vblocks) return t;
-        const int frame = v / blocks_per_frame, blk = v - frame * blocks_per_frame;
-        const int xcd = blk % nxcd, slot = blk / nxcd;
-        const int tile = xcd * band + slot;
-        if (slot >= band || tile >= ntiles) return t;
-        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-        t.ok = true; t.frame = frame; t.x0 = tx * TW; t.y0 = ty * TH;
-        return t;
-    };
-    // next valid virtual block at or after v (empty slots of the banding are skipped); returns vblocks when there is none
-    auto next_valid = [&](int v) {
-        while (v < vblocks && !locate(v).ok) v += gridDim.x;
-        return v < vblocks ? v : vblocks;
-    };
-    // this wave's share of a tile's rows: row pairs wave, wave + 4, ... The three DMA instructions of a row pair are ONE asm
-    // statement: hipcc must not know that LDS writes are pending (it would put vmcnt(0) in front of every ds_read that may
-    // alias the image, i.e. drain the NEXT tile's rows and the stores before the epilogue: measured in the first version of
-    // this kernel's ISA), so their completion is counted by hand below. M0 (the LDS destination base) is saved and restored.
-    static_assert(KI == 3, "three DMA wave-instructions per row pair");
-    // The third instruction covers dwords 128 .. 2 IN_W - 1 of the row pair only: its other lanes would land in the NEXT row
-    // pair's first columns (the pitch is 2 IN_P2 = 2 IN_W + 4 dwords), so they are switched off through EXEC -- a lane outside
-    // EXEC writes nothing, a lane with a poisoned offset writes zero.
-    constexpr unsigned long long LAST_MASK = (2 * IN_W - 128 >= 64) ? ~0ull : ((1ull << (2 * IN_W - 128)) - 1ull);
-    auto dma3 = [&](const __amdgpu_buffer_rsrc_t rs, unsigned lds_dst, unsigned v0, unsigned v1, unsigned v2, int soff) {
-        unsigned keep;
-        unsigned long long keep_exec;
-        asm volatile("s_nop 4\n\t"
-                     "s_mov_b32 %0, m0\n\t"
-                     "s_mov_b32 m0, %6\n\ts_nop 0\n\t"
-                     "buffer_load_dword %2, %5, %7 offen lds\n\t"
-                     "s_add_u32 m0, %6, 0x100\n\ts_nop 0\n\t"
-                     "buffer_load_dword %3, %5, %7 offen lds\n\t"
-                     "s_add_u32 m0, %6, 0x200\n\t"
-                     "s_mov_b64 %1, exec\n\t"
-                     "s_mov_b64 exec, %8\n\t"
-                     "buffer_load_dword %4, %5, %7 offen lds\n\t"
-                     "s_mov_b64 exec, %1\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(keep), "=&s"(keep_exec)
-                     : "v"(v0), "v"(v1), "v"(v2), "s"(rs), "s"(__builtin_amdgcn_readfirstlane(lds_dst)),
-                       "s"(__builtin_amdgcn_readfirstlane(soff)),       // wave-uniform by construction; the s_nop 4 covers the hazard
-                       "s"(LAST_MASK)
-                     : "memory", "scc");
-    };
-    auto dma_tile = [&](const Tile &t, int buf) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(batch.image[t.frame]), 0, img_bytes, 0x00020000);
-        unsigned vo[KI];
-#pragma unroll
-        for (int k = 0; k < KI; ++k) {
-            const int c = 32 * k + (lane >> 1), gx = t.x0 - RA + c;
-            vo[k] = (c < IN_W && gx >= 0 && gx < width) ? (unsigned)(((lane & 1) * width + gx) * 4) : POISON;
-        }
-        const unsigned base = (unsigned)(uintptr_t)s_in + (unsigned)buf * (SIN * 4);
-        for (int p = wave; p < RP; p += 4) {
-            const int gy0 = t.y0 - R + 2 * p;                   // scalar
-            const unsigned dst = base + (unsigned)p * (IN_P2 * 2 * 4);
-            if (gy0 >= 0) {
-                dma3(rs, dst, vo[0], vo[1], vo[2], gy0 * width * 4);
-            } else {                                            // rows above the image (top tiles): row gy0 + half < 0 is zero
-                unsigned va[KI];
-#pragma unroll
-                for (int k = 0; k < KI; ++k) {
-                    const int half = lane & 1;
-                    const bool rowok = gy0 + half >= 0;          // only gy0 == -1, half == 1: image row 0
-                    va[k] = (rowok && vo[k] != POISON) ? vo[k] - (unsigned)(half * width * 4) : POISON;
-                }
-                dma3(rs, dst, va[0], va[1], va[2], 0);
-            }
-        }
-    };
-    constexpr int NDMA = ((RP + 3) / 4) * KI;                   // upper bound per wave (waves with one pair fewer issue KI less)
-    (void)NDMA;
-
-    int v = next_valid(blockIdx.x);
-    if (v >= vblocks) return;
-    Tile cur = locate(v);
-    dma_tile(cur, 0);
-    int buf = 0;
-    bool prev_interior = false, prev_result = false;              // were ALL of the previous epilogue's stores issued by every lane?
-    for (;;) {
-        const int vn = next_valid(v + gridDim.x);
-        const Tile nxt = locate(vn);
-        float *__restrict__ result = batch.result[cur.frame];
-        float *__restrict__ dog = batch.dog[cur.frame];
-        float2 *__restrict__ grad = reinterpret_cast<float2 *>(batch.grad[cur.frame]);
-        float *__restrict__ down = batch.down[cur.frame];
-        // stores every wave has issued behind this tile's rows: 4 output rows x (level + DoG + gradient) + 2 decimated rows
-        constexpr int NST_FULL = 4 * (1 + (WRITE_DOG ? 1 : 0) + (WRITE_GRAD ? 1 : 0));
-        __builtin_amdgcn_sched_barrier(0);
-        // (a decimating launch issues two more: the bound stays a LOWER bound, the wait then also covers the two oldest stores)
-        if (prev_interior && prev_result) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST_FULL) : "memory");
-        else if (prev_interior && NST_FULL > 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST_FULL > 4 ? NST_FULL - 4 : 0) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        const float *sin_cur = s_in + buf * SIN;
-        {
-            const int p = tid & 31, cg = tid >> 5;
-            if (p < RP) pk_row_task<R, false>(sin_cur, s_mid, w, p, cg, nullptr, cur.x0, cur.y0, width, height);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (nxt.ok) dma_tile(nxt, buf ^ 1);                       // BEFORE the epilogue's stores: see the header
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("" ::: "memory");
-        pk_cols_epilogue<R, WRITE_DOG, WRITE_GRAD, false>(sin_cur, s_mid, w, tid, cur.x0, cur.y0, width, height, result, dog, grad, down);
-        __builtin_amdgcn_sched_barrier(0);
-        prev_interior = (cur.x0 + TW <= width) && (cur.y0 + TH <= height);
-        prev_result = result != nullptr;
-        if (!nxt.ok) break;
-        cur = nxt; v = vn; buf ^= 1;
-    }
-}
-
+// (Round 6, measured and removed -- the version is in the repository's history, commit "Experiments (measured, negative)":
+// conv_pk_ring_kernel, ONE persistent workgroup per LDS slot walking the same XCD-banded tile list with a 2-deep LDS-DMA input
+// ring: the next tile's rows requested by buffer_load_dword ... lds (inline asm, so that hipcc places no vmcnt(0) in front of
+// the ds_reads) BEFORE the current tile's epilogue stores, `s_waitcnt vmcnt(#stores)` at the top of the next iteration so the
+// rows are waited for but not the stores behind them, raw s_barrier + lgkmcnt(0). Bit-exact (44 GPU tests), and 25-40 % SLOWER:
+// 65.2 / 66.0 / 73.6 us per frame at 8 / 3 / 2 workgroups per CU against 52.3 for the launches above (64-frame chain, same box,
+// alternating). The row-pair interleaved tile forces 4-BYTE DMA -- lane l lands row (l & 1), column l >> 1: 24 wave-instructions
+// per wave and tile where the register path issues 6 16-byte loads per thread -- and two input images leave 2-4 workgroups per CU
+// where 4-6 one-tile workgroups already overlap one another's loads (the guide's regime rule: LDS-DMA spans pay at ~1 block per CU,
+// not at high occupancy). profiles/r06_e_conv_ring_experiment.txt)
 // (Round 5, measured and removed: issue priorities (s_setprio 3 while the tile's loads are issued / 2 or 1 in the epilogue / both):
 // 54.2-54.9 us per frame against 54.4-54.5, 64-frame chain, same box -- nothing beyond the run-to-run spread.)
 // (Round 5, measured and removed: 64-ROW tiles with 512 threads -- the share of halo rows the row pass filters and the loads
@@ -835,28 +691,6 @@ static int launch_conv_pk(const NmConvBatch &b, int width, int height, const flo
     const int nxcd = nm_xcd_count();
     const bool dog = b.dog[0] != nullptr, grad = b.grad[0] != nullptr;
     const int bpf = nm_divup(ntiles, nxcd) * nxcd;
-    static const int ring = [] { const char *e = getenv("NM_CONV_RING"); return e ? atoi(e) : 0; }();
-    if (ring > 0 && (long)bpf * b.n >= 4L * nm_cu_count()) {
-        // persistent form: `ring` workgroups per CU (capped by what the LDS holds), a multiple of the XCD count
-        using G = PkGeom<R>;
-        const int lds = (2 * G::RP * G::IN_P2 * 2 + G::ROWS * G::MID_P) * 4;
-        int per_cu = 160 * 1024 / lds;
-        if (per_cu > ring) per_cu = ring;
-        if (per_cu < 1) per_cu = 1;
-        int g = per_cu * nm_cu_count();
-        g -= g % nxcd;
-        if (g > bpf * b.n) g = bpf * b.n;
-#define NM_RING_LAUNCH(DOG, GRAD)                                                                                      \
-    hipLaunchKernelGGL((conv_pk_ring_kernel<R, DOG, GRAD>), dim3(g), dim3(256), 0, stream, b, width, height, taps,     \
-                       tiles_x, ntiles, bpf, nxcd, bpf * b.n)
-        if (dog && grad) NM_RING_LAUNCH(true, true);
-        else if (dog) NM_RING_LAUNCH(true, false);
-        else if (grad) NM_RING_LAUNCH(false, true);
-        else NM_RING_LAUNCH(false, false);
-#undef NM_RING_LAUNCH
-        NM_LAUNCH_CHECK();
-        return 0;
-    }
     dim3 grid(bpf * b.n);
 #define NM_PK_LAUNCH(DOG, GRAD)                                                                                     \
     hipLaunchKernelGGL((conv_pk_kernel<R, DOG, GRAD>), grid, dim3(256), 0, stream, b, width, height, taps, tiles_x, \

@@ -49,7 +49,8 @@ public:
     }
     ~device_vector() { release(); }
 
-    size_t size() const { settle(); return _n; }
+    //! (a deferred size is read through its record without modifying this object: concurrent readers do not race)
+    size_t size() const { return _pend ? pending_size() : _n; }
     bool empty() const { return size() == 0; }
     T *data() { return _p; }
     const T *data() const { return _p; }
@@ -61,7 +62,7 @@ public:
     //! words before it is 0: an empty level ends its octave (sift/siftfunctions.cu:145). The allocation must already hold the
     //! largest possible count (reserve_uninitialized).
     void defer_size(std::shared_ptr<pending_counts> p, int index) { _pend = std::move(p); _pend_idx = index; }
-    bool size_pending() const { return bool(_pend); }
+    bool size_pending() const { return _pend && !_pend->resolved(); }
     //! the pending record (or null): lets the owner check that a deferred size is still the one it installed
     const std::shared_ptr<pending_counts> &pending_record() const { return _pend; }
     //! capacity >= n, size and contents untouched (no-op when already large enough; otherwise the contents are lost)
@@ -110,9 +111,9 @@ public:
     }
     std::vector<T> to_host() const
     {
-        settle();
-        std::vector<T> h(_n);
-        if (_n) nm_check((int)hipMemcpy(h.data(), _p, _n * sizeof(T), hipMemcpyDeviceToHost), "device_vector D2H");
+        const size_t n = size();
+        std::vector<T> h(n);
+        if (n) nm_check((int)hipMemcpy(h.data(), _p, n * sizeof(T), hipMemcpyDeviceToHost), "device_vector D2H");
         return h;
     }
 
@@ -136,30 +137,35 @@ private:
         _cap = 0;
         _pend.reset();
     }
-    //! a deferred size becomes a number: waits for the producing stream (once per pending record)
-    void settle() const
+    //! a deferred size as a number: waits for the producing launch (once per pending record); does not modify the vector
+    size_t pending_size() const
     {
-        if (!_pend) return;
         _pend->resolve();
         bool live = true;
         for (int k = 0; k < _pend_idx; ++k) live = live && _pend->values[k] != 0;
         // an empty level ends its octave (sift/siftfunctions.cu:145): the levels behind it count as empty (SURVEY Q9 -- the
         // reference leaves their previous sizes in place, which nothing reads: compute_descriptors stops at the empty level too)
         const size_t n = (live && _pend->values[_pend_idx] > 0) ? (size_t)_pend->values[_pend_idx] : 0;
-        _n = n < _cap ? n : _cap;
+        return n < _cap ? n : _cap;
+    }
+    //! latch a deferred size (non-const paths that go on to change the vector)
+    void settle()
+    {
+        if (!_pend) return;
+        _n = pending_size();
         _pend.reset();
     }
     void copy_from(const device_vector &o)
     {
-        o.settle();
+        const size_t n = o.size();
         release();
-        allocate(o._n);
+        allocate(n);
         if (_n) nm_check((int)hipMemcpy(_p, o._p, _n * sizeof(T), hipMemcpyDeviceToDevice), "device_vector D2D");
     }
     T *_p;
-    mutable size_t _n;
+    size_t _n;
     size_t _cap;
-    mutable std::shared_ptr<pending_counts> _pend;
+    std::shared_ptr<pending_counts> _pend;
     int _pend_idx = 0;
 };
 

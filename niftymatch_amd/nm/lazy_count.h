@@ -15,52 +15,73 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
 #include <memory>
+#include <mutex>
 
 namespace nm {
 
 //! Four host words a kernel fills (mapped pinned memory): [0..2] the raw per-level counts of an octave, [3] a running item
-//! count. resolve() waits for the producing stream once and latches them.
+//! count. The ring pre-sets the words to -1 (counts are never negative) when it hands the slot out; resolve() waits ONCE until
+//! the words this record's kernel writes (`need`, a bit per word) have left -1, and latches them. No stream handle and no event
+//! is involved: the producing stream may be destroyed or its handle re-used at any time, and nothing is added to the stream
+//! (an event recorded per launch cost the one-thread client loop 7 % on MI355X: 697 against 748 pairs/s). Thread-safe: any
+//! number of host threads may resolve / read the same record concurrently.
 struct pending_counts {
-    const volatile int *host;
-    hipStream_t stream;
-    bool resolved;
+    volatile int *host;
+    unsigned need;              //!< bit i: word i is written by this record's kernel
     int values[4];
-    pending_counts(const volatile int *h, hipStream_t s) : host(h), stream(s), resolved(false), values{0, 0, 0, 0} {}
-    void resolve();            // defined in pyramidata.cpp (error convention of the C++ layer)
+    pending_counts(volatile int *h, unsigned need_words) : host(h), need(need_words), values{0, 0, 0, 0}, _resolved(false) {}
+    void resolve();             //!< defined in pyramidata.cpp (error convention of the C++ layer)
+    bool resolved() const { return _resolved.load(std::memory_order_acquire); }
+    //! have the needed words arrived? (no waiting)
+    bool arrived() const
+    {
+        for (int i = 0; i < 4; ++i)
+            if (((need >> i) & 1u) && host[i] == -1) return false;
+        return true;
+    }
+
+private:
+    std::atomic<bool> _resolved;
+    std::mutex _m;
 };
 
 //! An int whose value may still be on its way from the device. Converts to int (resolving), assigns from int (which makes the
-//! host value authoritative again). Drop-in for `int SiftData::_num_items` wherever it is used as a number; the one thing it
-//! cannot do is travel through C varargs (printf("%d", data._num_items) needs an explicit int(...)).
+//! host value authoritative again). Drop-in for `int SiftData::_num_items` wherever it is used as a number. The constructor from
+//! int is EXPLICIT: with an implicit one, `cond ? data._num_items : 0` was ambiguous and mixed comparisons had two
+//! viable conversions; now every mixed expression converts the lazy_int to int, as the reference's plain int would read. What a
+//! class cannot do (INTEGRATION.md section 3.1 lists the patterns and their one-line fixes): bind to `int &` / `int *`, deduce as `int` in
+//! std::min / std::max, travel through C varargs.
+//! Reading is const and does not modify the object (a resolved record stays attached), so concurrent readers do not race;
+//! writers need the same external ordering a plain int needs.
 class lazy_int {
 public:
-    lazy_int(int v = 0) : _v(v) {}
+    lazy_int() : _v(0) {}
+    explicit lazy_int(int v) : _v(v) {}
     lazy_int(const lazy_int &o) : _v(int(o)) {}
-    lazy_int &operator=(const lazy_int &o) { _v = int(o); _p.reset(); return *this; }
+    lazy_int &operator=(const lazy_int &o) { const int v = int(o); _p.reset(); _v = v; return *this; }
     lazy_int &operator=(int v) { _p.reset(); _v = v; return *this; }
     operator int() const
     {
-        if (_p) {
-            _p->resolve();
-            _v = _p->values[3];
-            _p.reset();
-        }
+        if (_p) { _p->resolve(); return _p->values[3]; }
         return _v;
     }
     lazy_int &operator+=(int d) { return *this = int(*this) + d; }
     lazy_int &operator-=(int d) { return *this = int(*this) - d; }
     lazy_int &operator++() { return *this += 1; }
+    lazy_int &operator--() { return *this -= 1; }
     int operator++(int) { const int v = *this; *this = v + 1; return v; }
+    int operator--(int) { const int v = *this; *this = v - 1; return v; }
     //! true while the value has not been read back (the device-side word is then the authority)
-    bool pending() const { return bool(_p); }
+    bool pending() const { return _p && !_p->resolved(); }
     void defer(std::shared_ptr<pending_counts> p) { _p = std::move(p); }
-    //! the host value WITHOUT resolving (meaningful only while !pending())
-    int host_value() const { return _v; }
+    //! the host value WITHOUT waiting (meaningful only while !pending())
+    int host_value() const { return (_p && _p->resolved()) ? _p->values[3] : _v; }
 
 private:
-    mutable int _v;
-    mutable std::shared_ptr<pending_counts> _p;
+    int _v;
+    std::shared_ptr<pending_counts> _p;
 };
 
 }  // namespace nm

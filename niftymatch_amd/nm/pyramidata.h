@@ -45,17 +45,18 @@ private:
     int *_p;
 };
 
-//! A ring of NM_LAZY_SLOTS x 4 mapped pinned host words for lazy_count.h: a kernel writes a slot, the host reads it after it
-//! has waited for that kernel's stream. A slot is handed out again only once the record that used it last has been resolved
-//! (or dropped). Same value semantics as pinned_counts: a copy starts with a ring of its own, a move takes the ring along.
+//! A ring of NM_LAZY_SLOTS x 4 mapped pinned host words for lazy_count.h: a kernel writes a slot, the host reads it once the
+//! words have left the -1 the ring put there. A slot is handed out again only once its last producer has WRITTEN it -- also
+//! when that record was dropped unread: its kernel may still be about to write the words the next owner's kernel will write
+//!. Same value semantics as pinned_counts: a copy starts with a ring of its own, a move takes the ring along.
 class pinned_ring {
 public:
     enum { SLOTS = 64 };
-    pinned_ring() : _host(nullptr), _dev(nullptr), _next(0) {}
-    pinned_ring(const pinned_ring &) : _host(nullptr), _dev(nullptr), _next(0) {}
+    pinned_ring() : _host(nullptr), _dev(nullptr), _next(0) { for (auto &n : _need) n = 0; }
+    pinned_ring(const pinned_ring &) : _host(nullptr), _dev(nullptr), _next(0) { for (auto &n : _need) n = 0; }
     pinned_ring(pinned_ring &&o) noexcept : _host(o._host), _dev(o._dev), _next(o._next)
     {
-        for (int i = 0; i < SLOTS; ++i) _last[i] = std::move(o._last[i]);
+        for (int i = 0; i < SLOTS; ++i) { _last[i] = std::move(o._last[i]); _need[i] = o._need[i]; }
         o._host = nullptr; o._dev = nullptr;
     }
     pinned_ring &operator=(const pinned_ring &) { return *this; }
@@ -64,22 +65,27 @@ public:
         if (this != &o) {
             release();
             _host = o._host; _dev = o._dev; _next = o._next;
-            for (int i = 0; i < SLOTS; ++i) _last[i] = std::move(o._last[i]);
+            for (int i = 0; i < SLOTS; ++i) { _last[i] = std::move(o._last[i]); _need[i] = o._need[i]; }
             o._host = nullptr; o._dev = nullptr;
         }
         return *this;
     }
     ~pinned_ring() { release(); }
-    //! a fresh pending record on `stream`; *dev_words = the slot's four words as the DEVICE addresses them
-    std::shared_ptr<pending_counts> take(hipStream_t stream, int **dev_words);
+    //! a fresh pending record for a kernel about to be launched on `stream` that writes the words `need` (bit per word);
+    //! *dev_words = the slot's four words as the DEVICE addresses them
+    std::shared_ptr<pending_counts> take(hipStream_t stream, unsigned need, int **dev_words);
 
 private:
     void release();
     int *_host, *_dev;
     int _next;
     std::weak_ptr<pending_counts> _last[SLOTS];
+    unsigned _need[SLOTS];             //!< the words the slot's last producer writes (0: never handed out)
 };
 }  // namespace nm
+
+//! Upper bound of the keypoints of one DoG level of a w x h octave: strict maxima are pairwise non-adjacent, strict minima too.
+inline size_t nm_keypoint_bound(int w, int h) { return 2 * (size_t)((w + 1) / 2) * (size_t)((h + 1) / 2); }
 
 class PyramidData {
 public:

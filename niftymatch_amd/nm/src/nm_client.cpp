@@ -156,11 +156,12 @@ extern "C" int nm_client_lazy_counts(const float *gray, int width, int height, i
                 compute_gradients(py, params, ow, oh, st);
                 compute_keypoints(py, params, o, ow, oh, st);
                 compute_orientations(py, params, o, ow, oh, st);
-                if (look == 1 && o < max_octaves)
-                    for (int l = 0; l < 3; ++l) {
-                        r.pending += py._orientations[l].size_pending() ? 1 : 0;
-                        r.watch[4 * o + l] = (int)py._orientations[l].size();
-                    }
+                if (look == 1 && o < max_octaves) {
+                    // (the three sizes share one pending record: the first look resolves it for all of them, so "pending" is
+                    // asked of all three before any size is read)
+                    for (int l = 0; l < 3; ++l) r.pending += py._orientations[l].size_pending() ? 1 : 0;
+                    for (int l = 0; l < 3; ++l) r.watch[4 * o + l] = (int)py._orientations[l].size();
+                }
                 compute_descriptors(py, params, o, ow, oh, out, st);
                 if (look && o < max_octaves) {
                     r.pending += out._num_items.pending() ? 1 : 0;

@@ -1,6 +1,9 @@
 // pyramidata.cpp -- PyramidData on top of the C ABI (reference: src/gpu/sift/pyramidata.cu:18-123).
 #include "../pyramidata.h"
 
+#include <chrono>
+#include <thread>
+
 #include "../../../include/nm_abi.h"
 #include "../exception.h"
 
@@ -24,10 +27,13 @@ void PyramidData::initialize(const SiftParams &params)
     for (int i = 0; i < params._num_dog_levels; ++i) {
         _key_pts[i] = nm::device_vector<float4>(num_pixels, invalid);
         _collated_kpts[i] = nm::device_vector<float4>(num_pixels, invalid);
-        // room for every pixel's keypoint, size 0: compute_orientations then sets the size without knowing it on the host
-        // (lazy_count.h; the reference re-creates the vector per level with the count it has just read back, pyramidata.cu:90)
+        // room for every keypoint a level can hold, size 0: compute_orientations then sets the size without knowing it on the
+        // host (lazy_count.h; the reference re-creates the vector per level with the count it has just read back,
+        // pyramidata.cu:90). A keypoint is a STRICT extremum of its 3 x 3 x 3 neighbourhood (keypoint.cu:195-196): two pixels
+        // that touch cannot both be maxima (or both minima), so a level holds at most ceil(w/2) ceil(h/2) of each -- half the
+        // pixels, not all of them (50 MB per PyramidData at 1080p with one entry per pixel).
         _orientations[i] = nm::device_vector<float2>();
-        _orientations[i].reserve_uninitialized(num_pixels);
+        _orientations[i].reserve_uninitialized(nm_keypoint_bound(params._width, params._height));
     }
     _lazy_rec.reset(); _lazy_octave = -1;
     _grad = nm::device_vector<float2>(num_pixels * _num_dogs, make_float2(0, 0));
@@ -57,19 +63,48 @@ void PyramidData::clear()
     _num_octaves = _num_dogs = _num_kernels = 0;
 }
 
-void nm::pending_counts::resolve()
+static bool nm_stream_capturing(hipStream_t stream)
 {
-    if (resolved) return;
-    // the kernel that fills the words runs on `stream`; a stream the client has destroyed since is covered by the device
-    if (hipStreamSynchronize(stream) != hipSuccess) {
-        (void)hipGetLastError();
-        nm_check((int)hipDeviceSynchronize(), "keypoint count read-back");
-    }
-    for (int i = 0; i < 4; ++i) values[i] = host[i];
-    resolved = true;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st != hipStreamCaptureStatusNone;
 }
 
-std::shared_ptr<nm::pending_counts> nm::pinned_ring::take(hipStream_t stream, int **dev_words)
+// Wait until the words `need` of a slot have left -1: a short spin (the usual case: the kernel has long finished), then
+// yielding; after 20 s without the words the device is drained once and, if they are still missing, the error convention of
+// the C++ layer applies (the producing launch never ran: a failed launch or a destroyed stream's dropped work).
+static void nm_wait_words(volatile int *host, unsigned need, const char *what)
+{
+    auto arrived = [&]() {
+        for (int i = 0; i < 4; ++i)
+            if (((need >> i) & 1u) && host[i] == -1) return false;
+        return true;
+    };
+    for (int spin = 0; spin < 2000; ++spin)
+        if (arrived()) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (!arrived()) {
+        std::this_thread::yield();
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+            nm_check((int)hipDeviceSynchronize(), what);
+            if (!arrived()) nm_check((int)hipErrorNotReady, what);
+            return;
+        }
+    }
+}
+
+void nm::pending_counts::resolve()
+{
+    if (_resolved.load(std::memory_order_acquire)) return;
+    std::lock_guard<std::mutex> lock(_m);
+    if (_resolved.load(std::memory_order_relaxed)) return;
+    nm_wait_words(host, need, "keypoint count read-back");
+    std::atomic_thread_fence(std::memory_order_acquire);
+    for (int i = 0; i < 4; ++i) values[i] = ((need >> i) & 1u) ? host[i] : 0;
+    _resolved.store(true, std::memory_order_release);
+}
+
+std::shared_ptr<nm::pending_counts> nm::pinned_ring::take(hipStream_t stream, unsigned need, int **dev_words)
 {
     if (!_host) {
         nm_check((int)hipHostMalloc(reinterpret_cast<void **>(&_host), SLOTS * 4 * sizeof(int), hipHostMallocMapped),
@@ -81,8 +116,18 @@ std::shared_ptr<nm::pending_counts> nm::pinned_ring::take(hipStream_t stream, in
     }
     const int slot = _next;
     _next = (_next + 1) % SLOTS;
-    if (auto old = _last[slot].lock()) old->resolve();        // 64 calls later and still unread: latch it before the words are reused
-    auto rec = std::make_shared<pending_counts>(_host + 4 * slot, stream);
+    volatile int *words = _host + 4 * slot;
+    if (!nm_stream_capturing(stream)) {
+        // (no host waits while a capture is open: a captured launch does not run now, its words arrive at the first replay)
+        if (auto old = _last[slot].lock()) old->resolve();    // 64 calls later and still unread: latch it before the words are reused
+        // the slot's last producer must have WRITTEN even if its record was dropped unread: it would otherwise overwrite what
+        // the new owner's kernel is about to write
+        if (_need[slot]) nm_wait_words(words, _need[slot], "pinned counter ring slot");
+        for (int i = 0; i < 4; ++i) words[i] = -1;
+        std::atomic_thread_fence(std::memory_order_release);
+    }
+    _need[slot] = need;
+    auto rec = std::make_shared<pending_counts>(words, need);
     _last[slot] = rec;
     *dev_words = _dev + 4 * slot;
     return rec;
@@ -90,8 +135,12 @@ std::shared_ptr<nm::pending_counts> nm::pinned_ring::take(hipStream_t stream, in
 
 void nm::pinned_ring::release()
 {
-    for (int i = 0; i < SLOTS; ++i)
+    for (int i = 0; i < SLOTS; ++i) {
         if (auto old = _last[i].lock()) old->resolve();       // records outlive the ring: give them their values first
+        // a producer whose record was dropped may still be about to write into the memory freed below
+        if (_host && _need[i]) nm_wait_words(_host + 4 * i, _need[i], "pinned counter ring release");
+        _need[i] = 0;
+    }
     if (_host) (void)hipHostFree(_host);
     _host = _dev = nullptr;
 }

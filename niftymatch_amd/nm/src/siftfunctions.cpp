@@ -38,10 +38,6 @@ static bool async_matches()
     }
     return v == 1;
 }
-// (the legacy NULL stream synchronises with every blocking stream: nothing special to do for it -- the name keeps the call
-// site honest about what it checks)
-static bool stream_is_capturing(hipStream_t stream);
-static bool stream_is_capturing_or_null_legacy(hipStream_t stream) { return stream_is_capturing(stream); }
 static bool stream_is_capturing(hipStream_t stream)
 {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
@@ -210,16 +206,17 @@ void compute_orientations(PyramidData &pydata, const SiftParams &params, const i
 {
     const float xper = std::pow(2.0, octave);
     const int num_pixels_for_octave = octave_width * octave_height;
-    if (params._num_dog_levels == 3 && !eager_counts() && !stream_is_capturing_or_null_legacy(stream)) {
+    if (params._num_dog_levels == 3 && (!eager_counts() || stream_is_capturing(stream))) {
         // Lazy counts (nm/lazy_count.h): the collation's three counts stay on the device, the orientation kernel reads them
-        // there, and _orientations[l].size() becomes pending -- no host synchronisation in this call.
+        // there, and _orientations[l].size() becomes pending -- no host synchronisation in this call. It is also the ONLY
+        // capture-compatible path (the eager one reads the counts back), so a capturing stream always takes it.
         pydata.gpu_collate_keypoints_for_octave_dev(num_pixels_for_octave, stream);
         int *words = nullptr;
-        std::shared_ptr<nm::pending_counts> rec = pydata._ring.take(stream, &words);
+        std::shared_ptr<nm::pending_counts> rec = pydata._ring.take(stream, 0x7u, &words);      // the three level counts
         const float *kp[3];
         float *res[3];
         for (int i = 0; i < 3; ++i) {
-            pydata._orientations[i].reserve_uninitialized(pydata._collated_kpts[i].size());
+            pydata._orientations[i].reserve_uninitialized(nm_keypoint_bound(octave_width, octave_height));
             kp[i] = reinterpret_cast<const float *>(pydata._collated_kpts[i].data());
             res[i] = reinterpret_cast<float *>(pydata._orientations[i].data());
         }
@@ -270,7 +267,7 @@ void compute_descriptors(PyramidData &pydata, const SiftParams &params, const in
     // Lazy counts: compute_orientations of THIS octave left its counts on the device and nobody has looked at them since --
     // the descriptor kernel reads them (and the running item count) there; data._num_items becomes pending.
     const std::shared_ptr<nm::pending_counts> &rec = pydata._lazy_rec;
-    if (params._num_dog_levels == 3 && rec && !rec->resolved && pydata._lazy_octave == octave &&
+    if (params._num_dog_levels == 3 && rec && !rec->resolved() && pydata._lazy_octave == octave &&
         pydata._orientations[0].pending_record() == rec && pydata._orientations[1].pending_record() == rec &&
         pydata._orientations[2].pending_record() == rec && data._capacity > 0) {
         if (data._items_dev.size() < 2) data._items_dev = nm::device_vector<int>(2);
@@ -279,7 +276,7 @@ void compute_descriptors(PyramidData &pydata, const SiftParams &params, const in
         const int *base_in = dev_base ? data._items_dev.data() + data._items_cur : nullptr;
         int *items_out = data._items_dev.data() + (data._items_cur ^ 1);
         int *words = nullptr;
-        std::shared_ptr<nm::pending_counts> items = pydata._ring.take(stream, &words);
+        std::shared_ptr<nm::pending_counts> items = pydata._ring.take(stream, 0x8u, &words);    // the running item count
         for (int i = 0; i < 3; ++i) {
             kp[i] = reinterpret_cast<const float *>(pydata._collated_kpts[i].data());
             ori[i] = reinterpret_cast<const float *>(pydata._orientations[i].data());

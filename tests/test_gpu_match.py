@@ -720,6 +720,46 @@ def test_distance_on_the_mfma_every_entry_within_1e_4(nm, oracle, cuda, screen):
     run(A, B, "NaN / inf rows")
 
 
+def test_distance_with_one_nan_takes_the_exact_kernel(nm, cuda, screen):
+    """ONE NaN in B makes the mean row NaN, the acceptance test fails everywhere and every 32 x 32 block is listed.
+    Beyond a quarter of the blocks the list counts as overflowed and exact_distance_kernel fills the matrix (the per-block fix-up
+    -- one wave per block -- would take many times longer): the result is bit-equal to NM_MATCH_DISTANCE=exact, and the call
+    costs about what the exact mode costs, at the bench's 12k x 12k."""
+    import time
+    import torch
+    if screen != "f16":
+        pytest.skip("one run is enough")
+    nA, nB = 12223, 12080
+    A = _t(H.synth.descriptors(41, nA) * 100, cuda)
+    Bh = H.synth.descriptors(42, nB) * 100
+    Bh[4321, 77] = np.nan
+    B = _t(Bh, cuda)
+    ws = nm.MatchWorkspace(nA, nB, cuda)
+    before = nm.get_distance_mode()
+    out = {}
+    try:
+        for mode in ("exact", "mfma"):
+            nm.set_distance_mode(mode)
+            for _ in range(2):
+                res, D = nm.sift_match(A, B, 0.8, want_distance=True, workspace=ws)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                res, D = nm.sift_match(A, B, 0.8, want_distance=True, workspace=ws)
+            torch.cuda.synchronize()
+            out[mode] = ((time.perf_counter() - t0) / 5, res.clone(), D.clone())
+            if mode == "mfma":
+                listed, cap = nm.match_distance_listed(ws, nA, nB)
+                blocks = ((nA + 31) // 32) * ((nB + 31) // 32)
+                assert cap == blocks // 4 and listed > cap, (listed, cap, blocks)       # every block listed: counted as overflow
+    finally:
+        nm.set_distance_mode(before)
+    assert torch.equal(out["mfma"][1], out["exact"][1])
+    assert torch.equal(out["mfma"][2].view(torch.int32), out["exact"][2].view(torch.int32))       # NaN column included, bit for bit
+    assert bool(torch.isnan(out["mfma"][2][:, 4321]).all())
+    assert out["mfma"][0] < 2.0 * out["exact"][0], (out["mfma"][0], out["exact"][0])
+
+
 def test_fp32_mfma_rounding_is_inside_what_the_fp32_bounds_assume(nm, cuda, screen):
     """The hardware premise under the fp32 screen's bound (since round 1) and under the materialised distance pass's acceptance
     test (round 5): v_mfma_f32_32x32x2_f32 forms C + a0 b0 + a1 b1 with exact products and at most two roundings, so a chain of
