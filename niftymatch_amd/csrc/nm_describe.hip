@@ -568,6 +568,10 @@ __global__ __launch_bounds__(256) void frame_orient_kernel(NmDescribeArgs a)
 // the vote rounds' LDS instructions and exec-masked adds. 46.8 against 46.9 us per frame (the 2 x 2-row passes are skipped less
 // often than the 4-row passes of one chunk, 128 VGPRs), and NOT the same sums: rows 0.. of chunk c + 1 are then added before rows
 // ..15 of chunk c, which share words with them. profiles/r06_g_desc_pairs_ab.txt)
+// (Round 6, measured and removed: the weights and the votes' adds as packed fp32 -- (wm ax) ay and * at as v_pk_mul_f32, a round's
+// eight adds as four v_pk_add_f32 on the ds_read2 pairs; |1 - r| = 1 - r and |0 - r| = r hold bit for bit on r in [0, 1] -- 165 -> 141
+// vector instructions per pass, bit-identical, and 3 % SLOWER (47.3 against 45.8 us per frame, alternating): an exec-masked
+// v_add_f32 with 16 live lanes costs less than its share of a packed instruction. profiles/r06_k_desc_packed_ab.txt)
 // (Setting up keypoint pt + stride -- window and first chunk of samples -- before computing keypoint pt was measured:
 // 983 vs 930 us per 16 frames. This kernel is bound by VALU issue, not by the gather latency, and the second setup costs
 // 12 VGPRs. The straightforward loop stays.)
