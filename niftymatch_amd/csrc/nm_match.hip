@@ -276,6 +276,9 @@ struct MatchBatch {
                                // accumulation of the coarse pass only, the fp16 rounding enters through ra / rb
     int n_cu, n_xcd;           // device-sized calls: the geometry the device-side plan is made for (n_cu = persistent workgroups)
     int n_cu2;                 // two-stage screen: workgroups of the second pass (one per CU), for the plan fine_rows_kernel makes
+    int pair_xcd;              // coarse pass (round 6): > 0 = the number of XCDs when every pair of the call belongs to ONE of them
+                               // (pair q to XCD q mod pair_xcd: the workgroups wg with wg mod pair_xcd == q mod pair_xcd, local
+                               // index wg / pair_xcd, under a one-group plan for n_cu workgroups); 0 = every workgroup on every pair
 };
 static_assert(sizeof(MatchBatch) <= 4096, "kernel arguments are limited to 4 KB");
 
@@ -1113,11 +1116,18 @@ __global__ __launch_bounds__(512, 1) void match_coarse_kernel(MatchBatch bt)
             plan.X = __builtin_amdgcn_readfirstlane(d[6]); plan.Gx = __builtin_amdgcn_readfirstlane(d[7]);
             plan.Tc = __builtin_amdgcn_readfirstlane(d[8]); plan.C = __builtin_amdgcn_readfirstlane(d[9]);
             plan.q_base = __builtin_amdgcn_readfirstlane(d[10]); plan.q_rem = __builtin_amdgcn_readfirstlane(d[11]);
-            if (wg >= plan.G) continue;
+            int xg, vg;
+            if (bt.pair_xcd > 0) {                        // the pair lives on one XCD: its A and B images cross the fabric once
+                if (pq % bt.pair_xcd != wg % bt.pair_xcd) continue;
+                xg = 0; vg = wg / bt.pair_xcd;            // (the plan is a one-group plan: X = 1)
+                if (vg >= plan.G) continue;
+            } else {
+                if (wg >= plan.G) continue;
+                xg = wg % plan.X; vg = wg / plan.X;
+            }
             const MatchPair &c = bt.p[pq];
             cx.pq = pq; cx.nA = nA; cx.plan = plan;
-            const int xg = wg % plan.X;
-            cx.vg = wg / plan.X;
+            cx.vg = vg;
             cx.grp = plan_group(plan, xg);
             cx.u_end = group_begin(cx.grp, cx.vg + 1);
             cx.it.init(group_begin(cx.grp, cx.vg), cx.u_end);
@@ -2476,6 +2486,15 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
     if (bt.n >= 4) n_wg2 = max(2 * xcd, (n_cu / bt.n) / xcd * xcd);
     if (n_wg2 > n_cu || n_wg2 % xcd != 0) n_wg2 = n_cu;
     bt.n_cu = n_cu * wg_per_cu; bt.n_cu2 = n_wg2; bt.n_xcd = nm_xcd_count();
+    // Coarse pass, round 6: with a multiple of the XCD count of pairs in the call, pair q is screened by the 32 workgroups of
+    // XCD q mod 8 alone (the XCDs work on 8 pairs side by side) instead of by all 256 on pair after pair: every XCD's L2 then
+    // fetches ITS pairs' fp16 images once (2 x 3.1 MB, which it holds) where each of the 8 L2s fetched every pair's candidate
+    // tiles (643 MB per 16-pair launch against 146 MB algorithmic). NM_COARSE_PAIR_XCD=0 keeps the old division.
+    bt.pair_xcd = 0;
+    if (screen == 2 && xcd > 1 && n_cu % xcd == 0 && bt.n >= xcd && bt.n % xcd == 0) {
+        static const int env = [] { const char *e = getenv("NM_COARSE_PAIR_XCD"); return e ? atoi(e) : 1; }();
+        if (env) { bt.pair_xcd = xcd; bt.n_cu = n_cu / xcd; bt.n_xcd = 1; }
+    }
     if (phases & NM_MATCH_PHASE_PREP) {
         const dim3 pg(nm_divup(max_rows, PREP_ROWS), bt.n);
         if (screen == 2) hipLaunchKernelGGL(prep_kernel<2>, pg, dim3(256), 0, st, bt);
