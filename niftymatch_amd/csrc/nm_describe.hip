@@ -523,23 +523,34 @@ __device__ __forceinline__ int octave_of(const NmFrameBook *book, int num_octave
     return o;
 }
 
+// (Round 6, measured and removed: the keypoints dealt to the XCDs by LOCALITY instead of round robin. Consecutive keypoints are
+// neighbours in (octave, level, y, x) and their gradient windows overlap; dealt round robin, every window line is fetched by all
+// eight L2s: 92 % of the orientation kernel's L2 requests and 79 % of the descriptor kernel's miss (142 MB per frame for 66 MB of
+// planes). Giving XCD x the x-th eighth of every (octave, level) list -- a raster band per level, the same mix of scales on every
+// XCD -- raised the hit rates to 42 % / 59 % and made both kernels SLOWER (descriptors 46.9 against 44.9 us per frame, orientation
+// 18.7 against 17.4, headline -2 %; one contiguous eighth of the whole list: 52 against 46, the XCDs with the large scales carry
+// 25 % more work). The misses are not what these kernels wait for; the bands' uneven keypoint density is worse than the traffic.
+// profiles/r06_m_gather_traffic.txt, r06_n_desc_xcd_locality.txt)
 __global__ __launch_bounds__(256) void frame_orient_kernel(NmDescribeArgs a)
 {
     __shared__ __attribute__((aligned(16))) float s_part[4][ORI_LDS];
     const int wave = threadIdx.x >> 6;
     const int frame = blockIdx.y;
     const NmFrameBook *book = a.book[frame];
-    const int n = book->oct_base[a.o_end];            // keypoints of octaves [o_begin, o_end): output slots [oct_base[o_begin], n)
     const float4 *kpts = reinterpret_cast<const float4 *>(a.kpts[frame]);
     float2 *orients = reinterpret_cast<float2 *>(a.orients[frame]);
-    const int stride = gridDim.x * 4;
-    int pt = book->oct_base[a.o_begin] + blockIdx.x * 4 + wave;
+    const int first = book->oct_base[a.o_begin], n_end = book->oct_base[a.o_end];   // output slots [first, n_end) of octaves [o_begin, o_end)
+    const int vstride = gridDim.x * 4;
+    int v = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
+    auto pick = [&](int vv) { return first + vv < n_end ? first + vv : -1; };
     OriSamples cur, nxt;
     auto fetch = [&](int p, const float4 kp, OriSamples &o) {
         const int oc = octave_of(book, a.num_octaves, p);
         orient_fetch(kp, reinterpret_cast<const float2 *>(a.grad0[frame] + a.grad_off[oc]), a.geom[oc].ow, a.geom[oc].oh, 1.5f,
                      a.geom[oc].xper, o);
     };
+    // (Round 6: the loop carries the keypoint INDICES of the next two iterations instead of re-deriving their bounds from pt: the
+    // same requests in the same order, 18.0 against 18.8 us per frame, alternating on one box.)
     // Two loads deep: the samples of keypoint i + 1 are requested from the keypoint record loaded during keypoint i - 1, behind
     // the VOTES of keypoint i (the only part that reads samples) and in front of its sums, smoothing and peaks. Round 5 stamps
     // of the loop as it was (next keypoint's record loaded and its samples requested at the TOP of an iteration): 23 % of a
@@ -548,17 +559,20 @@ __global__ __launch_bounds__(256) void frame_orient_kernel(NmDescribeArgs a)
     // few hundred cycles earlier as well (`profiles/r05_ak_orient_stamps.txt`).
     const float4 none = make_float4(0.f, 0.f, 0.f, -1.f);           // w < 0: orient_fetch / votes / peaks do nothing
     float4 kp_next = none, kp_after = none;
-    if (pt < n) fetch(pt, kpts[pt], cur);
-    if (pt + stride < n) kp_next = kpts[pt + stride];
-    for (; pt < n; pt += stride) {
-        const bool more = pt + stride < n;
+    int pt = pick(v), pt_next = pick(v + vstride), pt_after = -1;
+    if (pt >= 0) fetch(pt, kpts[pt], cur);
+    if (pt_next >= 0) kp_next = kpts[pt_next];
+    for (; pt >= 0; v += vstride) {
+        const bool more = pt_next >= 0;
         orient_votes(cur, s_part[wave]);
-        if (more) fetch(pt + stride, kp_next, nxt);                     // (kp_next landed an iteration ago: nothing newer is in flight)
-        if (pt + 2 * stride < n) kp_after = kpts[pt + 2 * stride];
+        if (more) fetch(pt_next, kp_next, nxt);                         // (kp_next landed an iteration ago: nothing newer is in flight)
+        pt_after = more ? pick(v + 2 * vstride) : -1;
+        if (pt_after >= 0) kp_after = kpts[pt_after];
         float th0, th1;                           // unset components stay -1 (pyramidata.cu:90)
         orient_peaks(cur, th0, th1, s_part[wave]);
         if ((threadIdx.x & 63) == 0) orients[pt] = make_float2(th0, th1);
         if (more) { cur = nxt; kp_next = kp_after; }
+        pt = pt_next; pt_next = pt_after;
     }
 }
 

@@ -569,7 +569,8 @@ __global__ __launch_bounds__(256) void conv_pk_kernel(NmConvBatch batch, int wid
 // alternating). The row-pair interleaved tile forces 4-BYTE DMA -- lane l lands row (l & 1), column l >> 1: 24 wave-instructions
 // per wave and tile where the register path issues 6 16-byte loads per thread -- and two input images leave 2-4 workgroups per CU
 // where 4-6 one-tile workgroups already overlap one another's loads (the guide's regime rule: LDS-DMA spans pay at ~1 block per CU,
-// not at high occupancy). profiles/r06_e_conv_ring_experiment.txt)
+// not at high occupancy). profiles/r06_e_conv_ring_experiment.txt. Also measured, no effect (+-1 %, 16- and 64-frame chains):
+// the gradient planes stored non-temporally, so that they would not displace the level the next launch reads.)
 // (Round 5, measured and removed: issue priorities (s_setprio 3 while the tile's loads are issued / 2 or 1 in the epilogue / both):
 // 54.2-54.9 us per frame against 54.4-54.5, 64-frame chain, same box -- nothing beyond the run-to-run spread.)
 // (Round 5, measured and removed: 64-ROW tiles with 512 threads -- the share of halo rows the row pass filters and the loads
