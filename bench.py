@@ -726,11 +726,18 @@ def main():
         call's first event pair around it and the others empty): its launches are the calls, with the flops of their pairs."""
         ms = [a.elapsed_time(b) for a, b in evs_all[:EV_STEPS * P]]
         fl = [256.0 * float(counts_host[j][2 * i]) * float(counts_host[j][2 * i + 1]) for j in range(EV_STEPS) for i in range(P)]
-        if nm.get_match_screen() == "f16":
-            calls = [(j * P + k, j * P + min(k + MB, P)) for j in range(EV_STEPS) for k in range(0, P, MB)]
+        # pairs per MFMA launch under the current screen (the library says: nm_sift_match_pairs_per_launch): the launch's first
+        # pair carries its events, the others are recorded back to back
+        ppl = pairs_per_launch()
+        if ppl > 1:
+            calls = [(j * P + k + g, j * P + min(k + g + ppl, k + MB, P)) for j in range(EV_STEPS) for k in range(0, P, MB)
+                     for g in range(0, min(MB, P - k), ppl)]
             ms = [sum(ms[a:b]) for a, b in calls]
             fl = [sum(fl[a:b]) for a, b in calls]
         return ms, fl
+
+    def pairs_per_launch():
+        return max(1, nm.match_pairs_per_launch(min(MB, P)))
 
     screen = nm.get_match_screen()
     evs = mk_events(EV_STEPS * P)
@@ -740,6 +747,7 @@ def main():
     torch.cuda.synchronize()
     counts_host = hist.cpu().tolist()                 # [step][frame]: read AFTER the timed region
     match_ms, match_fl = launch_times(evs, counts_host)
+    ppl_default = pairs_per_launch()
     last_set = (total_steps - 1) % n_sets
     # what the timed loop left in the arenas / results of pair 0, for the oracle check below
     snap = None
@@ -774,6 +782,7 @@ def main():
             torch.cuda.synchronize()
             c32 = hist32.cpu().tolist()
             ms32, fl32 = launch_times(evs32, c32)
+            ppl32 = pairs_per_launch()
             # the last step again through the default screen, matches only: both screens must emit the same indexes
             nm.set_match_screen(screen)
             res2 = [torch.full((CAP,), -1, dtype=torch.int32, device=dev) for _ in range(P)]
@@ -782,7 +791,7 @@ def main():
             torch.cuda.synchronize()
             row = c32[NSUB - 1]
             same = all(torch.equal(res2[i][:row[2 * i]], results[i][:row[2 * i]]) for i in range(P))
-            f32 = {"dt": dt32, "ms": ms32, "fl": fl32, "same": bool(same)}
+            f32 = {"dt": dt32, "ms": ms32, "fl": fl32, "same": bool(same), "ppl": ppl32}
         except Exception as exc:
             f32 = {"error": repr(exc)}
         finally:
@@ -937,13 +946,15 @@ def main():
         p_ms = sum(pyr_ms) / len(pyr_ms) if pyr_ms else float("nan")
         traffic = load_traffic()
 
-        def roof_of(scr, ms, fl):
+        def roof_of(scr, ms, fl, ppl):
             # ALGORITHMIC flops (2NM128, with every launch's own N and M) over the summed launch time
             ach = sum(fl) / (sum(ms) * 1e-3) / 1e12
             if scr == "f32":
-                r = {"kernel": "match_top2_kernel<f32>", "bound": "mfma", "achieved": round(ach, 3),
+                r = {"kernel": "match_top2_group_kernel<f32>" if ppl > 1 else "match_top2_kernel<f32>", "bound": "mfma",
+                     "achieved": round(ach, 3),
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
-                     "traffic": stored(traffic, "match_top2_kernel_f32", "hbm_bytes_per_launch", 1)}
+                     "traffic": stored(traffic, "match_top2_group_kernel_f32" if ppl > 1 else "match_top2_kernel_f32",
+                                       "hbm_bytes_per_launch", ppl)}
             elif scr == "f16":
                 # two-stage screen: the timed kernel is its coarse pass, ONE fp16 product per k (+ one 16-deep k-slot step for
                 # the norms: 1.125 executed flops per algorithmic flop) against the dense fp16 peak. The bf16x3 second pass
@@ -969,7 +980,7 @@ def main():
                      "vs_f32_mfma_peak": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
                      "sustained_bf16_mfma_measured": MFMA_BF16_SUSTAINED_MEASURED_TFLOPS,
                      "frac_executed_of_sustained": round(ach * BF16X3_EXECUTED_PER_ALGORITHMIC / MFMA_BF16_SUSTAINED_MEASURED_TFLOPS, 4),
-                     "traffic": stored(traffic, "match_top2_kernel_bf16x3", "hbm_bytes_per_launch", 1),
+                     "traffic": stored(traffic, "match_top2_kernel_bf16x3", "hbm_bytes_per_launch", 1) if ppl == 1 else None,
                      "note": "screen on split bf16 operands (a_h.b_h + a_h.b_l + a_l.b_h); match decisions are made on "
                              "distances recomputed exactly in fp32 (results bit-identical to the fp32 screen and the oracle)"}
             r.update({"traffic_note": "HBM bytes per launch (as launched here: `pairs_per_launch` pairs for the coarse pass) from the "
@@ -977,10 +988,10 @@ def main():
                                       "launch shape is not this run's)",
                       "avg_ms": round(sum(ms) / len(ms), 4), "launches_timed": len(ms),
                       "avg_launch_flops": round(sum(fl) / len(fl), 1), "screen": scr})
-            if scr == "f16":                              # one launch = the MB pairs of a match call
-                r.update({"pairs_per_launch": MB, "avg_ms_per_pair": round(sum(ms) / len(ms) / MB, 4)})
+            if ppl > 1:                                   # one launch = ppl pairs of a match call (the coarse pass: all MB of them)
+                r.update({"pairs_per_launch": ppl, "avg_ms_per_pair": round(sum(ms) / len(ms) / ppl, 4)})
             return r
-        roof = roof_of(screen, match_ms, match_fl)
+        roof = roof_of(screen, match_ms, match_fl, ppl_default)
         roof["launch_shape_last_step_pair0"] = [nA, nB, 128]
         if snap.get("rows"):
             roof["rows_second_pass_sample"], roof["rows_exact_fallback_sample"] = snap["rows"]     # first pair of the last match call
@@ -1017,7 +1028,7 @@ def main():
                 out["roofline_f32_screen"] = {"error": f32["error"]}
             else:
                 out["value_f32_screen"] = round(pairs_total / f32["dt"], 3)
-                out["roofline_f32_screen"] = roof_of("f32", f32["ms"], f32["fl"])
+                out["roofline_f32_screen"] = roof_of("f32", f32["ms"], f32["fl"], f32["ppl"])
                 # also in the HEAD of the line (a truncated tail of the line still shows them)
                 head["value_f32_screen"] = out["value_f32_screen"]
                 head["roofline_f32_screen_frac"] = out["roofline_f32_screen"]["frac"]

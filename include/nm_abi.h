@@ -280,6 +280,13 @@ NM_API int nm_sift_match_distance_listed(const void *workspace, int nA, int nB, 
  * NM_MATCH_SCREEN=f32|bf16x3|f16 sets the initial value. Extension: the reference has one (exact VALU) path. */
 NM_API int nm_sift_match_set_screen(int screen);
 NM_API int nm_sift_match_get_screen(void);
+/* How many pairs ONE launch of the screening kernel covers in a batched call of n_pairs non-empty pairs under the current screen
+ * (diagnostic: what a timing harness divides a launch's duration by). Round 6: when n_pairs is a multiple of the device's XCD count
+ * every pair of a launch belongs to one XCD (its workgroups alone screen it, the XCDs work on 8 pairs side by side): the two-stage
+ * screen's coarse pass is one launch for all n_pairs, the single-pass screens launch once per 8 pairs; otherwise the coarse pass
+ * still covers all pairs and the single-pass screens launch once per pair. NM_COARSE_PAIR_XCD=0 / NM_TOP2_PAIR_XCD=0 keep the
+ * divisions of rounds 3-5. Results never depend on the division. */
+NM_API int nm_sift_match_pairs_per_launch(int n_pairs);
 /* n <= 16 independent matches in one call (arrays of n): the norms, finalize and fallback launches cover all pairs at
  * once (the pair is a grid dimension), only the MFMA kernel runs once per pair -- 4 + n stream operations instead of
  * 5 n. result[k] as in nm_sift_match_f32 (no distance matrices). workspace: nm_sift_match_batch_workspace_bytes bytes

@@ -66,6 +66,7 @@ _SIGNATURES = {
     "nm_sift_match_workspace_bytes": (_SZ, [_I, _I]),
     "nm_sift_match_set_screen": (_I, [_I]),
     "nm_sift_match_get_screen": (_I, []),
+    "nm_sift_match_pairs_per_launch": (_I, [_I]),
     "nm_sift_match_set_distance_mode": (_I, [_I]),
     "nm_sift_set_detect_tall_min": (_I, [_I]),
     "nm_sift_match_get_distance_mode": (_I, []),
@@ -433,6 +434,11 @@ def set_match_screen(name):
 def get_match_screen():
     v = lib().nm_sift_match_get_screen()
     return [k for k, x in MATCH_SCREENS.items() if x == v][0]
+
+
+def match_pairs_per_launch(n_pairs):
+    """Pairs one launch of the screening kernel covers in a batched call of n_pairs pairs under the current screen (nm_abi.h)."""
+    return int(lib().nm_sift_match_pairs_per_launch(int(n_pairs)))
 
 
 def set_detect_tall_min(min_groups=-1):

@@ -817,7 +817,7 @@ __device__ __forceinline__ void match_top2_body(const float *__restrict__ A, int
                                                 MatchPlan plan_arg, float4 *__restrict__ partial,
                                                 float *__restrict__ partial3,
                                                 const int *__restrict__ d_nA, const int *__restrict__ d_nB,
-                                                const MatchPlan *__restrict__ d_plan)
+                                                const MatchPlan *__restrict__ d_plan, const int wg)
 {
     static_assert(SCR == 0 || SCR == 1, "the coarse pass of the two-stage screen has its own kernel (match_coarse_kernel)");
     constexpr bool BF16 = SCR == 1, DMA = SCR != 0;
@@ -826,7 +826,6 @@ __device__ __forceinline__ void match_top2_body(const float *__restrict__ A, int
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int srow = tid >> 5, scol = (tid & 31) * 4;     // staging coordinates: 16 rows x 32 float4 per pass
-    const int wg = blockIdx.x;
     int nA = nA_arg, nB = nB_arg;
     MatchPlan plan = plan_arg;
     if (d_plan) {                                         // uniform: scalar loads
@@ -835,6 +834,7 @@ __device__ __forceinline__ void match_top2_body(const float *__restrict__ A, int
         plan = *d_plan;
         if (nA <= 0 || nB <= 0 || wg >= plan.G) return;   // an empty set is a no-op for the pair, as in the reference
     }
+    if (wg >= plan.G) return;                             // (group launches are sized for the chip, not for the plan)
     const int S = plan.S;
     const int xg = wg % plan.X, vg = wg / plan.X;         // XCD group (blocks b, b + X share an XCD) and position in it
     const PlanGroup grp = plan_group(plan, xg);
@@ -1335,7 +1335,20 @@ __global__ __launch_bounds__(512, 2) void match_top2_kernel(const float *__restr
                                                            const int *__restrict__ d_nA, const int *__restrict__ d_nB,
                                                            const MatchPlan *__restrict__ d_plan)
 {
-    match_top2_body<SCR>(A, nA_arg, B, nB_arg, na, nb, nbslot, plan_arg, partial, partial3, d_nA, d_nB, d_plan);
+    match_top2_body<SCR>(A, nA_arg, B, nB_arg, na, nb, nbslot, plan_arg, partial, partial3, d_nA, d_nB, d_plan, (int)blockIdx.x);
+}
+
+// Round 6: the single-pass screens with ONE XCD PER PAIR, like the coarse pass: a launch covers `xcd` pairs of the call (first,
+// first + 1, ...), pair first + (b mod xcd) on the workgroups b of that XCD with local index b / xcd, each under a one-group plan
+// for n_cu / xcd workgroups (host-sized calls: plans.p; device-sized: the pair's d_plan, made for that geometry by nbmax_kernel).
+struct MatchPlanPack { MatchPlan p[8]; };
+template <int SCR>
+__global__ __launch_bounds__(512, 2) void match_top2_group_kernel(MatchBatch bt, int first, int xcd, MatchPlanPack plans)
+{
+    const int k = (int)blockIdx.x % xcd;
+    const MatchPair &c = bt.p[first + k];
+    match_top2_body<SCR>(SCR ? reinterpret_cast<const float *>(c.As) : c.A, c.nA, SCR ? reinterpret_cast<const float *>(c.Bs) : c.B, c.nB,
+                         c.na, c.nb, c.nbslot, plans.p[k], c.partial, c.partial3, c.d_nA, c.d_nB, c.d_plan, (int)blockIdx.x / xcd);
 }
 
 // Second pass of the two-stage screen, all pairs of a call in ONE launch (blockIdx.y = pair): the bf16x3 screen on the
@@ -1345,7 +1358,7 @@ __global__ __launch_bounds__(512, 2) void match_top2_rows_kernel(MatchBatch bt)
 {
     const MatchPair &c = bt.p[blockIdx.y];
     match_top2_body<1>(reinterpret_cast<const float *>(c.As), c.nA, reinterpret_cast<const float *>(c.Bs), c.nB, c.na2, c.nb,
-                       c.nbslot, MatchPlan{}, c.partial, c.partial3, pair_f1_count(c), c.d_nB, pair_plan2(c));
+                       c.nbslot, MatchPlan{}, c.partial, c.partial3, pair_f1_count(c), c.d_nB, pair_plan2(c), (int)blockIdx.x);
 }
 
 __device__ __forceinline__ float exact_dist(const float4 *__restrict__ a, const float4 *__restrict__ b)
@@ -2491,9 +2504,18 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
     // fetches ITS pairs' fp16 images once (2 x 3.1 MB, which it holds) where each of the 8 L2s fetched every pair's candidate
     // tiles (643 MB per 16-pair launch against 146 MB algorithmic). NM_COARSE_PAIR_XCD=0 keeps the old division.
     bt.pair_xcd = 0;
-    if (screen == 2 && xcd > 1 && n_cu % xcd == 0 && bt.n >= xcd && bt.n % xcd == 0) {
+    if (xcd > 1 && xcd <= 8 && n_cu % xcd == 0 && bt.n >= xcd && bt.n % xcd == 0) {
         static const int env = [] { const char *e = getenv("NM_COARSE_PAIR_XCD"); return e ? atoi(e) : 1; }();
-        if (env) { bt.pair_xcd = xcd; bt.n_cu = n_cu / xcd; bt.n_xcd = 1; }
+        // (the single-pass screens, NM_MATCH_SCREEN=f32 / bf16x3, take the same division: one launch per `xcd` pairs)
+        static const int env1 = [] { const char *e = getenv("NM_TOP2_PAIR_XCD"); return e ? atoi(e) : 1; }();
+        if (screen == 2 ? env : env1) {
+            bt.pair_xcd = xcd; bt.n_cu = n_cu / xcd; bt.n_xcd = 1;
+            if (screen != 2 && !dev_sized)                           // host-sized plans are made here: for the XCD's share of the chip
+                for (int q = 0; q < bt.n; ++q) {
+                    plans[q] = make_plan_on(bt.p[q].nA, bt.p[q].nB, bt.n_cu, 1, 0, 1, [](int v) { return v; });
+                    bt.p[q].S = plans[q].S;
+                }
+        }
     }
     if (phases & NM_MATCH_PHASE_PREP) {
         const dim3 pg(nm_divup(max_rows, PREP_ROWS), bt.n);
@@ -2517,6 +2539,10 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
     if (screen == 2)
         NM_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void *>(match_top2_rows_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full));
+    else if (bt.pair_xcd > 0)
+        NM_RETURN_IF(hipFuncSetAttribute(screen ? reinterpret_cast<const void *>(match_top2_group_kernel<1>)
+                                                : reinterpret_cast<const void *>(match_top2_group_kernel<0>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     for (int q = 0; (phases & NM_MATCH_PHASE_SCREEN) && q < bt.n; ++q) {
         const MatchPair &c = bt.p[q];
         // device-sized: one workgroup per CU, of which the first plan.G (decided on the device) work
@@ -2527,6 +2553,14 @@ static int run_fused_batch(const MatchJob *jobs, int n, float ambiguity, hipStre
         nm_prof_begin(NM_PROF_MATCH_TOP2, st);
         if (screen == 2) {
             if (q == 0) hipLaunchKernelGGL(match_coarse_kernel, dim3(n_cu), dim3(512), lds_bytes, st, bt);
+        } else if (bt.pair_xcd > 0) {
+            // one launch per `xcd` pairs (the first pair's events bracket it, the others' are recorded back to back)
+            if (q % bt.pair_xcd == 0) {
+                MatchPlanPack pk{};
+                for (int k = 0; k < bt.pair_xcd; ++k) pk.p[k] = dev_sized ? MatchPlan{} : plans[q + k];
+                if (screen) hipLaunchKernelGGL(match_top2_group_kernel<1>, dim3(n_cu), dim3(512), lds_bytes, st, bt, q, bt.pair_xcd, pk);
+                else hipLaunchKernelGGL(match_top2_group_kernel<0>, dim3(n_cu), dim3(512), lds_bytes, st, bt, q, bt.pair_xcd, pk);
+            }
         } else if (screen)
             hipLaunchKernelGGL(match_top2_kernel<1>, dim3(grid), dim3(512), lds_bytes, st,
                                reinterpret_cast<const float *>(c.As), c.nA, reinterpret_cast<const float *>(c.Bs), c.nB,
@@ -2620,6 +2654,16 @@ int nm_sift_match_set_screen(int screen)
     return 0;
 }
 int nm_sift_match_get_screen(void) { return match_screen(); }
+
+int nm_sift_match_pairs_per_launch(int n_pairs)
+{
+    if (n_pairs <= 0) return 0;
+    const int screen = match_screen(), xcd = nm_xcd_count(), n_cu = nm_cu_count();
+    if (screen == 2) return n_pairs;
+    const char *e = getenv("NM_TOP2_PAIR_XCD");
+    const bool grouped = (!e || atoi(e)) && xcd > 1 && xcd <= 8 && n_cu % xcd == 0 && n_pairs >= xcd && n_pairs % xcd == 0;
+    return grouped ? xcd : 1;
+}
 
 float nm_sift_match_distance_budget(void) { return DIST_C; }
 

@@ -80,6 +80,7 @@ def test_stored_pmc_constants_carry_the_launch_shape_bench_divides_by():
     t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     args = bench.parse_args([])
     tails = {"match_coarse_kernel": args.match_batch, "match_top2_kernel_f32": 1, "match_top2_kernel_bf16x3": 1,
+             "match_top2_group_kernel_f32": 8,
              "distance_mfma_kernel": 1, "pyramid_all": args.batch, "pyramid_frame_driver": args.batch,
              "pyramid_levels_dog_only": args.batch, "frame_desc_kernel": args.batch, "frame_orient_kernel": args.batch,
              "detect_stage_kernel": args.batch}

@@ -34,6 +34,7 @@ JOBS = collections.OrderedDict([
     ("match_coarse_kernel", (["tools/kcoarse16.py"], {"PAIRS": str(MB)}, ["FETCH_SIZE", "WRITE_SIZE"], "match_coarse_kernel", "launch")),
     ("match_top2_kernel_f32", (["tools/kmatch_sustained.py", "16"], {"NM_MATCH_SCREEN": "f32"}, ["FETCH_SIZE", "WRITE_SIZE"], "match_top2_kernel", "launch")),
     ("match_top2_kernel_bf16x3", (["tools/kmatch_sustained.py", "16"], {"NM_MATCH_SCREEN": "bf16x3"}, ["FETCH_SIZE", "WRITE_SIZE"], "match_top2_kernel", "launch")),
+    ("match_top2_group_kernel_f32", (["tools/kcoarse16.py"], {"PAIRS": str(MB), "NM_MATCH_SCREEN": "f32"}, ["FETCH_SIZE", "WRITE_SIZE"], "match_top2_group_kernel", "launch")),
     ("distance_mfma_kernel", (["tools/kdist.py"], {}, ["FETCH_SIZE", "WRITE_SIZE"], "distance_mfma_kernel", "launch")),
     ("frame_desc_kernel", (["tools/ksite.py", "describe", str(B)], {}, ["SQ_INSTS_VALU SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"], "frame_desc_kernel", "counters")),
     ("frame_orient_kernel", (["tools/ksite.py", "orient", str(B)], {}, ["SQ_INSTS_VALU SQ_INSTS_LDS"], "frame_orient_kernel", "counters")),
@@ -41,7 +42,8 @@ JOBS = collections.OrderedDict([
 ])
 SHAPES = {"pyramid_all": [1920, 1080, B], "pyramid_frame_driver": [1920, 1080, B], "pyramid_levels_dog_only": [1920, 1080, B],
           "match_coarse_kernel": [12223, 12080, 128, MB], "match_top2_kernel_f32": [12223, 12080, 128, 1],
-          "match_top2_kernel_bf16x3": [12223, 12080, 128, 1], "distance_mfma_kernel": [12223, 12080, 128, 1],
+          "match_top2_kernel_bf16x3": [12223, 12080, 128, 1], "match_top2_group_kernel_f32": [12223, 12080, 128, 8],
+          "distance_mfma_kernel": [12223, 12080, 128, 1],
           "frame_desc_kernel": [1920, 1080, B], "frame_orient_kernel": [1920, 1080, B], "detect_stage_kernel": [1920, 1080, B]}
 
 
