@@ -570,7 +570,9 @@ __global__ __launch_bounds__(256) void conv_pk_kernel(NmConvBatch batch, int wid
 // per wave and tile where the register path issues 6 16-byte loads per thread -- and two input images leave 2-4 workgroups per CU
 // where 4-6 one-tile workgroups already overlap one another's loads (the guide's regime rule: LDS-DMA spans pay at ~1 block per CU,
 // not at high occupancy). profiles/r06_e_conv_ring_experiment.txt. Also measured, no effect (+-1 %, 16- and 64-frame chains):
-// the gradient planes stored non-temporally, so that they would not displace the level the next launch reads.)
+// the gradient planes stored non-temporally, so that they would not displace the level the next launch reads. And the frame
+// driver's chain in GROUPS of frames (the five launches of octave 0 / 1 for 8, 16 or 32 frames back to back, so that a level is
+// still in the 256 MB Infinity Cache when the next launch reads it): 56.1 / 53.9 / 52.6 against 51.9 us per frame.)
 // (Round 5, measured and removed: issue priorities (s_setprio 3 while the tile's loads are issued / 2 or 1 in the epilogue / both):
 // 54.2-54.9 us per frame against 54.4-54.5, 64-frame chain, same box -- nothing beyond the run-to-run spread.)
 // (Round 5, measured and removed: 64-ROW tiles with 512 threads -- the share of halo rows the row pass filters and the loads
