@@ -585,7 +585,9 @@ __global__ __launch_bounds__(256) void frame_orient_kernel(NmDescribeArgs a)
 // (Round 6, measured and removed: the weights and the votes' adds as packed fp32 -- (wm ax) ay and * at as v_pk_mul_f32, a round's
 // eight adds as four v_pk_add_f32 on the ds_read2 pairs; |1 - r| = 1 - r and |0 - r| = r hold bit for bit on r in [0, 1] -- 165 -> 141
 // vector instructions per pass, bit-identical, and 3 % SLOWER (47.3 against 45.8 us per frame, alternating): an exec-masked
-// v_add_f32 with 16 live lanes costs less than its share of a packed instruction. profiles/r06_k_desc_packed_ab.txt)
+// v_add_f32 with 16 live lanes costs less than its share of a packed instruction. profiles/r06_k_desc_packed_ab.txt. Taking that
+// at its word -- a half wave (two of a pass's four rows) none of whose samples can vote leaves the pass through EXEC -- is
+// bit-identical too and 2 % slower: 46.8 against 45.9 us per frame, five alternations.)
 // (Setting up keypoint pt + stride -- window and first chunk of samples -- before computing keypoint pt was measured:
 // 983 vs 930 us per 16 frames. This kernel is bound by VALU issue, not by the gather latency, and the second setup costs
 // 12 VGPRs. The straightforward loop stays.)
