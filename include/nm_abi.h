@@ -77,6 +77,13 @@ NM_API int nm_selftest_sqrt(unsigned long long *d_mismatches, void *stream);
  * compared. d_out (device, 3 x unsigned long long): [0] unreported differences (must be 0), [1] inputs that report a nearby
  * boundary, [2] inputs tested. */
 NM_API int nm_selftest_expw(unsigned long long *d_out, void *stream);
+/* Self-test (no reference counterpart): the orientation kernel (kernels/orientation.cu:39-75, 181-192) hoists a keypoint's part of
+ * each vote's arithmetic -- the window test in binary32, r2 / (2 sigma^2) with the divisor's reciprocal refined once, the 3-tap
+ * mean's division by 3 as a binary32 residual correction. Each form is compared with the expression it replaces: the two
+ * one-operand forms over ALL 2^32 binary32 inputs, the division on 2^32 pseudo-random pairs of its domain. d_out (device,
+ * 5 x unsigned long long): [0] differing thirds (must be 0), [1] inputs the third's guard rejects (2^24 + 1), [2] differing window
+ * tests (must be 0), [3] differing quotients (must be 0), [4] quotients tested. */
+NM_API int nm_selftest_orient(unsigned long long *d_out, void *stream);
 /* Self-test of the matrix-pipe rounding premise under the matcher's proofs (no reference counterpart; what it protects is
  * the exact scan of kernels/match.cu:83-117, which match_finalize_kernel must reproduce from MFMA-screened candidates).
  * instruction: 0 = v_mfma_f32_32x32x16_bf16 (bf16x3 screen, every norm k-slot), 1 = v_mfma_f32_32x32x16_f16 (coarse pass of

@@ -88,6 +88,7 @@ _SIGNATURES = {
     "nm_align_points": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "nm_selftest_sqrt": (_I, [_P, _P]),
     "nm_selftest_expw": (_I, [_P, _P]),
+    "nm_selftest_orient": (_I, [_P, _P]),
     "nm_selftest_mfma_model": (_I, [_I, _I, _I, _P, _P]),
     "nm_sift_match_accum_budget": (_F, [_I]),
     "nm_selftest_mfma_f32": (_I, [_I, _I, _P, _P]),
@@ -586,6 +587,15 @@ def selftest_expw():
     torch = _torch()
     out = torch.zeros(3, dtype=torch.int64, device="cuda")
     _check(lib().nm_selftest_expw(_dev(out), _stream()), "nm_selftest_expw")
+    return tuple(int(v) for v in out.cpu())
+
+
+def selftest_orient():
+    """nm_selftest_orient: (differing thirds, inputs the third's guard rejects, differing window tests, differing quotients,
+    quotients tested) of the orientation kernel's hoisted arithmetic against the expressions it replaces. [0], [2], [3] must be 0."""
+    torch = _torch()
+    out = torch.zeros(5, dtype=torch.int64, device="cuda")
+    _check(lib().nm_selftest_orient(_dev(out), _stream()), "nm_selftest_orient")
     return tuple(int(v) for v in out.cpu())
 
 

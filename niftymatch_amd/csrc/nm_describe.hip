@@ -67,15 +67,31 @@ __device__ __forceinline__ void orient_fetch(const float4 kp, const float2 *__re
 
 // part: ORI_LDS floats private to the wave, [bin][strip]. First half of a keypoint: zero the partial sums, cast the votes (the
 // only part that reads the gathered samples).
-__device__ __forceinline__ void orient_votes(const OriSamples &o, float *part)
+// FAST (a wave-uniform choice of the caller, orient_votes below): the vote's arithmetic with the keypoint's part of it hoisted --
+//   * `(double)r2 < r2lim` as the binary32 compare r2 < C, C the smallest binary32 >= r2lim (equivalent for every r2, NaN too);
+//   * r2 / denom by nmfp::div_by (5 instructions instead of the 11 of the IEEE expansion), its domain checked per keypoint:
+//     denom in [2^-20, 2^20], and r2 = 0 or >= 2^-100 because x, y are 0 or at least 2^-50 in magnitude (dx = (float)n - x is
+//     then 0 or at least 2^-50: for n != 0 it is 0 or no smaller than half an ulp of n);
+//   * the quotient is >= 0, so expf_spec's lower clamp is dropped;
+//   * bin = b mod 36 as a select when every lane's b lies in [0, 36] (orientations in [0, 2 pi] as the gradient kernel writes
+//     them; any other value takes `%`).
+__device__ __forceinline__ float orient_r2cap(double r2lim)      // r2lim > 0
+{
+    const float c = (float)r2lim;
+    return (double)c < r2lim ? __uint_as_float(__float_as_uint(c) + 1u) : c;      // the next binary32 up
+}
+
+template <bool FAST>
+__device__ __forceinline__ void orient_votes_as(const OriSamples &o, float *part)
 {
     const int lane = threadIdx.x & 63;
-    if (!o.valid) return;
     const float x = o.x, y = o.y;
     const int xi = o.xi, yi = o.yi, W = o.W;
     const int xmin = o.xmin, xmax = o.xmax, ymin = o.ymin, ymax = o.ymax;
     const float denom = o.denom;
     const double r2lim = (double)(W * W) + 0.6;
+    const float r2cap = orient_r2cap(r2lim);
+    const nmfp::DivBy by = nmfp::div_by(denom);
 
     {   // zero the wave's 36 x 65 partial sums with 16-byte stores (585 float4: 9 rounds of 64 lanes + 9)
         static_assert(ORI_LDS % 4 == 0 && ORI_LDS / 4 == 9 * 64 + 9, "zeroing pattern");
@@ -94,8 +110,8 @@ __device__ __forceinline__ void orient_votes(const OriSamples &o, float *part)
         const int cy = ymin + 7 * rg + j;
         const float dx = (float)(cx + xi) - x, dy = (float)(cy + yi) - y;
         const float r2 = fma32(dx, dx, dy * dy);
-        if (col_ok && cy <= ymax && (double)r2 < r2lim) {
-            const float wgt = nmfp::expf_spec(r2 / denom);
+        if (col_ok && cy <= ymax && (FAST ? r2 < r2cap : (double)r2 < r2lim)) {
+            const float wgt = FAST ? nmfp::expf_spec<true>(nmfp::div_by(by, r2)) : nmfp::expf_spec(r2 / denom);
             // Only floor(q) of q = (float)((double)(36 theta) / 2 pi) is used. A binary32 estimate q' = (36 theta) * (1 / 2 pi)
             // is within 1e-5 of q (q <= 36), so floor(q') = floor(q) whenever q' is at least 1e-4 away from an integer; the
             // few samples inside that band take the exact expression.
@@ -105,23 +121,59 @@ __device__ __forceinline__ void orient_votes(const OriSamples &o, float *part)
             const float dq = qe - fq;
             if (__builtin_expect(!(dq > 1e-4f && dq < 0.9999f), 0))
                 fq = __builtin_floorf(nmfp::div_to_f32((double)t36, nmfp::TWO_PI_D, nmfp::INV_TWO_PI_D));
-            const int bin = ((int)fq) % 36;
+            const int b = (int)fq;
+            int bin;
+            if (FAST && !__builtin_expect(__any((unsigned)b > 36u), 0)) bin = b == 36 ? 0 : b;
+            else bin = b % 36;
             mine[bin * ORI_PITCH] += o.gv[j].x * wgt;   // lane-private word: plain read-add-write, program order
         }
     }
     __builtin_amdgcn_wave_barrier();             // same-wave LDS traffic is in order; this only pins the compiler
 }
 
+__device__ __forceinline__ void orient_votes(const OriSamples &o, float *part)
+{
+    if (!o.valid) return;
+    const float ax = __builtin_fabsf(o.x), ay = __builtin_fabsf(o.y);
+    const bool fast = nmfp::div_by_domain(o.denom) && (ax == 0.f || ax >= 0x1p-50f) && (ay == 0.f || ay >= 0x1p-50f);
+#ifdef NM_ORIENT_PLAIN
+    if (false) orient_votes_as<true>(o, part);
+#else
+    if (__builtin_amdgcn_readfirstlane((int)fast)) orient_votes_as<true>(o, part);       // a keypoint's values are wave-uniform
+#endif
+    else orient_votes_as<false>(o, part);
+}
+
+// Lane exchanges of the second half as DPP operands of the instructions that consume them (no LDS traffic, no waits): the wave
+// rotations by one lane of GFX9 for the circular neighbours, the row patterns for the maximum.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lane_value(float v, int l)      // l wave-uniform
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+constexpr int DPP_WAVE_ROL1 = 0x134, DPP_WAVE_ROR1 = 0x13C;       // lane i <- lane i + 1 / lane i - 1, modulo 64
+constexpr int DPP_QUAD_X1 = 0xB1, DPP_QUAD_X2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+
 // Second half: sums, smoothing, peaks. Returns the number of peaks found (0..2); th0/th1 are valid in every lane.
+// Lane b < 36 owns bin b. The six smoothing rounds and the peak test read the two circular neighbours of a bin; so that these are
+// the neighbouring LANES, lanes 36..42 carry copies of bins 0..6 and lanes 57..63 copies of bins 29..35 (lane 63 -> lane 0 is the
+// rotation's wrap): a copy computes what its bin's owner computes, from the same operands in the same order, and stays right as
+// long as both its neighbours are -- the run of right lanes 57..63, 0..42 loses one lane at either end per round, and after six
+// rounds lanes 63, 0..36 are left, which is what the peak test of lanes 0..35 reads. Lanes 43..56 hold finite junk.
 __device__ __forceinline__ int orient_peaks(const OriSamples &o, float &th0, float &th1, const float *part)
 {
     const int lane = threadIdx.x & 63;
     th0 = -1.f; th1 = -1.f;
     if (!o.valid) return 0;
 
-    float h = 0.f;                                // lane b < 36 owns bin b: partials in strip order
-    if (lane < 36) {                              // h = ((row[0] + row[1]) + row[2]) + ... + row[62], reads 9 at a time
-        const float *row = part + lane * ORI_PITCH;
+    const int hb = lane < 36 ? lane : lane < 43 ? lane - 36 : lane >= 57 ? lane - 28 : -1;
+    float h = 0.f;                                // partials in strip order
+    if (hb >= 0) {                                // h = ((row[0] + row[1]) + row[2]) + ... + row[62], reads 9 at a time
+        const float *row = part + hb * ORI_PITCH;
 #pragma unroll
         for (int g = 0; g < 7; ++g) {
             float v[9];
@@ -133,25 +185,30 @@ __device__ __forceinline__ int orient_peaks(const OriSamples &o, float &th0, flo
     }
     __builtin_amdgcn_wave_barrier();
 
-    const int lm = (lane + 35) % 36, lp = (lane + 1) % 36;
 #pragma unroll
     for (int iter = 0; iter < 6; ++iter) {        // race-free circular 3-tap mean (orientation.cu:181-192)
-        const float prev = __shfl(h, lm), next = __shfl(h, lp);
-        const float nh = nmfp::div_to_f32((double)((prev + h) + next), 3.0, 1.0 / 3.0);    // == (float)(double(..) / 3.0)
-        h = (lane < 36) ? nh : 0.f;
+        const float s3 = (dpp_f32<DPP_WAVE_ROR1>(h) + h) + dpp_f32<DPP_WAVE_ROL1>(h);      // nh == (float)((double)s3 / 3.0)
+#ifdef NM_ORIENT_PLAIN
+        h = nmfp::div_to_f32((double)s3, 3.0, 1.0 / 3.0);
+#else
+        h = __builtin_expect(__all(nmfp::third_f32_exact(s3)), 1) ? nmfp::third_f32(s3) : nmfp::div_to_f32((double)s3, 3.0, 1.0 / 3.0);
+#endif
     }
-    float m = (lane < 36) ? h : 0.f;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, d));
+    const float hm = dpp_f32<DPP_WAVE_ROR1>(h), hp = dpp_f32<DPP_WAVE_ROL1>(h);
+    float m = (lane < 36) ? h : 0.f;              // the maximum of 64 values, in any order
+    m = __builtin_fmaxf(m, dpp_f32<DPP_QUAD_X1>(m));
+    m = __builtin_fmaxf(m, dpp_f32<DPP_QUAD_X2>(m));
+    m = __builtin_fmaxf(m, dpp_f32<DPP_HALF_MIRROR>(m));
+    m = __builtin_fmaxf(m, dpp_f32<DPP_ROW_MIRROR>(m));          // every lane: the maximum of its row of 16
+    m = __builtin_fmaxf(__builtin_fmaxf(lane_value(m, 0), lane_value(m, 16)), lane_value(m, 32));   // row 3 is all zeros, as is half of row 2
     const float threshold = (float)((double)m * 0.8);
-    const float hm = __shfl(h, lm), hp = __shfl(h, lp);
     const bool peak = (lane < 36) && (h > threshold) && (h > hm) && (h > hp);
     unsigned long long mask = __ballot(peak);
     const float di = (float)((-0.5 * (double)(hp - hm)) / (double)((hp + hm) - 2 * h));
-    const float th = (float)((nmfp::TWO_PI_D * ((double)((float)lane + di) + 0.5)) / 36.0);
+    const float th = nmfp::div_to_f32(nmfp::TWO_PI_D * ((double)((float)lane + di) + 0.5), 36.0, 1.0 / 36.0);
     int npk = 0;
-    if (mask) { th0 = __shfl(th, __ffsll((long long)mask) - 1); mask &= mask - 1; npk = 1; }
-    if (mask) { th1 = __shfl(th, __ffsll((long long)mask) - 1); npk = 2; }
+    if (mask) { th0 = lane_value(th, __ffsll((long long)mask) - 1); mask &= mask - 1; npk = 1; }
+    if (mask) { th1 = lane_value(th, __ffsll((long long)mask) - 1); npk = 2; }
     return npk;
 }
 
@@ -627,6 +684,46 @@ __global__ __launch_bounds__(256) void selftest_expw_kernel(unsigned long long *
     if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], bad); atomicAdd(&out[1], nears); atomicAdd(&out[2], n); }
 }
 
+// Self-test of the orientation kernel's hoisted arithmetic against the expressions it replaces (tests/test_gpu_stages.py):
+// out[0] = binary32 x (ALL 2^32) with third_f32_exact(x) and third_f32(x) != (float)((double)x / 3.0)          (must be 0)
+// out[1] = binary32 x that third_f32_exact rejects (2^24 + 1: the NaNs, the infinities, -0)
+// out[2] = (r2, W) with (r2 < orient_r2cap(W W + 0.6)) != ((double)r2 < W W + 0.6), all 2^32 r2 x W = 1..10  (must be 0)
+// out[3] = pseudo-random (num, den) of div_by's domain with div_by(den)(num) != num / den                     (must be 0)
+// out[4] = pairs tested for out[3]
+__global__ __launch_bounds__(256) void selftest_orient_kernel(unsigned long long *out)
+{
+    unsigned long long bad3 = 0, rej = 0, badc = 0, badd = 0, nd = 0;
+    float cap[10];
+    for (int W = 1; W <= 10; ++W) cap[W - 1] = orient_r2cap((double)(W * W) + 0.6);
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t b = tid; b < (1ull << 32); b += nth) {
+        const float x = __uint_as_float((uint32_t)b);
+        if (!nmfp::third_f32_exact(x)) ++rej;
+        else if (__float_as_uint(nmfp::third_f32(x)) != __float_as_uint((float)((double)x / 3.0))) ++bad3;
+#pragma unroll
+        for (int W = 1; W <= 10; ++W)
+            if ((x < cap[W - 1]) != ((double)x < (double)(W * W) + 0.6)) ++badc;
+    }
+    unsigned long long st = 0x9E3779B97F4A7C15ull * (tid + 1);
+    for (int it = 0; it < 2048; ++it) {
+        st = st * 6364136223846793005ull + 1442695040888963407ull;
+        const unsigned a = (unsigned)(st >> 32), c = (unsigned)st;
+        const int ed = (int)((a >> 23) % 41u) - 20;                                    // den in [2^-20, 2^21): clipped to the domain below
+        float den = __uint_as_float(((unsigned)(ed + 127) << 23) | (a & 0x7FFFFFu));
+        if (den > 0x1p20f) den = 0x1p20f;
+        const int en = (int)((c >> 23) % 108u) - 100;                                  // num in [2^-100, 2^7), one in 256 exactly 0
+        const float num = (c >> 24) == 0u ? 0.0f : __uint_as_float(((unsigned)(en + 127) << 23) | (c & 0x7FFFFFu));
+        ++nd;
+        if (__float_as_uint(nmfp::div_by(nmfp::div_by(den), num)) != __float_as_uint(num / den)) ++badd;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        bad3 += __shfl_xor(bad3, d); rej += __shfl_xor(rej, d); badc += __shfl_xor(badc, d); badd += __shfl_xor(badd, d); nd += __shfl_xor(nd, d);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[0], bad3); atomicAdd(&out[1], rej); atomicAdd(&out[2], badc); atomicAdd(&out[3], badd); atomicAdd(&out[4], nd);
+    }
+}
+
 }  // namespace
 
 // workgroups (of 4 keypoint-waves) per frame: few enough that a wave walks several keypoints and the prefetch pays
@@ -662,6 +759,15 @@ int nm_selftest_expw(unsigned long long *d_out, void *stream)
     if (!d_out) return (int)hipErrorInvalidValue;
     NM_RETURN_IF(hipMemsetAsync(d_out, 0, 3 * sizeof(unsigned long long), nm_stream(stream)));
     hipLaunchKernelGGL(selftest_expw_kernel, dim3(8192), dim3(256), 0, nm_stream(stream), d_out);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+int nm_selftest_orient(unsigned long long *d_out, void *stream)
+{
+    if (!d_out) return (int)hipErrorInvalidValue;
+    NM_RETURN_IF(hipMemsetAsync(d_out, 0, 5 * sizeof(unsigned long long), nm_stream(stream)));
+    hipLaunchKernelGGL(selftest_orient_kernel, dim3(8192), dim3(256), 0, nm_stream(stream), d_out);
     NM_LAUNCH_CHECK();
     return 0;
 }

@@ -75,6 +75,40 @@ __device__ __forceinline__ void div3_to_f32_wave(double a1, double a2, double b,
 }
 constexpr float TWO_PI_F = (float)(2 * 3.14159265358979323846);
 
+// (float)((double)x / 3.0) in three binary32 instructions: q = RN(x R) with R = RN32(1/3), one exact-residual correction. Equal to
+// the binary64 expression for EVERY binary32 x except -0 (gives +0), the infinities and NaN (give NaN), which third_f32_exact
+// names (one v_cmp_class) so that a caller can send them through div_to_f32: checked over all 2^32 inputs by nm_selftest_orient.
+__device__ __forceinline__ bool third_f32_exact(float x) { return !__builtin_amdgcn_classf(x, 0x227); }   // not: NaN, +-inf, -0
+__device__ __forceinline__ float third_f32(float x)
+{
+    const float R = 0x1.555556p-2f;
+    const float q = x * R;
+    return fma32(fma32(-3.0f, q, x), R, q);
+}
+
+// num / den for one divisor and many numerators: the instruction sequence of the IEEE expansion (rcp, one refinement, two
+// quotient corrections) with the divisor's part done once, and without the expansion's range scaling and special-case fix-up.
+// The same binary32 as `num / den` whenever neither is needed: den in [2^-20, 2^20] (div_by_domain), num = 0 or in [2^-100, 2^7)
+// -- the quotient and both exact residuals then stay in the normal range. Checked against `/` on that domain by nm_selftest_orient.
+struct DivBy {
+    float nden, rc;
+};
+__device__ __forceinline__ bool div_by_domain(float den) { return den >= 0x1p-20f && den <= 0x1p20f; }
+__device__ __forceinline__ DivBy div_by(float den)
+{
+    DivBy d;
+    const float r0 = __builtin_amdgcn_rcpf(den);
+    d.nden = -den;
+    d.rc = fma32(fma32(d.nden, r0, 1.0f), r0, r0);
+    return d;
+}
+__device__ __forceinline__ float div_by(const DivBy &d, float num)
+{
+    float q = num * d.rc;
+    q = fma32(fma32(d.nden, q, num), d.rc, q);
+    return fma32(fma32(d.nden, q, num), d.rc, q);
+}
+
 // atan(ay/ax), ax > 0, ay >= 0: one IEEE division (range chosen by products, see oracle/nmo_math.h)
 __device__ __forceinline__ float atanf_q1(float ay, float ax)
 {
@@ -111,10 +145,12 @@ __device__ __forceinline__ float mod_2pi_f(float x)      // kernels/cudamath.h:8
     return x;
 }
 
+// NONNEG: the caller knows that x >= 0 or x is NaN, for which the lower clamp never fires.
+template <bool NONNEG = false>
 __device__ __forceinline__ float expf_spec(float x)
 {
     if (x > 88.0f) x = 88.0f;
-    if (x < -87.0f) x = -87.0f;
+    if (!NONNEG && x < -87.0f) x = -87.0f;
     const float z = __builtin_floorf(fma32(1.44269504088896341f, x, 0.5f));
     const int n = (int)z;
     float r = fma32(z, -0.693359375f, x);

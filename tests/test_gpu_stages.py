@@ -67,6 +67,16 @@ def test_descriptor_weight_fast_form_equals_the_spec_sequence_everywhere(nm):
     assert near < n / 2 ** 13            # the fallback stays rare (2^-15 expected)
 
 
+def test_orientation_hoisted_arithmetic_equals_the_expressions_it_replaces(nm):
+    """frame_orient_kernel divides by 3 in binary32 (exact-residual form), tests the window in binary32 and divides r2 by a
+    keypoint's 2 sigma^2 through a once-refined reciprocal: all 2^32 floats for the two one-operand forms (every window radius),
+    2^32 pseudo-random pairs of its guarded domain for the division, each against the plain expression on the device."""
+    bad3, rejected, badc, badd, nd = nm.selftest_orient()
+    assert bad3 == 0 and badc == 0 and badd == 0
+    assert rejected == 2 ** 24 + 1          # NaNs (2^24 - 2), the two infinities, -0: these take the binary64 expression
+    assert nd == 8192 * 256 * 2048
+
+
 def _octave(oracle, w, h, seed):
     lv0 = H.blurred_frame(seed, w, h, sigma=2.0)
     return oracle.octave_pyramid(lv0, 1920, 1080)
