@@ -136,11 +136,7 @@ __device__ __forceinline__ void orient_votes(const OriSamples &o, float *part)
     if (!o.valid) return;
     const float ax = __builtin_fabsf(o.x), ay = __builtin_fabsf(o.y);
     const bool fast = nmfp::div_by_domain(o.denom) && (ax == 0.f || ax >= 0x1p-50f) && (ay == 0.f || ay >= 0x1p-50f);
-#ifdef NM_ORIENT_PLAIN
-    if (false) orient_votes_as<true>(o, part);
-#else
     if (__builtin_amdgcn_readfirstlane((int)fast)) orient_votes_as<true>(o, part);       // a keypoint's values are wave-uniform
-#endif
     else orient_votes_as<false>(o, part);
 }
 
@@ -163,7 +159,7 @@ constexpr int DPP_QUAD_X1 = 0xB1, DPP_QUAD_X2 = 0x4E, DPP_HALF_MIRROR = 0x141, D
 // the neighbouring LANES, lanes 36..42 carry copies of bins 0..6 and lanes 57..63 copies of bins 29..35 (lane 63 -> lane 0 is the
 // rotation's wrap): a copy computes what its bin's owner computes, from the same operands in the same order, and stays right as
 // long as both its neighbours are -- the run of right lanes 57..63, 0..42 loses one lane at either end per round, and after six
-// rounds lanes 63, 0..36 are left, which is what the peak test of lanes 0..35 reads. Lanes 43..56 hold finite junk.
+// rounds lanes 63, 0..36 are left, which is what the peak test of lanes 0..35 reads. Lanes 43..56 hold junk that nothing reads.
 __device__ __forceinline__ int orient_peaks(const OriSamples &o, float &th0, float &th1, const float *part)
 {
     const int lane = threadIdx.x & 63;
@@ -188,11 +184,7 @@ __device__ __forceinline__ int orient_peaks(const OriSamples &o, float &th0, flo
 #pragma unroll
     for (int iter = 0; iter < 6; ++iter) {        // race-free circular 3-tap mean (orientation.cu:181-192)
         const float s3 = (dpp_f32<DPP_WAVE_ROR1>(h) + h) + dpp_f32<DPP_WAVE_ROL1>(h);      // nh == (float)((double)s3 / 3.0)
-#ifdef NM_ORIENT_PLAIN
-        h = nmfp::div_to_f32((double)s3, 3.0, 1.0 / 3.0);
-#else
         h = __builtin_expect(__all(nmfp::third_f32_exact(s3)), 1) ? nmfp::third_f32(s3) : nmfp::div_to_f32((double)s3, 3.0, 1.0 / 3.0);
-#endif
     }
     const float hm = dpp_f32<DPP_WAVE_ROR1>(h), hp = dpp_f32<DPP_WAVE_ROL1>(h);
     float m = (lane < 36) ? h : 0.f;              // the maximum of 64 values, in any order
