@@ -72,7 +72,8 @@ __device__ __forceinline__ void orient_fetch(const float4 kp, const float2 *__re
 //   * r2 / denom by nmfp::div_by (5 instructions instead of the 11 of the IEEE expansion), its domain checked per keypoint:
 //     denom in [2^-20, 2^20], and r2 = 0 or >= 2^-100 because x, y are 0 or at least 2^-50 in magnitude (dx = (float)n - x is
 //     then 0 or at least 2^-50: for n != 0 it is 0 or no smaller than half an ulp of n);
-//   * the quotient is >= 0, so expf_spec's lower clamp is dropped;
+//   * the quotient lies in [0, 87.1] (r2 < C <= 87 denom), so expf_spec's two clamps are dropped;
+//   * a row's (float)(cy + yi) as fy0 + j (|y| < 2^22: both sides exact);
 //   * bin = b mod 36 as a select when every lane's b lies in [0, 36] (orientations in [0, 2 pi] as the gradient kernel writes
 //     them; any other value takes `%`).
 __device__ __forceinline__ float orient_r2cap(double r2lim)      // r2lim > 0
@@ -105,13 +106,14 @@ __device__ __forceinline__ void orient_votes_as(const OriSamples &o, float *part
     const int cx = xmin + rx;
     const bool col_ok = (lane < 63) && (cx <= xmax);
     float *mine = part + lane;
+    const int cy0 = ymin + 7 * rg, rows_left = ymax - cy0;
+    const float dx = (float)(cx + xi) - x;
+    const float fy0 = (float)(cy0 + yi);             // FAST: |y| < 2^22, so (float)(cy0 + yi + j) = fy0 + j, both exact
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
-        const int cy = ymin + 7 * rg + j;
-        const float dx = (float)(cx + xi) - x, dy = (float)(cy + yi) - y;
+        const float dy = (FAST ? fy0 + (float)j : (float)(cy0 + j + yi)) - y;
         const float r2 = fma32(dx, dx, dy * dy);
-        if (col_ok && cy <= ymax && (FAST ? r2 < r2cap : (double)r2 < r2lim)) {
-            const float wgt = FAST ? nmfp::expf_spec<true>(nmfp::div_by(by, r2)) : nmfp::expf_spec(r2 / denom);
+        if (col_ok && j <= rows_left && (FAST ? r2 < r2cap : (double)r2 < r2lim)) {
             // Only floor(q) of q = (float)((double)(36 theta) / 2 pi) is used. A binary32 estimate q' = (36 theta) * (1 / 2 pi)
             // is within 1e-5 of q (q <= 36), so floor(q') = floor(q) whenever q' is at least 1e-4 away from an integer; the
             // few samples inside that band take the exact expression.
@@ -123,9 +125,12 @@ __device__ __forceinline__ void orient_votes_as(const OriSamples &o, float *part
                 fq = __builtin_floorf(nmfp::div_to_f32((double)t36, nmfp::TWO_PI_D, nmfp::INV_TWO_PI_D));
             const int b = (int)fq;
             int bin;
-            if (FAST && !__builtin_expect(__any((unsigned)b > 36u), 0)) bin = b == 36 ? 0 : b;
+            if (FAST && !__builtin_expect(__any((unsigned)b > 36u), 0)) bin = (int)min((unsigned)b, (unsigned)b - 36u);   // b - 36 wraps unless b = 36
             else bin = b % 36;
-            mine[bin * ORI_PITCH] += o.gv[j].x * wgt;   // lane-private word: plain read-add-write, program order
+            float *const word = FAST ? mine + __mul24(bin, ORI_PITCH) : mine + bin * ORI_PITCH;
+            const float sum = *word;                    // lane-private word: plain read-add-write, program order
+            const float wgt = FAST ? nmfp::expf_spec<0>(nmfp::div_by(by, r2)) : nmfp::expf_spec(r2 / denom);
+            *word = sum + o.gv[j].x * wgt;
         }
     }
     __builtin_amdgcn_wave_barrier();             // same-wave LDS traffic is in order; this only pins the compiler
@@ -135,7 +140,8 @@ __device__ __forceinline__ void orient_votes(const OriSamples &o, float *part)
 {
     if (!o.valid) return;
     const float ax = __builtin_fabsf(o.x), ay = __builtin_fabsf(o.y);
-    const bool fast = nmfp::div_by_domain(o.denom) && (ax == 0.f || ax >= 0x1p-50f) && (ay == 0.f || ay >= 0x1p-50f);
+    const bool fast = nmfp::div_by_domain(o.denom) && (ax == 0.f || ax >= 0x1p-50f) && (ay == 0.f || ay >= 0x1p-50f) &&
+                      ay < 0x1p22f && orient_r2cap((double)(o.W * o.W) + 0.6) <= 87.0f * o.denom;
     if (__builtin_amdgcn_readfirstlane((int)fast)) orient_votes_as<true>(o, part);       // a keypoint's values are wave-uniform
     else orient_votes_as<false>(o, part);
 }

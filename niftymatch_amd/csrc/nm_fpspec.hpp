@@ -145,12 +145,13 @@ __device__ __forceinline__ float mod_2pi_f(float x)      // kernels/cudamath.h:8
     return x;
 }
 
-// NONNEG: the caller knows that x >= 0 or x is NaN, for which the lower clamp never fires.
-template <bool NONNEG = false>
+// CLAMP: which of the two clamps are compiled (1: upper, 2: lower); a caller that knows x <= 88 / x >= -87 (or NaN, for which
+// neither fires) drops them.
+template <int CLAMP = 3>
 __device__ __forceinline__ float expf_spec(float x)
 {
-    if (x > 88.0f) x = 88.0f;
-    if (!NONNEG && x < -87.0f) x = -87.0f;
+    if ((CLAMP & 1) && x > 88.0f) x = 88.0f;
+    if ((CLAMP & 2) && x < -87.0f) x = -87.0f;
     const float z = __builtin_floorf(fma32(1.44269504088896341f, x, 0.5f));
     const int n = (int)z;
     float r = fma32(z, -0.693359375f, x);
