@@ -255,7 +255,15 @@ __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
     v.mask = MASKED ? (DENSE ? a.mask : a.masks[frame]) : nullptr; v.mask_w = a.mask_w; v.mask_h = a.mask_h;
     v.ow = a.ow; v.oh = a.oh; v.peak = a.peak; v.edge = a.edge; v.xper = a.xper; v.sigma0 = a.sigma0;
     v.num_dogs = a.num_dogs; v.n_blocks = a.n_blocks; v.nseg = a.nseg;
-    detect_stage_body<DENSE, LEV, MASKED, false, 1, ROWS>(v, blockIdx.x, &sm);
+    int blk = blockIdx.x;
+    if (!DENSE && a.xcd_band > 0) {                      // NmDetectArgs::xcd_band
+        const int xcd = blk & 7, slot = blk >> 3;
+        const int row = slot / a.nseg, seg = slot - row * a.nseg;
+        const int yg = xcd * a.xcd_band + row;
+        if (yg >= a.group_rows) return;                  // the whole workgroup: padding of the last band
+        blk = yg * a.nseg + seg;
+    }
+    detect_stage_body<DENSE, LEV, MASKED, false, 1, ROWS>(v, blk, &sm);
 }
 
 __global__ __launch_bounds__(1024) void scan_book_kernel(NmScanArgs a)
@@ -317,15 +325,22 @@ __global__ __launch_bounds__(256) void gather_stage_kernel(NmGatherArgs a)
 constexpr int DET_TALL_MIN_DEFAULT = NM_DET_TALL_MIN_DEFAULT;
 static std::atomic<int> g_tall_min{DET_TALL_MIN_DEFAULT};
 
-int nm_launch_detect_octave(const NmDetectArgs &d, const NmScanArgs &s, const NmGatherArgs &g, hipStream_t stream)
+int nm_launch_detect_octave(const NmDetectArgs &d_in, const NmScanArgs &s, const NmGatherArgs &g, hipStream_t stream)
 {
+    NmDetectArgs d = d_in;
     if (d.n_blocks <= 0 || d.n <= 0) return 0;
-    const dim3 grid(d.nseg * nm_divup(d.oh, DET_ROWS), d.n);
+    dim3 grid(d.nseg * nm_divup(d.oh, DET_ROWS), d.n);
     const bool prof = s.octave == 0;
     if (prof) nm_prof_begin(NM_PROF_DETECT_O0, stream);
     // tall unit groups when there are thousands of them even so (see DET_ROWS_TALL)
-    const dim3 tall(d.nseg * nm_divup(d.oh, DET_ROWS_TALL), d.n);
+    dim3 tall(d.nseg * nm_divup(d.oh, DET_ROWS_TALL), d.n);
     const bool use_tall = d.from_levels && (long)tall.x * tall.y >= g_tall_min.load(std::memory_order_relaxed);
+    {   // XCD bands (NmDetectArgs::xcd_band) when every XCD gets at least two group rows
+        static const int env_band = [] { const char *e = getenv("NM_DETECT_XCD_BANDS"); return e ? atoi(e) : 1; }();
+        d.group_rows = nm_divup(d.oh, use_tall ? DET_ROWS_TALL : DET_ROWS);
+        d.xcd_band = (env_band && d.group_rows >= 16) ? nm_divup(d.group_rows, 8) : 0;
+        if (d.xcd_band) { grid.x = 8 * d.xcd_band * d.nseg; tall.x = grid.x; }
+    }
     if (use_tall && d.any_mask)
         hipLaunchKernelGGL((detect_stage_kernel<false, true, true, DET_ROWS_TALL>), tall, dim3(256), 0, stream, d);
     else if (use_tall)
