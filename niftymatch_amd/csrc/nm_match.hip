@@ -731,6 +731,9 @@ __device__ __forceinline__ void f16_kstep(f32x16 &acc0, f32x16 &acc1, const u32x
 // k-step lasts ~64-128 cycles, less than an LDS read under load, so the fragments of a whole half group (8 x 16 bytes per
 // lane) are requested while the previous half group is multiplied.
 // fr[2 t], fr[2 t + 1] = the lane's chunks of k-step KS0 + t for the two accumulators.
+// (Round 6, measured: the fragment reads are NOT what the kernel waits for -- a diagnostic build that issues HALF of them (the
+// second accumulator reusing the first one's chunk; what 64 queries per wave would save) runs the 16-pair launch in 593.4-595.4
+// against 600.2-601.0 us, three alternations on one box: -1.2 %. profiles/r06_y_coarse_half_fragment_reads.txt)
 template <int KS0>
 __device__ __forceinline__ void f16_fetch(u32x4 (&fr)[8], const char *tb, const unsigned (&foff)[8])
 {
