@@ -696,10 +696,47 @@ constexpr int COARSE_SLOT_BITS = 6;
 // one to the running triple a second time as the group's third: every value of the group it did not keep is >= it, which
 // is all the third key is for (the lower bound `rest` of the finalize pass). The price: a segment whose two best
 // candidates share a group reports third == second and its row goes to the second pass (~0.5 % of the rows more).
-template <bool SELECT, int E0>
+// Diagnostic builds only (tools/build_variant.py stub_X nm_match.hip -DNM_STUB_X=1; tools/gpu_coarse_ab.sh): NM_STUB_NOSELECT drops
+// the selection instructions, NM_STUB_NOMFMA the matrix instructions, NM_STUB_NODMA the tile requests of the ring. Round 6, 16-pair
+// launch, one box, three alternations, us per pair: whole 36.8 | no selection 31.7 | no MFMA 22.3 | no requests 33.6 | neither
+// selection nor MFMA 16.2 | none of the three 12.6 (fragment reads, norm slots, barriers, fold, publication). The MFMAs' share is
+// their own pipe time (37.8 GFLOP at the 2.5 PFLOP/s peak = 15.1 us per pair): NOTHING else of an iteration runs under them -- the
+// per-tile barrier keeps the eight waves in the same phase, so a SIMD's two waves want the matrix pipe together and stall together.
+// profiles/r06_y_coarse_stubs.txt. No stub executes in the product.
+template <bool SELECT_, int E0>
 __device__ __forceinline__ void f16_kstep(f32x16 &acc0, f32x16 &acc1, const u32x4 h0, const u32x4 h1, const u32x4 qh,
                                           float p0, float p1, float p2, float p3, int &g1, int &g2)
 {
+#ifdef NM_STUB_NOSELECT
+    constexpr bool SELECT = false;
+#else
+    constexpr bool SELECT = SELECT_;
+#endif
+#ifdef NM_STUB_NOMFMA
+    if (SELECT) {
+        int k;
+        const int mask = ~((1 << COARSE_SLOT_BITS) - 1);
+        asm volatile("v_and_or_b32 %4, %8, %12, %13\n\t"
+                     "v_med3_i32 %3, %2, %3, %4\n\t"
+                     "v_min_i32 %2, %2, %4\n\t"
+                     "v_and_or_b32 %4, %9, %12, %14\n\t"
+                     "v_med3_i32 %3, %2, %3, %4\n\t"
+                     "v_min_i32 %2, %2, %4\n\t"
+                     "v_and_or_b32 %4, %10, %12, %15\n\t"
+                     "v_med3_i32 %3, %2, %3, %4\n\t"
+                     "v_min_i32 %2, %2, %4\n\t"
+                     "v_and_or_b32 %4, %11, %12, %16\n\t"
+                     "v_med3_i32 %3, %2, %3, %4\n\t"
+                     "v_min_i32 %2, %2, %4"
+                     : "+v"(acc0), "+v"(acc1), "+v"(g1), "+v"(g2), "=&v"(k)
+                     : "v"(h0), "v"(h1), "v"(qh), "v"(p0), "v"(p1), "v"(p2), "v"(p3), "s"(mask),
+                       "n"(E0), "n"(E0 + 1), "n"(E0 + 2), "n"(E0 + 3)
+                     : "memory");
+    } else {
+        asm volatile("" : "+v"(acc0), "+v"(acc1) : "v"(h0), "v"(h1), "v"(qh) : "memory");
+    }
+    return;
+#endif
     if (SELECT) {
         int k;
         const int mask = ~((1 << COARSE_SLOT_BITS) - 1);
@@ -1299,7 +1336,9 @@ __global__ __launch_bounds__(512, 1) void match_coarse_kernel(MatchBatch bt)
             NM_STAMP(6);
             // (The request spread over the last half group, one piece behind each k-step, measured 1.5 % SLOWER than five
             // instructions back to back here: 651 against 642 us per 16-pair launch, same box.)
+#ifndef NM_STUB_NODMA
             if (ex2) dma_tile(in2 ? pc_cur.rsB : nB_rs, in2 ? pc_cur.rsS : nS_rs, tile2, b);
+#endif
             f16_half<true, 4, 32>(b0, b1, a1, frB, qw, g1, g2);
             fold(g1, g2, g2, n);
             NM_STAMP(7);
