@@ -163,6 +163,38 @@ def test_keypoints_orientations_descriptors(nm, oracle, cuda, wh):
     assert total > 20
 
 
+def test_orientations_outside_the_hoisted_forms_domain(nm, oracle, cuda):
+    """The orientation kernel runs a keypoint's votes in their hoisted form only inside a guarded domain (2 sigma_w^2 in
+    [2^-20, 2^20], coordinates 0 or >= 2^-50 and below 2^22, quotient below 87) and the 3-tap mean's binary32 division only for
+    finite sums: keypoints and gradients outside either -- tiny and huge scales, a denormal-range coordinate, infinite
+    magnitudes, orientations beyond 2 pi (bins 37.. take `%`) and exactly 2 pi (bin 36 -> 0) -- must still equal the oracle bit
+    for bit, beside ordinary keypoints on the same planes."""
+    w, h = 320, 200
+    levels, dogs, grad = oracle.octave_pyramid(_extreme_level0(w, h), 1920, 1080)
+    grad = np.array(grad, dtype=np.float32, copy=True)
+    assert np.isinf(grad[..., 0]).any()                       # the 3e30 plateau's edge: dx^2 overflows
+    two_pi = np.float32(2 * 3.14159265358979323846)
+    grad[0, 60:70, 100:130, 1] = two_pi                       # bin 36
+    grad[0, 70:80, 100:130, 1] = np.float32(7.5)              # bin 42 -> 6 through the generic remainder
+    grad[0, 60:80, 100:130, 0] = np.float32(3.0)
+    xper = 2.0
+    rng = np.random.default_rng(11)
+    rows = []
+    for _ in range(200):                                      # ordinary keypoints all over the plane (borders included)
+        rows.append((rng.uniform(0, w - 1) * xper, rng.uniform(0, h - 1) * xper, rng.uniform(1.0, 4.5) * xper, 0.0))
+    for x, y in ((110.3, 66.2), (120.9, 74.5), (105.0, 79.0), (162.0, 12.0), (170.5, 52.0)):
+        for sc in (1e-4, 3e-4, 1.6, 2.7, 1e5, 1e6):          # tiny / ordinary / huge scales on the special regions
+            rows.append((x * xper, y * xper, sc * xper, 0.0))
+    rows.append((1e-30 * xper, 40.0 * xper, 2.0 * xper, 0.0))     # denormal-range coordinates
+    rows.append((55.0 * xper, 3e-25 * xper, 2.0 * xper, 0.0))
+    rows.append((0.0, 0.0, 2.0 * xper, 0.0))
+    kp = np.asarray(rows, dtype=np.float32)
+    ref = oracle.detect_orientations(kp, grad, w, h, 1.5, xper)
+    got = nm.detect_orientations(_t(kp, cuda), _t(grad, cuda), w, h, 1.5, xper)
+    _eq(got, ref, "orientations outside the hoisted forms' domain")
+    assert (np.asarray(ref)[:, 0] >= 0).sum() > 50
+
+
 def test_masked_keypoints(nm, oracle, cuda):
     w, h = 160, 120
     levels, dogs, grad = _octave(oracle, w, h, 9)
