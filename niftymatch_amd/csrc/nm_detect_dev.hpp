@@ -143,6 +143,7 @@ constexpr int DET_ROWS = 5;
 #define NM_DET_ROWS_TALL 20
 #endif
 constexpr int DET_ROWS_TALL = NM_DET_ROWS_TALL;
+constexpr int DET_ROWS_TALL2 = 27;       // the second tall height (nm_launch_detect_octave picks per launch)
 // A wave tests 62 columns: its lanes 0 and 63 hold the halo columns of the 3 x 3 neighbourhoods and test nothing, so every lane
 // loads ONE value per plane and row and the horizontal neighbours come from the adjacent lanes alone. (Until round 5 a wave
 // tested 64 columns and every lane loaded a second value -- the left neighbour on lane 0, the right one elsewhere -- of which

@@ -325,30 +325,40 @@ __global__ __launch_bounds__(256) void gather_stage_kernel(NmGatherArgs a)
 constexpr int DET_TALL_MIN_DEFAULT = NM_DET_TALL_MIN_DEFAULT;
 static std::atomic<int> g_tall_min{DET_TALL_MIN_DEFAULT};
 
+// One detection launch of the frame driver with ROWS image rows per unit group. bands: the unit groups are dealt to the XCDs in
+// bands of group rows (NmDetectArgs::xcd_band) when every XCD gets at least two.
+template <int ROWS>
+static void launch_detect_rows(NmDetectArgs &d, bool bands, hipStream_t stream)
+{
+    d.group_rows = nm_divup(d.oh, ROWS);
+    d.xcd_band = (bands && d.group_rows >= 16) ? nm_divup(d.group_rows, 8) : 0;
+    const dim3 grid(d.xcd_band ? 8 * d.xcd_band * d.nseg : d.nseg * d.group_rows, d.n);
+    if (d.from_levels && d.any_mask) hipLaunchKernelGGL((detect_stage_kernel<false, true, true, ROWS>), grid, dim3(256), 0, stream, d);
+    else if (d.from_levels) hipLaunchKernelGGL((detect_stage_kernel<false, true, false, ROWS>), grid, dim3(256), 0, stream, d);
+    else if (d.any_mask) hipLaunchKernelGGL((detect_stage_kernel<false, false, true, ROWS>), grid, dim3(256), 0, stream, d);
+    else hipLaunchKernelGGL((detect_stage_kernel<false, false, false, ROWS>), grid, dim3(256), 0, stream, d);
+}
+
 int nm_launch_detect_octave(const NmDetectArgs &d_in, const NmScanArgs &s, const NmGatherArgs &g, hipStream_t stream)
 {
     NmDetectArgs d = d_in;
     if (d.n_blocks <= 0 || d.n <= 0) return 0;
-    dim3 grid(d.nseg * nm_divup(d.oh, DET_ROWS), d.n);
     const bool prof = s.octave == 0;
     if (prof) nm_prof_begin(NM_PROF_DETECT_O0, stream);
-    // tall unit groups when there are thousands of them even so (see DET_ROWS_TALL)
-    dim3 tall(d.nseg * nm_divup(d.oh, DET_ROWS_TALL), d.n);
-    const bool use_tall = d.from_levels && (long)tall.x * tall.y >= g_tall_min.load(std::memory_order_relaxed);
-    {   // XCD bands (NmDetectArgs::xcd_band) when every XCD gets at least two group rows
-        static const int env_band = [] { const char *e = getenv("NM_DETECT_XCD_BANDS"); return e ? atoi(e) : 1; }();
-        d.group_rows = nm_divup(d.oh, use_tall ? DET_ROWS_TALL : DET_ROWS);
-        d.xcd_band = (env_band && d.group_rows >= 16) ? nm_divup(d.group_rows, 8) : 0;
-        if (d.xcd_band) { grid.x = 8 * d.xcd_band * d.nseg; tall.x = grid.x; }
+    static const bool bands = [] { const char *e = getenv("NM_DETECT_XCD_BANDS"); return e ? atoi(e) != 0 : true; }();
+    // tall unit groups when there are thousands of them even so (see DET_ROWS_TALL). Of the two tall heights the launch takes the
+    // one under which the busiest XCD walks fewer image rows, halo rows included: ceil(groups / 8) * (ROWS + 2) -- at 1080 rows
+    // 27 divides into 40 groups, five per XCD and none of them partial (145 rows against the 154 of 54 groups of 20: octave 0 of
+    // 64 frames 12.5 -> 11.9 us per frame; 24, 26, 28 rows are all SLOWER than 20: profiles/r06_z_detect_rows.txt), at 480 rows
+    // 20 wins (66 against 87).
+    const long tall_groups = (long)d.nseg * nm_divup(d.oh, DET_ROWS_TALL) * d.n;
+    if (d.from_levels && tall_groups >= g_tall_min.load(std::memory_order_relaxed)) {
+        auto cost = [&](int rows) { return nm_divup(nm_divup(d.oh, rows), 8) * (rows + 2); };
+        if (cost(DET_ROWS_TALL2) < cost(DET_ROWS_TALL)) launch_detect_rows<DET_ROWS_TALL2>(d, bands, stream);
+        else launch_detect_rows<DET_ROWS_TALL>(d, bands, stream);
+    } else {
+        launch_detect_rows<DET_ROWS>(d, bands, stream);
     }
-    if (use_tall && d.any_mask)
-        hipLaunchKernelGGL((detect_stage_kernel<false, true, true, DET_ROWS_TALL>), tall, dim3(256), 0, stream, d);
-    else if (use_tall)
-        hipLaunchKernelGGL((detect_stage_kernel<false, true, false, DET_ROWS_TALL>), tall, dim3(256), 0, stream, d);
-    else if (d.from_levels && d.any_mask) hipLaunchKernelGGL((detect_stage_kernel<false, true, true>), grid, dim3(256), 0, stream, d);
-    else if (d.from_levels) hipLaunchKernelGGL((detect_stage_kernel<false, true, false>), grid, dim3(256), 0, stream, d);
-    else if (d.any_mask) hipLaunchKernelGGL((detect_stage_kernel<false, false, true>), grid, dim3(256), 0, stream, d);
-    else hipLaunchKernelGGL((detect_stage_kernel<false, false, false>), grid, dim3(256), 0, stream, d);
     if (prof) nm_prof_end(NM_PROF_DETECT_O0, stream);
     NM_LAUNCH_CHECK();
     hipLaunchKernelGGL(scan_book_kernel, dim3(s.n), dim3(1024), 0, stream, s);
