@@ -573,6 +573,9 @@ __global__ __launch_bounds__(256) void conv_pk_kernel(NmConvBatch batch, int wid
 // the gradient planes stored non-temporally, so that they would not displace the level the next launch reads. And the frame
 // driver's chain in GROUPS of frames (the five launches of octave 0 / 1 for 8, 16 or 32 frames back to back, so that a level is
 // still in the 256 MB Infinity Cache when the next launch reads it): 56.1 / 53.9 / 52.6 against 51.9 us per frame.)
+// (Round 6, measured and removed: the frames of every other launch walked in REVERSE order, so that a launch starts on the planes
+// the previous one wrote last (256 MB of Infinity Cache = the last ~10 frames' outputs): 51.1-51.5 against 51.4-51.7 us per frame,
+// three alternations -- nothing. profiles/r06_z_conv_pingpong.txt)
 // (Round 5, measured and removed: issue priorities (s_setprio 3 while the tile's loads are issued / 2 or 1 in the epilogue / both):
 // 54.2-54.9 us per frame against 54.4-54.5, 64-frame chain, same box -- nothing beyond the run-to-run spread.)
 // (Round 5, measured and removed: 64-ROW tiles with 512 threads -- the share of halo rows the row pass filters and the loads
