@@ -257,11 +257,8 @@ __global__ __launch_bounds__(256) void detect_stage_kernel(NmDetectArgs a)
     v.num_dogs = a.num_dogs; v.n_blocks = a.n_blocks; v.nseg = a.nseg;
     int blk = blockIdx.x;
     if (!DENSE && a.xcd_band > 0) {                      // NmDetectArgs::xcd_band
-        const int xcd = blk & 7, slot = blk >> 3;
-        const int row = slot / a.nseg, seg = slot - row * a.nseg;
-        const int yg = xcd * a.xcd_band + row;
-        if (yg >= a.group_rows) return;                  // the whole workgroup: padding of the last band
-        blk = yg * a.nseg + seg;
+        blk = (blk & 7) * a.xcd_band + (blk >> 3);
+        if (blk >= a.group_rows * a.nseg) return;        // the whole workgroup: padding of the last band
     }
     detect_stage_body<DENSE, LEV, MASKED, false, 1, ROWS>(v, blk, &sm);
 }
@@ -320,19 +317,23 @@ __global__ __launch_bounds__(256) void gather_stage_kernel(NmGatherArgs a)
 }  // namespace
 
 #ifndef NM_DET_TALL_MIN_DEFAULT
-#define NM_DET_TALL_MIN_DEFAULT 2048             // eight workgroups per CU
+// 20-row unit groups of a launch from which it takes tall groups. Round 5: 2 048 (eight workgroups per CU). Round 6: 1 200 -- octave 2
+// of a 64-frame 1080p call (1 792 such groups = 1 280 workgroups of 27 rows) 73 -> 52 us (profiles/r06_z_detect_tall_min.txt); a
+// single frame's octave 0 (432) keeps the 5-row groups that fill the chip.
+#define NM_DET_TALL_MIN_DEFAULT 1200
 #endif
 constexpr int DET_TALL_MIN_DEFAULT = NM_DET_TALL_MIN_DEFAULT;
 static std::atomic<int> g_tall_min{DET_TALL_MIN_DEFAULT};
 
 // One detection launch of the frame driver with ROWS image rows per unit group. bands: the unit groups are dealt to the XCDs in
-// bands of group rows (NmDetectArgs::xcd_band) when every XCD gets at least two.
+// bands (NmDetectArgs::xcd_band) when every XCD gets at least eight.
 template <int ROWS>
 static void launch_detect_rows(NmDetectArgs &d, bool bands, hipStream_t stream)
 {
     d.group_rows = nm_divup(d.oh, ROWS);
-    d.xcd_band = (bands && d.group_rows >= 16) ? nm_divup(d.group_rows, 8) : 0;
-    const dim3 grid(d.xcd_band ? 8 * d.xcd_band * d.nseg : d.nseg * d.group_rows, d.n);
+    const int groups = d.group_rows * d.nseg;
+    d.xcd_band = (bands && groups >= 64) ? nm_divup(groups, 8) : 0;
+    const dim3 grid(d.xcd_band ? 8 * d.xcd_band : groups, d.n);
     if (d.from_levels && d.any_mask) hipLaunchKernelGGL((detect_stage_kernel<false, true, true, ROWS>), grid, dim3(256), 0, stream, d);
     else if (d.from_levels) hipLaunchKernelGGL((detect_stage_kernel<false, true, false, ROWS>), grid, dim3(256), 0, stream, d);
     else if (d.any_mask) hipLaunchKernelGGL((detect_stage_kernel<false, false, true, ROWS>), grid, dim3(256), 0, stream, d);
@@ -347,13 +348,12 @@ int nm_launch_detect_octave(const NmDetectArgs &d_in, const NmScanArgs &s, const
     if (prof) nm_prof_begin(NM_PROF_DETECT_O0, stream);
     static const bool bands = [] { const char *e = getenv("NM_DETECT_XCD_BANDS"); return e ? atoi(e) != 0 : true; }();
     // tall unit groups when there are thousands of them even so (see DET_ROWS_TALL). Of the two tall heights the launch takes the
-    // one under which the busiest XCD walks fewer image rows, halo rows included: ceil(groups / 8) * (ROWS + 2) -- at 1080 rows
-    // 27 divides into 40 groups, five per XCD and none of them partial (145 rows against the 154 of 54 groups of 20: octave 0 of
-    // 64 frames 12.5 -> 11.9 us per frame; 24, 26, 28 rows are all SLOWER than 20: profiles/r06_z_detect_rows.txt), at 480 rows
-    // 20 wins (66 against 87).
+    // one under which the busiest XCD walks fewer segment rows, halo rows included: ceil(groups / 8) * (ROWS + 2) -- at 1080p
+    // 27 rows divide into 320 groups, 40 per XCD and none of them partial (1 160 rows against the 1 188 of 432 groups of 20:
+    // octave 0 of 64 frames 12.5 -> 11.9 us per frame; 24, 26, 28 rows are all SLOWER than 20: profiles/r06_z_detect_rows.txt).
     const long tall_groups = (long)d.nseg * nm_divup(d.oh, DET_ROWS_TALL) * d.n;
     if (d.from_levels && tall_groups >= g_tall_min.load(std::memory_order_relaxed)) {
-        auto cost = [&](int rows) { return nm_divup(nm_divup(d.oh, rows), 8) * (rows + 2); };
+        auto cost = [&](int rows) { return nm_divup(nm_divup(d.oh, rows) * d.nseg, 8) * (rows + 2); };
         if (cost(DET_ROWS_TALL2) < cost(DET_ROWS_TALL)) launch_detect_rows<DET_ROWS_TALL2>(d, bands, stream);
         else launch_detect_rows<DET_ROWS_TALL>(d, bands, stream);
     } else {

@@ -35,10 +35,11 @@ struct NmDetectArgs {
     // det_blocks that detect (the reference resets the whole maps with thrust::fill per octave, siftfunctions.cu:120-121)
     size_t reset_end[3];
     int det_blocks, fill_blocks;
-    // frame driver: unit groups dealt to the XCDs in BANDS of xcd_band consecutive group rows (0: blockIdx.x is the group). The
-    // hardware deals workgroups round-robin over the 8 XCDs; with grid.x = 8 * xcd_band * nseg, workgroup b is slot b / 8 of XCD
-    // b % 8, and slot s of XCD k is group row k * xcd_band + s / nseg, segment s % nseg: the cache lines two neighbouring segments
-    // share (a segment is 248 pixels: 992 B, 7.75 lines) and the halo rows of two neighbouring group rows are then fetched by ONE L2.
+    // frame driver: unit groups (raster order: group row, segment) dealt to the XCDs in BANDS of xcd_band consecutive groups (0:
+    // blockIdx.x is the group). The hardware deals workgroups round-robin over the 8 XCDs; with grid.x = 8 * xcd_band, workgroup b
+    // is slot b / 8 of XCD b % 8 and takes group (b % 8) * xcd_band + b / 8: the cache lines two neighbouring segments share (a
+    // segment is 248 pixels: 992 B, 7.75 lines) and the halo rows of two neighbouring group rows are then fetched by ONE L2, and
+    // every XCD gets the same number of groups to within one.
     int xcd_band, group_rows;
 };
 

@@ -8,6 +8,8 @@ import torch
 import bench
 import niftymatch_amd as nm
 dev = torch.device("cuda:0")
+if os.environ.get("KSITE_TALL_MIN"):                # unit groups per launch from which detection takes its tall groups
+    nm.set_detect_tall_min(int(os.environ["KSITE_TALL_MIN"]))
 what = sys.argv[1] if len(sys.argv) > 1 else "describe"
 site = {"describe": nm.PROF_DESCRIBE, "orient": nm.PROF_ORIENT, "detect": nm.PROF_DETECT_O0, "pyramid": nm.PROF_PYRAMID_O0}[what]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
