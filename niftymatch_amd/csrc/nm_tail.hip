@@ -611,7 +611,12 @@ int nm_launch_tail(const NmTailArgs &a, hipStream_t stream)
     // more than one per CU; a workgroup that waits for a counter still holds its CU's LDS
     const int total = a.n * a.items_per_frame;
     const int widest = a.seg[0].per_frame + (a.n_seg > 1 ? a.seg[1].per_frame / 2 : 0);
-    const int grid = std::max(1, std::min(std::min(total, nm_cu_count()), a.n * widest));
+    // ... and never more than 3/8 of the CUs: a tail workgroup owns its CU (1 024 threads x 128 registers: the whole register file),
+    // so what runs BESIDE the launch -- octave T - 1's detection, then orientation + descriptors of the large octaves -- has only the
+    // CUs it leaves. Round 6, one 1080p pair at batch 1 (two frames: 216 workgroups uncapped), us per pair at a cap of
+    // none / 192 / 160 / 128 / 96 / 64 / 48 / 32: 541 / 532 / 524 / 515 / 509 / 506 / 519 / 584; one frame (108 uncapped) at
+    // none / 96 / 64 / 48: 270 / 268 / 276 / 288 (profiles/r06_zz_tail_grid_cap.txt).
+    const int grid = std::max(1, std::min(std::min(std::min(total, nm_cu_count()), a.n * widest), nm_cu_count() * 3 / 8));
     hipLaunchKernelGGL(tail_kernel, dim3(grid), dim3(NT), a.lds_bytes + NM_TAIL_LDS_CTRL, stream, a);
     NM_LAUNCH_CHECK();
     return 0;

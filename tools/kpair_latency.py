@@ -12,7 +12,11 @@ a = [nm.SiftArena(bench.W, bench.H, bench.CAP, device=dev) for _ in range(2)]
 ws = nm.MatchBatchDevWorkspace(1, bench.CAP, bench.CAP, dev)
 res = torch.full((bench.CAP,), -1, dtype=torch.int32, device=dev)
 s = torch.cuda.Stream()
+single = len(sys.argv) > 1 and sys.argv[1] == "frame"        # one single-frame call instead of the pair
 def pair():
+    if single:
+        a[0].detect_describe(f[0])
+        return
     nm.detect_describe_batch(a, f)
     nm.sift_match_batch_dev([a[0].desc], [a[0].num_items], [a[1].desc], [a[1].num_items], [res], 0.8, workspace=ws)
 with torch.cuda.stream(s):
@@ -24,5 +28,5 @@ with torch.cuda.stream(s):
         pair()
     s.synchronize()
     us = (time.perf_counter() - t0) / 300 * 1e6
-print("pair %s: %.1f us (%d + %d keypoints)" % (" ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items()) if k.startswith("NM_") and k != "NM_BENCH_DETAIL"), us,
+print(("frame" if single else "pair") + " %s: %.1f us (%d + %d keypoints)" % (" ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items()) if k.startswith("NM_") and k != "NM_BENCH_DETAIL"), us,
                                                   int(a[0].num_items.item()), int(a[1].num_items.item())))
