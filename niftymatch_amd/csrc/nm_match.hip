@@ -425,11 +425,22 @@ __global__ __launch_bounds__(1024) void nbmax_kernel(MatchBatch bt)
     }
     // +inf as soon as one candidate norm is not a finite number below NORM_LIMIT (fmax would drop a NaN): the finalize
     // pass then sends EVERY row of the pair to the exact fallback, which is the reference's own scan
+    // (eight loads of either array in flight per thread: the kernel is ONE workgroup per pair, i.e. a chain of memory round trips;
+    // with one element per trip it took 9 us of a 127 us single-pair match)
     float m = 0.f, mr = 0.f;
-    for (int i = threadIdx.x; i < nB; i += 1024) {
-        const float v = c.nb[i];
-        m = (v < NORM_LIMIT) ? __builtin_fmaxf(m, v) : __builtin_inff();
-        if (c.rb) { const float e = c.rb[i]; mr = (e < NORM_LIMIT) ? __builtin_fmaxf(mr, e) : __builtin_inff(); }
+    for (int i0 = threadIdx.x; i0 < nB; i0 += 8 * 1024) {
+        float v[8], e[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k * 1024;
+            v[k] = (i < nB) ? c.nb[i] : 0.f;
+            e[k] = (c.rb && i < nB) ? c.rb[i] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            m = (v[k] < NORM_LIMIT) ? __builtin_fmaxf(m, v[k]) : __builtin_inff();
+            mr = (e[k] < NORM_LIMIT) ? __builtin_fmaxf(mr, e[k]) : __builtin_inff();
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { m = __builtin_fmaxf(m, __shfl_xor(m, d)); mr = __builtin_fmaxf(mr, __shfl_xor(mr, d)); }
