@@ -174,7 +174,9 @@ __device__ __forceinline__ int orient_peaks(const OriSamples &o, float &th0, flo
 
     const int hb = lane < 36 ? lane : lane < 43 ? lane - 36 : lane >= 57 ? lane - 28 : -1;
     float h = 0.f;                                // partials in strip order
-    if (hb >= 0) {                                // h = ((row[0] + row[1]) + row[2]) + ... + row[62], reads 9 at a time
+    // (reads 9 at a time. Round 6, measured: all 63 reads issued before the first add -- 106 registers, the launch has 128 -- is
+    // 1 % SLOWER, five alternations: profiles/r06_zz_orient_sum63.txt)
+    if (hb >= 0) {                                // h = ((row[0] + row[1]) + row[2]) + ... + row[62]
         const float *row = part + hb * ORI_PITCH;
 #pragma unroll
         for (int g = 0; g < 7; ++g) {
