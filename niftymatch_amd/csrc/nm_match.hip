@@ -1207,6 +1207,9 @@ __global__ __launch_bounds__(512, 1) void match_coarse_kernel(MatchBatch bt)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (lds_void *)(ldsb + SLOT0 + b * SLOTB + wave_u * 1024), 16, lane * 16,
                                                      tile * SLOTB + wave_u * 1024, 0, 0);
     };
+    // (Round 6, measured: a tile requested by FOUR of the eight waves, eight pieces each -- waves 0-3, or waves 4-7, the ones the
+    // stamps show on the critical path -- is 0.8 % slower either way: 603-608 against 599 us per 16-pair launch, three alternations.
+    // profiles/r06_zz_coarse_dma_waves.txt)
     auto dma_tile = [&](rsrc_t rsB, rsrc_t rsS, int tile, int b) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) dma_piece(rsB, tile, b, t);
