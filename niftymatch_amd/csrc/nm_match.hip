@@ -697,7 +697,11 @@ __device__ __forceinline__ void mfma_half_bf16(f32x16 &acc0, f32x16 &acc1, const
 // per row from the residual norms (prep_kernel<2>); the rows it cannot prove are screened again by the bf16x3 kernel.
 // tb = this lane's candidate row of group 0 in the tile image (256-byte rows, 16-byte chunks XOR-swizzled by row & 15);
 // foff[t] = byte offset of the lane's chunk of k-step t; group 1 = + 32 rows. qf[s] = the query's k-step s (k = 16 s + 8 h ..+7).
+#ifdef NM_STUB_NOMFMA                           // diagnostic builds only (see f16_kstep): the instruction becomes an assembler comment
+#define NM_MFMA_H "; v_mfma_f32_32x32x16_f16 "
+#else
 #define NM_MFMA_H "v_mfma_f32_32x32x16_f16 "
+#endif
 // The coarse pass folds once per TILE ITERATION: the keys of the two groups selected in it (2 n - 1, selected beside the first
 // group of tile n, and 2 n) share one pair of running keys, told apart by a sixth slot bit; 2^-17 instead of 2^-18 of a
 // value is dropped, which the finalize constants cover.
@@ -722,31 +726,6 @@ __device__ __forceinline__ void f16_kstep(f32x16 &acc0, f32x16 &acc1, const u32x
     constexpr bool SELECT = false;
 #else
     constexpr bool SELECT = SELECT_;
-#endif
-#ifdef NM_STUB_NOMFMA
-    if (SELECT) {
-        int k;
-        const int mask = ~((1 << COARSE_SLOT_BITS) - 1);
-        asm volatile("v_and_or_b32 %4, %8, %12, %13\n\t"
-                     "v_med3_i32 %3, %2, %3, %4\n\t"
-                     "v_min_i32 %2, %2, %4\n\t"
-                     "v_and_or_b32 %4, %9, %12, %14\n\t"
-                     "v_med3_i32 %3, %2, %3, %4\n\t"
-                     "v_min_i32 %2, %2, %4\n\t"
-                     "v_and_or_b32 %4, %10, %12, %15\n\t"
-                     "v_med3_i32 %3, %2, %3, %4\n\t"
-                     "v_min_i32 %2, %2, %4\n\t"
-                     "v_and_or_b32 %4, %11, %12, %16\n\t"
-                     "v_med3_i32 %3, %2, %3, %4\n\t"
-                     "v_min_i32 %2, %2, %4"
-                     : "+v"(acc0), "+v"(acc1), "+v"(g1), "+v"(g2), "=&v"(k)
-                     : "v"(h0), "v"(h1), "v"(qh), "v"(p0), "v"(p1), "v"(p2), "v"(p3), "s"(mask),
-                       "n"(E0), "n"(E0 + 1), "n"(E0 + 2), "n"(E0 + 3)
-                     : "memory");
-    } else {
-        asm volatile("" : "+v"(acc0), "+v"(acc1) : "v"(h0), "v"(h1), "v"(qh) : "memory");
-    }
-    return;
 #endif
     if (SELECT) {
         int k;
