@@ -140,6 +140,34 @@ def test_batched_pair_call_captures_into_hip_graph(nm, oracle, cuda):
         _eq(x.desc[:n], ref["desc"], "batched call through a HIP graph")
 
 
+def test_many_frame_call_captures_into_hip_graph(nm, oracle, cuda):
+    """A call of 32 frames runs its scale-space chain as two half batches on two streams (nm_frame.hip: the second half on the
+    description stream, forked off the caller's stream, with one edge per octave into the detection stream): the fork / join
+    shape must capture into a HIP graph and replay, on other frames, to the oracle's results."""
+    import torch
+    w, h, cap, n = 160, 120, 1024, 32
+    f = [H.blurred_frame(300 + i, w, h) for i in range(n + 2)]
+    a = [nm.SiftArena(w, h, cap) for _ in range(n)]
+    d = [_t(f[i], cuda) for i in range(n)]
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        nm.detect_describe_batch(a, d)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        nm.detect_describe_batch(a, d)
+    d[0].copy_(_t(f[n], cuda)); d[n - 1].copy_(_t(f[n + 1], cuda))        # one frame of either half replaced
+    for x in a:
+        x.desc.zero_(); x.num_items.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for i, src in ((0, n), (1, 1), (n // 2 - 1, n // 2 - 1), (n // 2, n // 2), (n - 2, n - 2), (n - 1, n + 1)):
+        ref = oracle.sift_detect_describe(f[src], cap)
+        k = int(a[i].num_items.item())
+        assert k == ref["n"] and k > 0
+        _eq(a[i].desc[:k], ref["desc"], "frame %d of a 32-frame call through a HIP graph" % i)
+
+
 def test_calls_enqueued_from_several_host_threads(nm, oracle, cuda):
     """bench.py issues its detect calls from a thread pool (the ABI is re-entrant; an arena belongs to one call at a
     time): results stay bit-exact."""
