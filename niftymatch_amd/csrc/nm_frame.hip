@@ -43,7 +43,6 @@ struct nm_sift_arena {
     hipStream_t side;          // detection / compaction stream forked off the caller's stream
     hipStream_t desc;          // orientation + descriptors of the large octaves, beside the small octaves' pyramids / detection
     hipEvent_t ev_pyr[20], ev_join, ev_det, ev_desc;
-    hipEvent_t ev_pyr2[20], ev_fork;       // the second half of a split chain (nm_sift_detect_describe_batch)
     float *grad[20];           // per octave: 3 float2 planes
     size_t grad_off[20];       // grad[o] = grad[0] + grad_off[o]: the gradient planes of all octaves are one block
     size_t plane_stride[20];   // floats between consecutive levels / DoG planes of an octave (one block per octave)
@@ -150,8 +149,7 @@ int nm_sift_arena_create(int width, int height, int capacity, nm_sift_arena **ou
     a->mask = nullptr;
     a->device = -1;
     (void)hipGetDevice(&a->device);
-    for (int o = 0; o < 20; ++o) { a->ev_pyr[o] = nullptr; a->ev_pyr2[o] = nullptr; }
-    a->ev_fork = nullptr;
+    for (int o = 0; o < 20; ++o) a->ev_pyr[o] = nullptr;
     a->params = SiftParams(width, height);
     a->npix = (size_t)width * height;
     a->bytes = 0;
@@ -192,8 +190,6 @@ int nm_sift_arena_create(int width, int height, int capacity, nm_sift_arena **ou
         for (int o = 0; o < P._num_octaves; ++o) a->grad[o] = blk + a->grad_off[o];
     }
     for (int o = 0; !rc && o < P._num_octaves; ++o) rc = (int)hipEventCreateWithFlags(&a->ev_pyr[o], hipEventDisableTiming);
-    for (int o = 0; !rc && o < P._num_octaves; ++o) rc = (int)hipEventCreateWithFlags(&a->ev_pyr2[o], hipEventDisableTiming);
-    if (!rc) rc = (int)hipEventCreateWithFlags(&a->ev_fork, hipEventDisableTiming);
     if (!rc) rc = (int)hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming);
     if (!rc) rc = (int)hipEventCreateWithFlags(&a->ev_det, hipEventDisableTiming);
     if (!rc) rc = (int)hipEventCreateWithFlags(&a->ev_desc, hipEventDisableTiming);
@@ -258,12 +254,9 @@ void nm_sift_arena_destroy(nm_sift_arena *a)
     if (a->desc) { (void)hipStreamSynchronize(a->desc); (void)hipStreamDestroy(a->desc); }
     if (a->ev_det) (void)hipEventDestroy(a->ev_det);
     if (a->ev_desc) (void)hipEventDestroy(a->ev_desc);
-    for (int o = 0; o < 20; ++o) {
+    for (int o = 0; o < 20; ++o)
         if (a->ev_pyr[o]) (void)hipEventDestroy(a->ev_pyr[o]);
-        if (a->ev_pyr2[o]) (void)hipEventDestroy(a->ev_pyr2[o]);
-    }
     if (a->ev_join) (void)hipEventDestroy(a->ev_join);
-    if (a->ev_fork) (void)hipEventDestroy(a->ev_fork);
     for (void *p : a->allocs) (void)hipFree(p);
     delete a;
 }
@@ -389,9 +382,9 @@ float *nm_sift_arena_dog(nm_sift_arena *a, int d) { return (a && d >= 0 && d < 5
 float *nm_sift_arena_grad(nm_sift_arena *a) { return a ? a->grad[0] : nullptr; }
 
 static int octave_pyramid(nm_sift_arena *const *as, int n, int o, int ow, int oh, bool store_top, bool decimate,
-                          hipStream_t st, bool write_dog = true, bool per_octave = false, bool write_grad = true, bool prof = true)
+                          hipStream_t st, bool write_dog = true, bool per_octave = false, bool write_grad = true)
 {
-    if (o == 0 && prof) nm_prof_begin(NM_PROF_PYRAMID_O0, st);
+    if (o == 0) nm_prof_begin(NM_PROF_PYRAMID_O0, st);
     const size_t plane = (size_t)ow * oh;
     int rc = 0;
     for (int i = 1; i < 6 && !rc; ++i) {
@@ -412,7 +405,7 @@ static int octave_pyramid(nm_sift_arena *const *as, int n, int o, int ow, int oh
         }
         rc = nm_launch_convolve_batch(b, ow, oh, as[0]->taps[i - 1], as[0]->radii[i - 1], st);
     }
-    if (o == 0 && prof) nm_prof_end(NM_PROF_PYRAMID_O0, st);
+    if (o == 0) nm_prof_end(NM_PROF_PYRAMID_O0, st);
     return rc;
 }
 
@@ -451,28 +444,11 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
     hipStream_t st = nm_stream(stream);
     const SiftParams &P = as[0]->params;
     const int W = as[0]->width, H = as[0]->height;
-    // Calls of many frames: the scale-space chain runs as TWO half batches, the second on the description stream (idle until
-    // every octave is detected). Each of its launches still fills the chip, and the latency-bound launches of the small octaves --
-    // two dozen of 6-25 us -- of one half run beside the other half's (two 32-frame chains on two streams: 3 163 us, one 64-frame
-    // chain: 3 290, profiles/r06_zz_chain_two_streams.txt). Detection, orientation and description stay launches over all frames.
-    static const int chain_split_cfg = [] { const char *e = getenv("NM_FRAME_CHAIN_SPLIT"); return e ? atoi(e) : 1; }();
-    hipStream_t dstr = as[0]->desc;
-    const int n1 = (chain_split_cfg && n >= 32 && !frame_driver_writes_dog()) ? n / 2 : n;      // frames of the first half
-    bool forked_desc = false;
-    if (n1 < n) {
-        NM_RETURN_IF(hipEventRecord(as[0]->ev_fork, st));
-        NM_RETURN_IF(hipStreamWaitEvent(dstr, as[0]->ev_fork, 0));
-        forked_desc = true;
-    }
-    int rc = 0;
-    for (int half = 0; half < (n1 < n ? 2 : 1) && !rc; ++half) {
-        const int f0 = half ? n1 : 0, nh = half ? n - n1 : n1;
-        NmConvBatch base{};
-        base.n = nh;
-        for (int f = 0; f < nh; ++f) { base.result[f] = as[f0 + f]->level[0]; base.image[f] = gray[f0 + f]; }
-        rc = nm_launch_convolve_batch(base, W, H, as[0]->taps_base, as[0]->base_radius, half ? dstr : st);
-    }
-    if (rc && !forked_desc) return rc;
+    NmConvBatch base{};
+    base.n = n;
+    for (int f = 0; f < n; ++f) { base.result[f] = as[f]->level[0]; base.image[f] = gray[f]; }
+    int rc = nm_launch_convolve_batch(base, W, H, as[0]->taps_base, as[0]->base_radius, st);
+    if (rc) return rc;
 
     NmDescribeArgs da{};
     for (int o = 0; o < 20; ++o) da.grad_off[o] = as[0]->grad_off[o];      // same geometry => same offsets in every arena
@@ -486,7 +462,8 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
         da.desc[f] = desc[f]; da.x[f] = x[f]; da.y[f] = y[f];
     }
     hipStream_t side = as[0]->side;          // every detection / description launch covers all frames of the call
-    bool forked = false;
+    hipStream_t dstr = as[0]->desc;
+    bool forked = false, forked_desc = false;
     const bool dogs = frame_driver_writes_dog();
     // NM_FRAME_SPLIT_DESCRIBE=2 (experiment, off by default): octaves 0 and 1 hold ~98 % of a frame's keypoints; their
     // orientation + descriptor pass then starts as soon as octave 1 has been detected, on a stream of its own, beside the
@@ -527,7 +504,6 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
         tail_args.state = as[0]->tail_state;
     }
     auto body = [&]() -> int {
-        if (rc) return rc;                         // the base blur failed behind a fork: the joins below still run
         for (int o = 0; o < P._num_octaves; ++o) {
             const int ow = W >> o, oh = H >> o;
             const float xper = (float)std::pow(2.0, o);
@@ -536,15 +512,9 @@ int nm_sift_detect_describe_batch(nm_sift_arena *const *as, int n, const float *
                 da.geom[o].ow = ow; da.geom[o].oh = oh; da.geom[o].xper = xper;
                 continue;
             }
-            int e = octave_pyramid(as, n1, o, ow, oh, !dogs, o + 1 < P._num_octaves, st, dogs, true);
+            int e = octave_pyramid(as, n, o, ow, oh, !dogs, o + 1 < P._num_octaves, st, dogs, true);
             if (e) return e;
             NM_RETURN_IF(hipEventRecord(as[0]->ev_pyr[o], st));
-            if (n1 < n) {
-                e = octave_pyramid(as + n1, n - n1, o, ow, oh, !dogs, o + 1 < P._num_octaves, dstr, dogs, true, true, false);
-                if (e) return e;
-                NM_RETURN_IF(hipEventRecord(as[0]->ev_pyr2[o], dstr));
-                NM_RETURN_IF(hipStreamWaitEvent(side, as[0]->ev_pyr2[o], 0));
-            }
             if (use_tail && o + 1 == first_tail) {
                 // The tail launch (levels, gradients, detection of the octaves >= T) goes to the CALLER's stream, straight behind
                 // the pyramid of octave T - 1 whose decimated level 3 seeds it -- issued BEFORE this octave's detection launches

@@ -141,9 +141,8 @@ def test_batched_pair_call_captures_into_hip_graph(nm, oracle, cuda):
 
 
 def test_many_frame_call_captures_into_hip_graph(nm, oracle, cuda):
-    """A call of 32 frames runs its scale-space chain as two half batches on two streams (nm_frame.hip: the second half on the
-    description stream, forked off the caller's stream, with one edge per octave into the detection stream): the fork / join
-    shape must capture into a HIP graph and replay, on other frames, to the oracle's results."""
+    """A call of 32 frames (no octave tail: the per-octave launches over all frames, detection on the side stream) captures into a
+    HIP graph and replays, on other frames, to the oracle's results."""
     import torch
     w, h, cap, n = 160, 120, 1024, 32
     f = [H.blurred_frame(300 + i, w, h) for i in range(n + 2)]
