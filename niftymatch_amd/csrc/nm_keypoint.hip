@@ -354,7 +354,8 @@ int nm_launch_detect_octave(const NmDetectArgs &d_in, const NmScanArgs &s, const
     const long tall_groups = (long)d.nseg * nm_divup(d.oh, DET_ROWS_TALL) * d.n;
     if (d.from_levels && tall_groups >= g_tall_min.load(std::memory_order_relaxed)) {
         auto cost = [&](int rows) { return nm_divup(nm_divup(d.oh, rows) * d.nseg, 8) * (rows + 2); };
-        if (cost(DET_ROWS_TALL2) < cost(DET_ROWS_TALL)) launch_detect_rows<DET_ROWS_TALL2>(d, bands, stream);
+        static const bool rows2 = [] { const char *e = getenv("NM_DETECT_ROWS2"); return e ? atoi(e) != 0 : true; }();
+        if (rows2 && cost(DET_ROWS_TALL2) < cost(DET_ROWS_TALL)) launch_detect_rows<DET_ROWS_TALL2>(d, bands, stream);
         else launch_detect_rows<DET_ROWS_TALL>(d, bands, stream);
     } else {
         launch_detect_rows<DET_ROWS>(d, bands, stream);
